@@ -1,0 +1,178 @@
+"""Weight container ("ISBW" blob) and the deterministic weight generator.
+
+The reference ships no weights (``modules/ar/modules/raws/DISC.pth`` and the MetrABS
+engines are git-ignored: reference ``.gitignore:9-24,45``), so parity is established on
+deterministically generated tensors that can be loaded BOTH into the reference's own
+``TRXOS`` (``modules/ar/utils/model.py:219``) and into the HIP library.
+
+Blob layout (little endian), consumed by ``isb_ar_load_weights`` / ``isb_hpe_load_weights``
+(``include/isbfsar.h``):
+
+    char[4]  magic  = "ISBW"
+    u32      version = 1
+    u32      n_tensors
+    u32      reserved
+    n_tensors x { char[96] name (NUL padded); u32 ndim; u32 dims[4]; u64 offset; u64 nbytes }
+    payload  fp32 tensors, each 64-byte aligned, offsets relative to blob start
+
+The generator is counter based (splitmix64 over ``fnv1a(name) ^ seed + index``) so that any
+tensor can be regenerated anywhere without torch's RNG or a fixture file.
+"""
+from __future__ import annotations
+
+import struct
+from collections import OrderedDict
+from typing import Dict, Iterable, Mapping, Tuple
+
+import numpy as np
+
+MAGIC = b"ISBW"
+VERSION = 1
+_NAME_LEN = 96
+_ENTRY = struct.Struct("<96sI4IQQ")
+_HEADER = struct.Struct("<4sIII")
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def fnv1a64(name: str) -> int:
+    h = 0xCBF29CE484222325
+    for b in name.encode("utf-8"):
+        h ^= b
+        h = (h * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    """splitmix64 finaliser on a uint64 array (wrapping arithmetic)."""
+    with np.errstate(over="ignore"):
+        z = x + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def uniform01(name: str, n: int, seed: int = 0) -> np.ndarray:
+    """n float64 values in [0,1), a pure function of (name, seed, index)."""
+    base = np.uint64((fnv1a64(name) ^ (seed * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF)
+    with np.errstate(over="ignore"):
+        ctr = base + np.arange(n, dtype=np.uint64) * np.uint64(0xD1342543DE82EF95)
+    z = _splitmix64(ctr)
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+
+
+def uniform(name: str, shape: Tuple[int, ...], lo: float, hi: float, seed: int = 0) -> np.ndarray:
+    n = int(np.prod(shape)) if len(shape) else 1
+    u = uniform01(name, n, seed)
+    return (lo + (hi - lo) * u).astype(np.float32).reshape(shape)
+
+
+# --------------------------------------------------------------------------------------
+# AR (TRXOS skeleton branch) state dict. Key names/shapes follow the reference modules:
+#   MLP                      modules/ar/utils/model.py:164-180
+#   TemporalCrossTransformer modules/ar/utils/model.py:31-57
+#   Discriminator            modules/ar/utils/model.py:183-192, sized at :283-285
+# --------------------------------------------------------------------------------------
+def ar_state_shapes(seq_len: int, n_joints: int, d_in: int = 256, d_out: int = 128) -> "OrderedDict[str, Tuple[int, ...]]":
+    L, J = seq_len, n_joints
+    T = L * (L - 1) // 2
+    s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    s["features_extractor.sk.fc1.weight"] = (6 * J, 3 * J)
+    s["features_extractor.sk.fc1.bias"] = (6 * J,)
+    s["features_extractor.sk.fc2.weight"] = (d_in, 6 * J)
+    s["features_extractor.sk.fc2.bias"] = (d_in,)
+    s["transformers.0.k_linear.weight"] = (d_out, 2 * d_in)
+    s["transformers.0.k_linear.bias"] = (d_out,)
+    s["transformers.0.v_linear.weight"] = (d_out, 2 * d_in)
+    s["transformers.0.v_linear.bias"] = (d_out,)
+    s["transformers.0.norm_k.weight"] = (d_out,)
+    s["transformers.0.norm_k.bias"] = (d_out,)
+    s["discriminator.dimensionality_reduction.weight"] = (L, d_out)
+    s["discriminator.dimensionality_reduction.bias"] = (L,)
+    s["discriminator.fc1.weight"] = (256, T * L)
+    s["discriminator.fc1.bias"] = (256,)
+    s["discriminator.fc2.weight"] = (64, 256)
+    s["discriminator.fc2.bias"] = (64,)
+    s["discriminator.fc3.weight"] = (1, 64)
+    s["discriminator.fc3.bias"] = (1,)
+    return s
+
+
+def make_ar_state(seq_len: int, n_joints: int, seed: int = 0, gain: float = 1.0) -> "OrderedDict[str, np.ndarray]":
+    """Deterministic TRXOS (skeleton) weights: U(-g/sqrt(fan_in), g/sqrt(fan_in)) like
+    torch's Linear default; LayerNorm gamma in [0.8,1.2], beta in [-0.1,0.1] so that the
+    affine part of ``norm_k`` (model.py:46) is exercised."""
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    shapes = ar_state_shapes(seq_len, n_joints)
+    for name, shape in shapes.items():
+        if name.endswith("norm_k.weight"):
+            out[name] = uniform(name, shape, 0.8, 1.2, seed)
+        elif name.endswith("norm_k.bias"):
+            out[name] = uniform(name, shape, -0.1, 0.1, seed)
+        else:
+            # bias shares its Linear's fan_in (torch.nn.Linear.reset_parameters)
+            wshape = shapes[name[:-len("bias")] + "weight"] if name.endswith(".bias") else shape
+            fan_in = wshape[-1]
+            b = gain / np.sqrt(float(fan_in))
+            out[name] = uniform(name, shape, -b, b, seed)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# blob (de)serialisation
+# --------------------------------------------------------------------------------------
+def pack_blob(tensors: Mapping[str, np.ndarray]) -> bytes:
+    names = list(tensors.keys())
+    n = len(names)
+    table_bytes = _HEADER.size + n * _ENTRY.size
+    off = (table_bytes + 63) // 64 * 64
+    entries = []
+    payload = []
+    for name in names:
+        a = np.ascontiguousarray(tensors[name], dtype=np.float32)
+        if a.ndim > 4:
+            raise ValueError(f"{name}: ndim {a.ndim} > 4")
+        if len(name.encode()) >= _NAME_LEN:
+            raise ValueError(f"tensor name too long: {name}")
+        dims = list(a.shape) + [1] * (4 - a.ndim)
+        entries.append(_ENTRY.pack(name.encode(), a.ndim, *dims, off, a.nbytes))
+        payload.append((off, a.tobytes()))
+        off = (off + a.nbytes + 63) // 64 * 64
+    buf = bytearray(off)
+    _HEADER.pack_into(buf, 0, MAGIC, VERSION, n, 0)
+    p = _HEADER.size
+    for e in entries:
+        buf[p:p + _ENTRY.size] = e
+        p += _ENTRY.size
+    for o, b in payload:
+        buf[o:o + len(b)] = b
+    return bytes(buf)
+
+
+def unpack_blob(blob: bytes) -> "OrderedDict[str, np.ndarray]":
+    magic, ver, n, _ = _HEADER.unpack_from(blob, 0)
+    if magic != MAGIC or ver != VERSION:
+        raise ValueError("not an ISBW v1 blob")
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    p = _HEADER.size
+    for _ in range(n):
+        name, ndim, d0, d1, d2, d3, off, nbytes = _ENTRY.unpack_from(blob, p)
+        p += _ENTRY.size
+        shape = (d0, d1, d2, d3)[:ndim]
+        a = np.frombuffer(blob, dtype=np.float32, count=nbytes // 4, offset=off).reshape(shape)
+        out[name.rstrip(b"\0").decode()] = a
+    return out
+
+
+def state_from_torch(state_dict: Mapping[str, "object"], keys: Iterable[str] | None = None) -> Dict[str, np.ndarray]:
+    """Convert a torch ``state_dict`` (e.g. the reference's ``DISC.pth['model_state_dict']``,
+    ``modules/ar/ar.py:17-19``) into the numpy mapping ``pack_blob`` takes. ``.module`` infixes
+    left by ``DataParallel`` are stripped exactly as ``ar.py:18`` does."""
+    out = {}
+    for k, v in state_dict.items():
+        k2 = k.replace(".module", "")
+        if keys is not None and k2 not in keys:
+            continue
+        out[k2] = np.asarray(v.detach().cpu().numpy() if hasattr(v, "detach") else v, dtype=np.float32)
+    return out

@@ -1,0 +1,171 @@
+"""Golden-vector generator -- runs ONLY in the build container (needs /root/reference).
+
+Imports the reference's own classes (never copies their source), loads OUR deterministic
+weights (``isbfsar_amd.weights``) into them, runs them on OUR seeded synthetic inputs
+(``isbfsar_amd.synth``) and stores inputs' digests + outputs as small ``.npz`` fixtures under
+``tests/golden``. The fixtures are data; this script is what made them.
+
+    python oracle/gen_golden.py            # regenerates every fixture
+
+Reference entry points exercised:
+    modules/ar/utils/model.py:219  TRXOS            (torchvision stubbed: only the RGB branch uses it)
+    modules/hpe/utils/misc.py:243  homography       (imported unmodified)          [hpe goldens]
+    modules/hpe/hpe.py:48          HumanPoseEstimator.estimate through a fake Runner [hpe goldens]
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.dont_write_bytecode = True
+sys.path.insert(0, ROOT)
+
+from isbfsar_amd import synth, weights  # noqa: E402
+
+
+def digest(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _stub_torchvision():
+    import torch
+
+    tv = types.ModuleType("torchvision")
+    tvm = types.ModuleType("torchvision.models")
+    tvr = types.ModuleType("torchvision.models.resnet")
+    tvm.resnet50 = None
+    tvm.ResNet = torch.nn.Module            # only subclassed at class-definition time (model.py:221)
+    tvr.Bottleneck = None
+    tvr.resnet18 = None
+    tv.models = tvm
+    tvm.resnet = tvr
+    sys.modules.update({"torchvision": tv, "torchvision.models": tvm, "torchvision.models.resnet": tvr})
+
+
+def reference_trxos(seq_len: int, n_joints: int, way: int, state):
+    """Instantiate the reference's TRXOS on CPU with our weights."""
+    import torch
+
+    _stub_torchvision()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        from modules.ar.utils.model import TRXOS
+        from utils.params import TRXConfig
+    finally:
+        os.chdir(cwd)
+    args = TRXConfig()
+    args.device = "cpu"
+    args.seq_len, args.n_joints, args.way = seq_len, n_joints, way
+    net = TRXOS(args).eval()
+    sd = net.state_dict()
+    new = {}
+    for k, v in sd.items():
+        if k in state:
+            assert tuple(v.shape) == state[k].shape, (k, v.shape, state[k].shape)
+            new[k] = torch.from_numpy(np.array(state[k]))
+        else:
+            new[k] = v                         # pe buffer, unused post_resnet
+    net.load_state_dict(new)
+    return net
+
+
+def gen_ar(tag: str, L: int, J: int, way: int, B: int, seed: int, keep_intermediates: bool):
+    import torch
+
+    state = weights.make_ar_state(L, J, seed=seed)
+    net = reference_trxos(L, J, way, state)
+    ss = synth.skeleton_windows(way, L, J, seed=seed + 100)
+    q = synth.skeleton_windows(B, L, J, seed=seed + 200)
+    labels = torch.arange(way, dtype=torch.int32)[None]
+    outs = {"logits": [], "is_true": [], "qfeat": []}
+    with torch.no_grad():
+        # the reference's batch dimension carries its own copy of the support set (model.py:59-63)
+        for b in range(B):
+            o = net({"sk": torch.from_numpy(ss)[None]}, labels, {"sk": torch.from_numpy(q[b:b + 1])})
+            outs["logits"].append(o["logits"].numpy()[0])
+            outs["is_true"].append(o["is_true"].numpy()[0])
+            sf = o["support_features"].numpy()[0]
+            if b == 0:
+                # G3: cached-feature call (ar.py:56-61) equals the raw-pose call
+                o2 = net(None, labels, {"sk": torch.from_numpy(q[b:b + 1])}, ss_features=o["support_features"])
+                assert np.array_equal(o2["logits"].numpy(), o["logits"].numpy())
+                assert np.array_equal(o2["is_true"].numpy(), o["is_true"].numpy())
+                qf = net.features_extractor["sk"](torch.from_numpy(q[b:b + 1])).numpy()[0]
+                outs["qfeat"] = qf
+                tr = net.transformers[0]
+                if keep_intermediates:
+                    # Kq/Vq of query 0 as the reference computes them (model.py:65-84)
+                    x = tr.pe(torch.from_numpy(qf)[None, None])
+                    tq = torch.stack([torch.index_select(x, -2, p).reshape(1, 1, -1) for p in tr.tuples], dim=-2)
+                    outs["kq0"] = tr.norm_k(tr.k_linear(tq)).numpy()[0, 0]
+                    outs["vq0"] = tr.v_linear(tq).numpy()[0, 0]
+                    outs["proto0_c0"] = o["prototypes"][0].numpy()[0, 0]
+    rec = dict(
+        L=L, J=J, way=way, B=B, seed=seed,
+        ss_digest=digest(ss), q_digest=digest(q),
+        logits=np.stack(outs["logits"]), is_true=np.stack(outs["is_true"]),
+        qfeat0=outs["qfeat"], support_features_c0=sf[0], support_features_digest=digest(sf),
+        support_features_sum=np.float64(sf.astype(np.float64).sum()),
+    )
+    for k in ("kq0", "vq0", "proto0_c0"):
+        if k in outs:
+            rec[k] = outs[k]
+    if L * J * way <= 16 * 30 * 5:
+        rec["ss"] = ss
+        rec["q"] = q
+    np.savez_compressed(os.path.join(OUT, f"ar_{tag}.npz"), **rec)
+    print(f"ar_{tag}: logits[0,:5]={rec['logits'][0, :5]} is_true={rec['is_true'].ravel()[:4]}")
+
+
+def gen_ar_stream(tag: str, L: int, J: int, way: int, n_frames: int, seed: int):
+    """G7: the per-call outputs ActionRecognizer.inference (ar.py:30-84) produces for a frame
+    stream; the wrapper itself needs CUDA + an absent checkpoint (ar.py:17,20), so TRXOS is driven
+    with exactly the window contents the wrapper would assemble (ar.py:42-50)."""
+    import torch
+
+    state = weights.make_ar_state(L, J, seed=seed)
+    net = reference_trxos(L, J, way, state)
+    ss = synth.skeleton_windows(way, L, J, seed=seed + 100)
+    stream = synth.skeleton_windows(1, n_frames, J, seed=seed + 300)[0]   # [n_frames, 3J]
+    labels = torch.arange(way, dtype=torch.int32)[None]
+    probs, is_true = [], []
+    with torch.no_grad():
+        for t in range(L - 1, n_frames):
+            win = torch.from_numpy(stream[t - L + 1:t + 1])[None]
+            o = net({"sk": torch.from_numpy(ss)[None]}, labels, {"sk": win})
+            probs.append(torch.softmax(o["logits"].squeeze(0), dim=0).numpy())   # ar.py:77
+            is_true.append(o["is_true"].squeeze(0).numpy())                      # ar.py:78
+    np.savez_compressed(os.path.join(OUT, f"ar_stream_{tag}.npz"), L=L, J=J, way=way, seed=seed,
+                        n_frames=n_frames, stream_digest=digest(stream), ss_digest=digest(ss),
+                        probs=np.stack(probs), is_true=np.stack(is_true))
+    print(f"ar_stream_{tag}: {len(probs)} calls, probs[0]={probs[0]}")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    which = sys.argv[1:] or ["ar", "hpe"]
+    if "ar" in which:
+        gen_ar("ref_16_30_5", 16, 30, 5, B=3, seed=0, keep_intermediates=True)
+        gen_ar("bl_30_122_60", 30, 122, 60, B=2, seed=1, keep_intermediates=False)
+        gen_ar_stream("ref_16_30_5", 16, 30, 5, n_frames=20, seed=0)
+    if "hpe" in which:
+        try:
+            from gen_golden_hpe import gen_all
+        except ImportError:
+            sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+            from gen_golden_hpe import gen_all
+        gen_all(OUT)
+
+
+if __name__ == "__main__":
+    main()
