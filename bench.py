@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path (frame -> pose -> embedding -> match) on N MI355X of one node.
+
+    python bench.py --gpus N --steps K --warmup W [--workload pipeline|hpe|ar]
+
+One process per GPU (the driver launches N>1 through torch.distributed.run; RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* come from the environment, backend "nccl" = RCCL).  A step is one pass
+of the hot path over one batch of synthetic input already resident in HBM.  Units shard
+across ranks with no data-path collective (weak scaling: per-GPU batch fixed); the only
+collective is the all-gather of per-window results, inside the timed region for N>1.
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "bf16x3": 2500.0 / 3.0, "f32": 157.3}   # MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="auto", choices=["auto", "pipeline", "hpe", "ar"])
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (0 = the BASELINE config's)")
+    ap.add_argument("--way", type=int, default=60)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0)
+    return ap.parse_args()
+
+
+# --------------------------------------------------------------------------------------------
+# AR workload: BASELINE.json configs[2] -- B windows of 30 x 122 joints vs 60 classes
+# --------------------------------------------------------------------------------------------
+class ArWorkload:
+    name = "ar"
+    L, J = 30, 122
+
+    def __init__(self, args, rank, world, dev):
+        import torch
+        from isbfsar_amd import synth, weights
+        from isbfsar_amd.engine import ArEngine
+
+        self.torch = torch
+        self.way = args.way
+        self.B = args.batch or 1024
+        self.precision = args.precision
+        self.state = weights.make_ar_state(self.L, self.J, seed=1)
+        self.ss = synth.skeleton_windows(self.way, self.L, self.J, seed=101)
+        q = synth.skeleton_windows(self.B, self.L, self.J, seed=1000 + rank)
+        self.q_host = q
+        self.eng = ArEngine(self.L, self.J, self.way, device=dev, precision=self.precision, max_batch=min(self.B, 1024))
+        self.eng.load_weights(self.state)
+        self.eng.set_support(poses=self.ss)
+        self.q = torch.from_numpy(q).cuda(dev)
+        self.world = world
+        self.out = None
+
+    def units_per_step(self):
+        return self.B
+
+    def step(self):
+        logits, is_true, embed = self.eng.infer(self.q, want_embed=self.world > 1)
+        if self.world > 1:
+            import torch.distributed as dist
+            torch = self.torch
+            # one fused all-gather of the packed per-window record
+            rec = torch.cat([logits, is_true[:, None], embed.reshape(self.B, -1)], dim=1)
+            gathered = torch.empty((self.world * self.B, rec.shape[1]), dtype=rec.dtype, device=rec.device)
+            dist.all_gather_into_tensor(gathered, rec)
+            self.out = gathered
+        else:
+            self.out = (logits, is_true)
+
+    # algorithmic work of the dominant kernel (ar_proto, all classes): S and P contractions
+    def roofline(self, steps):
+        T = self.L * (self.L - 1) // 2
+        self.eng.profile(True)
+        for _ in range(steps):
+            self.step()
+        self.torch.cuda.synchronize()
+        ms, launches = self.eng.profile_read()
+        self.eng.profile(False)
+        chunk = min(self.B, 1024)
+        flops_per_launch = chunk * self.way * 2 * (2 * T * T * 128)     # S^T and P^T MACs x2
+        avg_s = ms / max(launches, 1) / 1e3
+        achieved = flops_per_launch / avg_s / 1e12
+        peak = MFMA_PEAK_TFLOPS[self.precision]
+        return {"bound": "mfma", "kernel": "ar_proto_kernel", "achieved": round(achieved, 2), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                "avg_launch_ms": round(ms / max(launches, 1), 4), "launches": int(launches)}
+
+    def cpu_baseline(self, sample):
+        from oracle.ar_oracle import TRXOSOracle
+        import torch
+        n = sample or 32
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        net = TRXOSOracle(self.state, self.L, self.J)
+        sf = net.mlp(self.ss)
+        net.forward(None, self.way, self.q_host[:2], ss_features=sf)   # warm-up
+        t0 = time.perf_counter()
+        net.forward(None, self.way, self.q_host[:n], ss_features=sf)
+        dt = time.perf_counter() - t0
+        return {"value": round(n / dt, 3), "unit": "windows/s", "cores": cores, "kind": "port",
+                "sample": f"{n} windows of {self.L}x{self.J} joints vs {self.way} classes, numpy oracle "
+                          f"(support features cached), {dt:.1f} s"}
+
+    def config(self, world):
+        return {"workload": "BASELINE configs[2]: AR embed + tuple cross-attention match + open-set score, "
+                            f"B={self.B} windows/GPU of {self.L}x{self.J} joints, way={self.way}",
+                "per_gpu_batch": self.B, "seq_len": self.L, "n_joints": self.J, "way": self.way,
+                "precision": self.precision, "parallelism": f"dp{world} (units sharded, one all-gather of results)"}
+
+    metric = "windows/sec (skeleton-window embed + few-shot match + open-set score)"
+    unit = "windows/s"
+
+
+def pick_workload(name):
+    if name in ("auto", "pipeline", "hpe"):
+        try:
+            from isbfsar_amd import bench_pipeline  # appears once the HPE stage exists
+            return bench_pipeline.get(name)
+        except ImportError:
+            if name != "auto":
+                raise
+    return ArWorkload
+
+
+def main():
+    args = parse()
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        # launched without torchrun: re-launching is the driver's job; run the N=1 case
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE=1; run under torch.distributed.run", file=sys.stderr)
+        args.gpus = 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    W = pick_workload(args.workload)(args, rank, world, local)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        W.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        W.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    roof = W.roofline(max(1, min(args.steps, 3))) if rank == 0 else None
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = W.cpu_baseline(args.cpu_sample)
+
+    if rank == 0:
+        units = W.units_per_step() * world * args.steps
+        line = {
+            "metric": W.metric, "value": round(units / dt, 3), "unit": W.unit, "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": W.precision if hasattr(W, "precision") else "bf16", "data": "synthetic",
+            "config": W.config(world), "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,75 @@
+"""ctypes binding of libisbfsar_hip.so (include/isbfsar.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libisbfsar_hip.so")
+
+ISB_AR_PREC_BF16 = 0
+ISB_AR_PREC_BF16X3 = 1
+
+
+class IsbError(RuntimeError):
+    pass
+
+
+class isb_ar_cfg(C.Structure):
+    _fields_ = [("seq_len", C.c_int32), ("n_joints", C.c_int32), ("way_max", C.c_int32),
+                ("device", C.c_int32), ("precision", C.c_int32), ("max_batch", C.c_int32)]
+
+
+class isb_hpe_cfg(C.Structure):
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("ppx", C.c_float), ("ppy", C.c_float),
+                ("width", C.c_int32), ("height", C.c_int32), ("device", C.c_int32),
+                ("max_batch", C.c_int32), ("n_out_joints", C.c_int32), ("reserved", C.c_int32)]
+
+
+_lib = None
+
+# name -> (restype, argtypes); every symbol include/isbfsar.h declares
+_P = C.c_void_p
+SIGNATURES = {
+    "isb_last_error": (C.c_char_p, []),
+    "isb_version": (C.c_int, []),
+    "isb_device_count": (C.c_int, []),
+    "isb_ar_create": (C.c_int, [C.POINTER(isb_ar_cfg), C.POINTER(_P)]),
+    "isb_ar_destroy": (None, [_P]),
+    "isb_ar_load_weights": (C.c_int, [_P, _P, C.c_size_t]),
+    "isb_ar_set_support": (C.c_int, [_P, _P, _P, C.c_int32]),
+    "isb_ar_get_support_features": (C.c_int, [_P, _P]),
+    "isb_ar_infer": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P]),
+    "isb_ar_infer_host": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P]),
+    "isb_ar_last_chosen": (C.c_int, [_P, _P, C.c_int32]),
+    "isb_ar_profile": (C.c_int, [_P, C.c_int32]),
+    "isb_ar_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+}
+
+
+def register(extra: dict) -> None:
+    SIGNATURES.update(extra)
+
+
+def lib() -> C.CDLL:
+    """Load the HIP library (once). Raises IsbError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise IsbError(f"{LIB_PATH} is missing: run `python -m isbfsar_amd.build` (hipcc, gfx950). "
+                           "There is no CPU fallback.")
+        _lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(_lib, name)
+            fn.restype = res
+            fn.argtypes = args
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().isb_last_error()
+        raise IsbError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")

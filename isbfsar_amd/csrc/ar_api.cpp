@@ -1,0 +1,410 @@
+// C-ABI glue of the action-recognition stage (include/isbfsar.h, isb_ar_*).
+// Host orchestration only: weight upload, support-set cache, per-chunk launch sequence.
+#include <algorithm>
+#include <cmath>
+#include <memory>
+#include <utility>
+
+#include "isb_common.h"
+#include "kernels.h"
+
+using namespace isb;
+
+struct isb_ar {
+    isb_ar_cfg cfg{};
+    int L = 0, J = 0, D3 = 0, H = 0, T = 0, NT = 0, Tp = 0;
+    int n = 0;                    // live classes
+    bool weights = false, support = false;
+    bool x3 = false, online = false;
+    float kscale = 0.f, qnorm_bound = 0.f;
+    hipStream_t own_stream = nullptr;
+
+    // weights (device)
+    DevBuf w1, b1, w2, b2, wcat, bk, bv, gamma, beta, wd, bd, wf1, bf1, wf2, bf2, wf3, bf3, pe, tup;
+    // support cache
+    DevBuf s_feat, s_proj, KcF, KcF_lo, VtF, VtF_lo, ub;
+    // per-chunk workspace
+    int ws_B = 0;
+    DevBuf win, h1, qfeat, proj, KqF, KqF_lo, lse2, part, diff, y1, f1, logits_tmp;
+    DevBuf chosen;
+    int chosen_cap = 0;
+
+    // profiling of the tuple-attention kernels
+    bool prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
+    double prof_ms = 0.0;
+    int64_t prof_launches = 0;
+};
+
+namespace {
+
+int ensure_ws(isb_ar* h, int Bc) {
+    if (Bc <= h->ws_B) return ISB_OK;
+    const size_t B = Bc, L = h->L, nmax = h->cfg.way_max;
+    ISB_TRY(h->win.alloc(B * L * h->D3 * 4));
+    ISB_TRY(h->h1.alloc(B * L * h->H * 4));
+    ISB_TRY(h->qfeat.alloc(B * L * 256 * 4));
+    ISB_TRY(h->proj.alloc(B * L * 512 * 4));
+    ISB_TRY(h->KqF.alloc(B * h->NT * 4096 * 2));
+    if (h->x3) ISB_TRY(h->KqF_lo.alloc(B * h->NT * 4096 * 2));
+    ISB_TRY(h->lse2.alloc(B * nmax * h->Tp * 4));
+    ISB_TRY(h->part.alloc(B * nmax * h->NT * 4));
+    ISB_TRY(h->diff.alloc(B * h->T * 128 * 4));
+    ISB_TRY(h->y1.alloc(B * h->T * L * 4));
+    ISB_TRY(h->f1.alloc(B * 256 * 4));
+    ISB_TRY(h->logits_tmp.alloc(B * nmax * 4));
+    h->ws_B = Bc;
+    return ISB_OK;
+}
+
+int gemm(hipStream_t st, const float* A, int lda, const float* W, int ldw, const float* bias, float* C,
+         int ldc, int M, int N, int K, int act, const float* add = nullptr, int ldadd = 0, int period = 1) {
+    GemmF32Args g{};
+    g.A = A; g.W = W; g.bias = bias; g.C = C; g.Aadd = add;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.ldadd = ldadd;
+    g.add_period = period; g.act = act;
+    return launch_gemm_f32(g, st);
+}
+
+// skeleton MLP (model.py:164-180) + tuple projections of (features + PE) (model.py:26,75-78)
+int features_and_proj(isb_ar* h, hipStream_t st, const float* d_poses, int items, float* d_feat,
+                      float* d_h1, float* d_proj) {
+    const int M = items * h->L;
+    ISB_TRY(gemm(st, d_poses, h->D3, h->w1.as<float>(), h->D3, h->b1.as<float>(), d_h1, h->H, M, h->H,
+                 h->D3, GEMM_ACT_RELU));
+    ISB_TRY(gemm(st, d_h1, h->H, h->w2.as<float>(), h->H, h->b2.as<float>(), d_feat, 256, M, 256, h->H,
+                 GEMM_ACT_RELU));
+    (void)d_proj;
+    return ISB_OK;
+}
+
+int project(isb_ar* h, hipStream_t st, const float* d_feat, int items, float* d_proj) {
+    return gemm(st, d_feat, 256, h->wcat.as<float>(), 256, nullptr, d_proj, 512, items * h->L, 512, 256,
+                GEMM_ACT_NONE, h->pe.as<float>(), 256, h->L);
+}
+
+}  // namespace
+
+extern "C" int isb_ar_create(const isb_ar_cfg* cfg, isb_ar** out) {
+    ISB_REQUIRE(cfg && out, ISB_ERR_INVALID, "isb_ar_create: null argument");
+    ISB_REQUIRE(cfg->seq_len >= 2 && cfg->seq_len <= 64, ISB_ERR_INVALID, "seq_len %d outside [2,64]", cfg->seq_len);
+    ISB_REQUIRE(cfg->n_joints >= 1 && cfg->n_joints <= 1024, ISB_ERR_INVALID, "n_joints %d outside [1,1024]", cfg->n_joints);
+    ISB_REQUIRE(cfg->way_max >= 1 && cfg->way_max <= 4096, ISB_ERR_INVALID, "way_max %d outside [1,4096]", cfg->way_max);
+    ISB_REQUIRE(cfg->precision == ISB_AR_PREC_BF16 || cfg->precision == ISB_AR_PREC_BF16X3, ISB_ERR_INVALID,
+                "unknown precision %d", cfg->precision);
+    int ndev = 0;
+    ISB_HIP(hipGetDeviceCount(&ndev));
+    ISB_REQUIRE(cfg->device >= 0 && cfg->device < ndev, ISB_ERR_INVALID, "device %d not in [0,%d)", cfg->device, ndev);
+    ISB_HIP(hipSetDevice(cfg->device));
+    std::unique_ptr<isb_ar> h(new (std::nothrow) isb_ar());
+    ISB_REQUIRE(h, ISB_ERR_NOMEM, "out of host memory");
+    h->cfg = *cfg;
+    if (h->cfg.max_batch <= 0) h->cfg.max_batch = 1024;
+    h->L = cfg->seq_len;
+    h->J = cfg->n_joints;
+    h->D3 = 3 * h->J;
+    h->H = 6 * h->J;
+    h->T = h->L * (h->L - 1) / 2;
+    h->NT = cdiv(h->T, 32);
+    h->Tp = h->NT * 32;
+    h->x3 = cfg->precision == ISB_AR_PREC_BF16X3;
+    ISB_HIP(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    *out = h.release();
+    return ISB_OK;
+}
+
+extern "C" void isb_ar_destroy(isb_ar* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device);
+    (void)hipDeviceSynchronize();
+    for (auto& e : h->prof_ev) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+extern "C" int isb_ar_load_weights(isb_ar* h, const void* blob, size_t nbytes) {
+    ISB_REQUIRE(h, ISB_ERR_INVALID, "null handle");
+    ISB_HIP(hipSetDevice(h->cfg.device));
+    std::map<std::string, BlobTensor> m;
+    ISB_TRY(parse_blob(blob, nbytes, m));
+    const uint32_t L = h->L, D3 = h->D3, H = h->H, T = h->T;
+    const BlobTensor *w1, *b1, *w2, *b2, *wk, *bk, *wv, *bv, *g, *be, *wd, *bd, *wf1, *bf1, *wf2, *bf2, *wf3, *bf3;
+    ISB_TRY(blob_get(m, "features_extractor.sk.fc1.weight", H, D3, &w1));
+    ISB_TRY(blob_get(m, "features_extractor.sk.fc1.bias", H, 1, &b1));
+    ISB_TRY(blob_get(m, "features_extractor.sk.fc2.weight", 256, H, &w2));
+    ISB_TRY(blob_get(m, "features_extractor.sk.fc2.bias", 256, 1, &b2));
+    ISB_TRY(blob_get(m, "transformers.0.k_linear.weight", 128, 512, &wk));
+    ISB_TRY(blob_get(m, "transformers.0.k_linear.bias", 128, 1, &bk));
+    ISB_TRY(blob_get(m, "transformers.0.v_linear.weight", 128, 512, &wv));
+    ISB_TRY(blob_get(m, "transformers.0.v_linear.bias", 128, 1, &bv));
+    ISB_TRY(blob_get(m, "transformers.0.norm_k.weight", 128, 1, &g));
+    ISB_TRY(blob_get(m, "transformers.0.norm_k.bias", 128, 1, &be));
+    ISB_TRY(blob_get(m, "discriminator.dimensionality_reduction.weight", L, 128, &wd));
+    ISB_TRY(blob_get(m, "discriminator.dimensionality_reduction.bias", L, 1, &bd));
+    ISB_TRY(blob_get(m, "discriminator.fc1.weight", 256, T * L, &wf1));
+    ISB_TRY(blob_get(m, "discriminator.fc1.bias", 256, 1, &bf1));
+    ISB_TRY(blob_get(m, "discriminator.fc2.weight", 64, 256, &wf2));
+    ISB_TRY(blob_get(m, "discriminator.fc2.bias", 64, 1, &bf2));
+    ISB_TRY(blob_get(m, "discriminator.fc3.weight", 1, 64, &wf3));
+    ISB_TRY(blob_get(m, "discriminator.fc3.bias", 1, 1, &bf3));
+
+    ISB_TRY(upload(h->w1, w1->data, w1->numel() * 4));
+    ISB_TRY(upload(h->b1, b1->data, b1->numel() * 4));
+    ISB_TRY(upload(h->w2, w2->data, w2->numel() * 4));
+    ISB_TRY(upload(h->b2, b2->data, b2->numel() * 4));
+    // factorised tuple Linear: rows [Ak | Bk | Av | Bv], each [128,256]
+    std::vector<float> wcat(512 * 256);
+    for (int o = 0; o < 128; ++o)
+        for (int k = 0; k < 256; ++k) {
+            wcat[(size_t)(o)*256 + k] = wk->data[(size_t)o * 512 + k];
+            wcat[(size_t)(128 + o) * 256 + k] = wk->data[(size_t)o * 512 + 256 + k];
+            wcat[(size_t)(256 + o) * 256 + k] = wv->data[(size_t)o * 512 + k];
+            wcat[(size_t)(384 + o) * 256 + k] = wv->data[(size_t)o * 512 + 256 + k];
+        }
+    ISB_TRY(upload(h->wcat, wcat.data(), wcat.size() * 4));
+    ISB_TRY(upload(h->bk, bk->data, 128 * 4));
+    ISB_TRY(upload(h->bv, bv->data, 128 * 4));
+    ISB_TRY(upload(h->gamma, g->data, 128 * 4));
+    ISB_TRY(upload(h->beta, be->data, 128 * 4));
+    ISB_TRY(upload(h->wd, wd->data, wd->numel() * 4));
+    ISB_TRY(upload(h->bd, bd->data, bd->numel() * 4));
+    ISB_TRY(upload(h->wf1, wf1->data, wf1->numel() * 4));
+    ISB_TRY(upload(h->bf1, bf1->data, 256 * 4));
+    ISB_TRY(upload(h->wf2, wf2->data, wf2->numel() * 4));
+    ISB_TRY(upload(h->bf2, bf2->data, 64 * 4));
+    ISB_TRY(upload(h->wf3, wf3->data, 64 * 4));
+    ISB_TRY(upload(h->bf3, bf3->data, 4));
+
+    // positional table, first L rows, computed in f32 like model.py:17-23 (scale 0.1)
+    std::vector<float> pe((size_t)L * 256);
+    const float c = (float)(-(std::log(10000.0) / 256.0));
+    for (uint32_t pos = 0; pos < L; ++pos)
+        for (int i = 0; i < 128; ++i) {
+            const float div = expf((float)(2 * i) * c);
+            const float ang = (float)pos * div;
+            pe[(size_t)pos * 256 + 2 * i] = sinf(ang) * 0.1f;
+            pe[(size_t)pos * 256 + 2 * i + 1] = cosf(ang) * 0.1f;
+        }
+    ISB_TRY(upload(h->pe, pe.data(), pe.size() * 4));
+
+    // tuple table: combinations(range(L), 2) in lexicographic order (model.py:52-54)
+    std::vector<int16_t> tup((size_t)h->Tp * 2, (int16_t)-1);
+    int t = 0;
+    for (int i = 0; i < h->L; ++i)
+        for (int j = i + 1; j < h->L; ++j) {
+            tup[2 * t] = (int16_t)i;
+            tup[2 * t + 1] = (int16_t)j;
+            ++t;
+        }
+    ISB_TRY(upload(h->tup, tup.data(), tup.size() * 2));
+
+    // LayerNorm norm bound -> softmax stabiliser (see ar_kernels.hip header)
+    double gmax = 0.0, bn2 = 0.0;
+    for (int i = 0; i < 128; ++i) {
+        gmax = std::max(gmax, (double)std::fabs(g->data[i]));
+        bn2 += (double)be->data[i] * be->data[i];
+    }
+    const double knorm = (gmax * std::sqrt(128.0) + std::sqrt(bn2)) * (1.0 + 1.0 / 256.0);
+    h->kscale = (float)(1.4426950408889634 / std::sqrt(128.0));
+    h->qnorm_bound = (float)(knorm * h->kscale);
+    // |s'| <= knorm * qnorm_bound; exp2(s' - ub) >= 2^-(2*that). Keep clear of f32 underflow.
+    h->online = 2.0 * knorm * h->qnorm_bound > 100.0;
+    h->weights = true;
+    h->support = false;
+    return ISB_OK;
+}
+
+extern "C" int isb_ar_set_support(isb_ar* h, const float* poses, const float* features, int32_t n) {
+    ISB_REQUIRE(h, ISB_ERR_INVALID, "null handle");
+    ISB_REQUIRE(h->weights, ISB_ERR_STATE, "isb_ar_set_support before isb_ar_load_weights");
+    ISB_REQUIRE((poses != nullptr) != (features != nullptr), ISB_ERR_INVALID,
+                "exactly one of poses / features must be given");
+    ISB_REQUIRE(n >= 1 && n <= h->cfg.way_max, ISB_ERR_INVALID, "support size %d outside [1,%d]", n, h->cfg.way_max);
+    ISB_HIP(hipSetDevice(h->cfg.device));
+    hipStream_t st = h->own_stream;
+    const size_t rows = (size_t)n * h->L;
+    ISB_TRY(h->s_feat.alloc(rows * 256 * 4));
+    ISB_TRY(h->s_proj.alloc(rows * 512 * 4));
+    if (poses) {
+        DevBuf dp, dh1;
+        ISB_TRY(upload(dp, poses, rows * h->D3 * 4));
+        ISB_TRY(dh1.alloc(rows * h->H * 4));
+        ISB_TRY(features_and_proj(h, st, dp.as<float>(), n, h->s_feat.as<float>(), dh1.as<float>(), nullptr));
+        ISB_HIP(hipStreamSynchronize(st));
+    } else {
+        ISB_HIP(hipMemcpy(h->s_feat.p, features, rows * 256 * 4, hipMemcpyHostToDevice));
+    }
+    ISB_TRY(project(h, st, h->s_feat.as<float>(), n, h->s_proj.as<float>()));
+    const size_t img = (size_t)n * h->NT * 4096 * 2;
+    ISB_TRY(h->KcF.alloc(img));
+    ISB_TRY(h->VtF.alloc(img));
+    if (h->x3) {
+        ISB_TRY(h->KcF_lo.alloc(img));
+        ISB_TRY(h->VtF_lo.alloc(img));
+    }
+    ISB_TRY(h->ub.alloc((size_t)n * h->Tp * 4));
+    ISB_HIP(hipMemsetAsync(h->ub.p, 0, (size_t)n * h->Tp * 4, st));
+    ArTupleArgs a{};
+    a.proj = h->s_proj.as<float>();
+    a.bk = h->bk.as<float>(); a.bv = h->bv.as<float>();
+    a.gamma = h->gamma.as<float>(); a.beta = h->beta.as<float>();
+    a.tup = h->tup.as<int16_t>();
+    a.KF = h->KcF.as<uint16_t>(); a.KF_lo = h->x3 ? h->KcF_lo.as<uint16_t>() : nullptr;
+    a.VtF = h->VtF.as<uint16_t>(); a.VtF_lo = h->x3 ? h->VtF_lo.as<uint16_t>() : nullptr;
+    a.ub = h->ub.as<float>();
+    a.kscale = 1.0f;
+    a.qnorm_bound = h->qnorm_bound;
+    a.n_items = n; a.L = h->L; a.T = h->T; a.NT = h->NT;
+    ISB_TRY(launch_ar_tuples(a, st));
+    ISB_HIP(hipStreamSynchronize(st));
+    h->n = n;
+    h->support = true;
+    return ISB_OK;
+}
+
+extern "C" int isb_ar_get_support_features(isb_ar* h, float* out) {
+    ISB_REQUIRE(h && out, ISB_ERR_INVALID, "null argument");
+    ISB_REQUIRE(h->support, ISB_ERR_STATE, "no support set installed");
+    ISB_HIP(hipSetDevice(h->cfg.device));
+    ISB_HIP(hipMemcpy(out, h->s_feat.p, (size_t)h->n * h->L * 256 * 4, hipMemcpyDeviceToHost));
+    return ISB_OK;
+}
+
+extern "C" int isb_ar_infer(isb_ar* h, const float* d_windows, int32_t B, float* d_logits, float* d_is_true,
+                            float* d_embed, void* stream) {
+    ISB_REQUIRE(h && d_windows && d_logits && d_is_true, ISB_ERR_INVALID, "null argument");
+    ISB_REQUIRE(B >= 1, ISB_ERR_INVALID, "batch %d < 1", B);
+    ISB_REQUIRE(h->weights && h->support, ISB_ERR_STATE, "isb_ar_infer needs weights and a support set");
+    ISB_HIP(hipSetDevice(h->cfg.device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->own_stream;
+    const int Bc_max = std::min<int>(B, h->cfg.max_batch);
+    ISB_TRY(ensure_ws(h, Bc_max));
+    if (B > h->chosen_cap) {
+        ISB_TRY(h->chosen.alloc((size_t)B * 4));
+        h->chosen_cap = B;
+    }
+    const int n = h->n, L = h->L, T = h->T, NT = h->NT;
+    for (int b0 = 0; b0 < B; b0 += Bc_max) {
+        const int Bc = std::min(Bc_max, B - b0);
+        const float* win = d_windows + (size_t)b0 * L * h->D3;
+        float* feat = d_embed ? d_embed + (size_t)b0 * L * 256 : h->qfeat.as<float>();
+        int32_t* chosen = h->chosen.as<int32_t>() + b0;
+        ISB_TRY(features_and_proj(h, st, win, Bc, feat, h->h1.as<float>(), nullptr));
+        ISB_TRY(project(h, st, feat, Bc, h->proj.as<float>()));
+
+        ArTupleArgs ta{};
+        ta.proj = h->proj.as<float>();
+        ta.bk = h->bk.as<float>(); ta.bv = h->bv.as<float>();
+        ta.gamma = h->gamma.as<float>(); ta.beta = h->beta.as<float>();
+        ta.tup = h->tup.as<int16_t>();
+        ta.KF = h->KqF.as<uint16_t>(); ta.KF_lo = h->x3 ? h->KqF_lo.as<uint16_t>() : nullptr;
+        ta.kscale = h->kscale;
+        ta.n_items = Bc; ta.L = L; ta.T = T; ta.NT = NT;
+        ISB_TRY(launch_ar_tuples(ta, st));
+
+        ArStatsArgs sa{};
+        sa.KqF = h->KqF.as<uint16_t>(); sa.KqF_lo = h->x3 ? h->KqF_lo.as<uint16_t>() : nullptr;
+        sa.KcF = h->KcF.as<uint16_t>(); sa.KcF_lo = h->x3 ? h->KcF_lo.as<uint16_t>() : nullptr;
+        sa.ub = h->ub.as<float>();
+        sa.lse2 = h->lse2.as<float>();
+        sa.B = Bc; sa.n = n; sa.T = T; sa.NT = NT; sa.x3 = h->x3; sa.online = h->online;
+        ISB_TRY(launch_ar_stats(sa, st));
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (h->prof) {
+            ISB_HIP(hipEventCreate(&e0));
+            ISB_HIP(hipEventCreate(&e1));
+            ISB_HIP(hipEventRecord(e0, st));
+        }
+
+        ArProtoArgs pa{};
+        pa.KqF = sa.KqF; pa.KqF_lo = sa.KqF_lo; pa.KcF = sa.KcF; pa.KcF_lo = sa.KcF_lo;
+        pa.VtF = h->VtF.as<uint16_t>(); pa.VtF_lo = h->x3 ? h->VtF_lo.as<uint16_t>() : nullptr;
+        pa.lse2 = h->lse2.as<float>();
+        pa.proj = h->proj.as<float>(); pa.bv = h->bv.as<float>(); pa.tup = h->tup.as<int16_t>();
+        pa.chosen = nullptr; pa.part = h->part.as<float>(); pa.diff = nullptr;
+        pa.B = Bc; pa.n = n; pa.L = L; pa.T = T; pa.NT = NT; pa.x3 = h->x3;
+        ISB_TRY(launch_ar_proto(pa, st));
+        if (h->prof) {
+            ISB_HIP(hipEventRecord(e1, st));
+            h->prof_ev.emplace_back(e0, e1);
+            h->prof_launches += 1;
+        }
+
+        ArFinalArgs fa{};
+        fa.part = h->part.as<float>(); fa.logits = d_logits + (size_t)b0 * n; fa.chosen = chosen;
+        fa.B = Bc; fa.n = n; fa.T = T; fa.NT = NT;
+        ISB_TRY(launch_ar_finalize(fa, st));
+
+        // diff of the arg-max class (model.py:323-324), then the Discriminator (model.py:194-204)
+        pa.chosen = chosen; pa.part = nullptr; pa.diff = h->diff.as<float>();
+        ISB_TRY(launch_ar_proto(pa, st));
+        ISB_TRY(gemm(st, h->diff.as<float>(), 128, h->wd.as<float>(), 128, h->bd.as<float>(), h->y1.as<float>(), L,
+                     Bc * T, L, 128, GEMM_ACT_NONE));
+        ISB_TRY(gemm(st, h->y1.as<float>(), T * L, h->wf1.as<float>(), T * L, h->bf1.as<float>(), h->f1.as<float>(),
+                     256, Bc, 256, T * L, GEMM_ACT_RELU));
+        ArDiscTailArgs da{};
+        da.h1 = h->f1.as<float>(); da.w2 = h->wf2.as<float>(); da.b2 = h->bf2.as<float>();
+        da.w3 = h->wf3.as<float>(); da.b3 = h->bf3.as<float>(); da.is_true = d_is_true + b0; da.B = Bc;
+        ISB_TRY(launch_ar_disc_tail(da, st));
+    }
+    return ISB_OK;
+}
+
+extern "C" int isb_ar_infer_host(isb_ar* h, const float* windows, int32_t B, float* logits, float* is_true,
+                                 float* embed) {
+    ISB_REQUIRE(h && windows && logits && is_true, ISB_ERR_INVALID, "null argument");
+    ISB_REQUIRE(B >= 1, ISB_ERR_INVALID, "batch %d < 1", B);
+    ISB_REQUIRE(h->weights && h->support, ISB_ERR_STATE, "isb_ar_infer_host needs weights and a support set");
+    ISB_HIP(hipSetDevice(h->cfg.device));
+    hipStream_t st = h->own_stream;
+    DevBuf dw, dl, di, de;
+    const size_t wbytes = (size_t)B * h->L * h->D3 * 4;
+    ISB_TRY(dw.alloc(wbytes));
+    ISB_TRY(dl.alloc((size_t)B * h->n * 4));
+    ISB_TRY(di.alloc((size_t)B * 4));
+    if (embed) ISB_TRY(de.alloc((size_t)B * h->L * 256 * 4));
+    ISB_HIP(hipMemcpyAsync(dw.p, windows, wbytes, hipMemcpyHostToDevice, st));
+    ISB_TRY(isb_ar_infer(h, dw.as<float>(), B, dl.as<float>(), di.as<float>(), embed ? de.as<float>() : nullptr, st));
+    ISB_HIP(hipMemcpyAsync(logits, dl.p, (size_t)B * h->n * 4, hipMemcpyDeviceToHost, st));
+    ISB_HIP(hipMemcpyAsync(is_true, di.p, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    if (embed) ISB_HIP(hipMemcpyAsync(embed, de.p, (size_t)B * h->L * 256 * 4, hipMemcpyDeviceToHost, st));
+    ISB_HIP(hipStreamSynchronize(st));
+    return ISB_OK;
+}
+
+extern "C" int isb_ar_last_chosen(isb_ar* h, int32_t* out, int32_t B) {
+    ISB_REQUIRE(h && out, ISB_ERR_INVALID, "null argument");
+    ISB_REQUIRE(B >= 1 && B <= h->chosen_cap, ISB_ERR_INVALID, "B %d exceeds last batch %d", B, h->chosen_cap);
+    ISB_HIP(hipSetDevice(h->cfg.device));
+    ISB_HIP(hipDeviceSynchronize());
+    ISB_HIP(hipMemcpy(out, h->chosen.p, (size_t)B * 4, hipMemcpyDeviceToHost));
+    return ISB_OK;
+}
+
+extern "C" int isb_ar_profile(isb_ar* h, int32_t enable) {
+    ISB_REQUIRE(h, ISB_ERR_INVALID, "null handle");
+    h->prof = enable != 0;
+    return ISB_OK;
+}
+
+extern "C" int isb_ar_profile_read(isb_ar* h, double* ms_total, int64_t* launches) {
+    ISB_REQUIRE(h && ms_total && launches, ISB_ERR_INVALID, "null argument");
+    ISB_HIP(hipSetDevice(h->cfg.device));
+    for (auto& e : h->prof_ev) {
+        ISB_HIP(hipEventSynchronize(e.second));
+        float ms = 0.f;
+        ISB_HIP(hipEventElapsedTime(&ms, e.first, e.second));
+        h->prof_ms += ms;
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    h->prof_ev.clear();
+    *ms_total = h->prof_ms;
+    *launches = h->prof_launches;
+    h->prof_ms = 0.0;
+    h->prof_launches = 0;
+    return ISB_OK;
+}

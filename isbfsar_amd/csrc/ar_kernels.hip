@@ -1,0 +1,560 @@
+// Tuple cross-attention of the TRX action-recognition head on gfx950 (MI355X).
+//
+// What the reference computes (modules/ar/utils/model.py:59-143, per query window and class c):
+//     t_(i,j) = [x_i || x_j]  for the T = C(L,2) ordered frame pairs           (model.py:65-72)
+//     K = LayerNorm(Wk t + bk),  V = Wv t + bv                                   (model.py:75-84)
+//     S = Kq Kc^T / sqrt(128);  A = softmax(S, dim=-2)  (over the QUERY tuple axis, model.py:49,109)
+//     P = A Vc;  diff = Vq - P;  logit_c = -||diff||_F^2 / T                     (model.py:127-137)
+//
+// How it is laid out here
+//   * the 512-wide tuple Linear factorises exactly: K_(i,j) = Ak[i] + Bk[j] + bk with
+//     Ak = x Wk[:, :256]^T, Bk = x Wk[:, 256:]^T -- the tuple gather (55-60 % of the
+//     reference's CPU time) disappears; `ar_tuples_*` builds K/V of every tuple from the per-frame
+//     projections [L,512] and writes them as bf16 MFMA *fragment images*:
+//         KF  chunk (item, tile t32, kstep ks)      : [lane 0..63][8]  = K[32 t32 + (lane&31)][16 ks + 8 (lane>>5) + e]
+//         VtF chunk (item, tile j32, dtile dt, s)   : [lane][8]        = V[32 j32 + 16 s + 8 (e>>2) + 4 (lane>>5) + (e&3)][32 dt + (lane&31)]
+//     so every operand load is one linear 1-KiB wave access (global or LDS, conflict free), and the
+//     VtF k-order is exactly the order in which a 32x32 f32 accumulator, converted pairwise to
+//     bf16, presents its ROWS as the B operand of the next MFMA (no LDS transpose between the two
+//     contractions).
+//   * everything is computed transposed: S^T = Kc Kq^T (rows = support tuple j, cols = query tuple
+//     i on the lane), P^T = V^T A^T, so the softmax axis (i) runs across lanes + i-tiles and the
+//     prototype contraction (j) runs down accumulator rows.
+//   * the softmax normaliser needs ALL i of a window before any P can be formed, so the work is two
+//     launches: `ar_stats` writes lse2[b,c,j] = log2 sum_i exp2(s'[i,j]) (s' already carries
+//     log2(e)/sqrt(128), folded into Kq), `ar_proto` recomputes S^T tiles, forms A^T = exp2(s' - lse2)
+//     in registers, contracts with V^T and reduces ||Vq - P||^2 on the fly.  Vq is never stored:
+//     it is re-formed from the per-frame projections in the epilogue.
+//   * no running max is needed in the common case: |kq'|.|kc_j| bounds s' from LayerNorm's norm
+//     bound, `ub[c,j]` is that bound and exp2(s' - ub) cannot overflow; the host picks the ONLINE
+//     (running max) variant when the bound is too loose to rule out underflow.
+//   * bf16x3: operands split hi+lo, three MFMAs per product (lo*lo dropped) -> ~2^-16 relative.
+#include "isb_common.h"
+#include "kernels.h"
+
+namespace isb {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ uint16_t f2bf(float x) { return __builtin_bit_cast(uint16_t, (__bf16)x); }
+__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+
+__device__ __forceinline__ bf16x8 ld_frag(const uint16_t* p) {
+    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(p));
+}
+
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+// row of accumulator register r inside a 32x32 tile for lane-half h
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// =====================================================================================
+// tuples: per-frame projections -> K fragment image (LayerNorm'ed, scaled, bf16)
+// grid (NT, n_items), block 512: thread = (ks = tid>>6, lane): 8 consecutive d of tuple (lane&31)
+// =====================================================================================
+__global__ __launch_bounds__(512) void ar_tuples_k_kernel(ArTupleArgs p) {
+    __shared__ float red[16][33];
+    const int tid = threadIdx.x;
+    const int ks = tid >> 6, lane = tid & 63, h = lane >> 5, r = lane & 31;
+    const int it = blockIdx.x, item = blockIdx.y;
+    const int t = it * 32 + r;
+    const int d0 = 16 * ks + 8 * h;
+    const bool valid = t < p.T;
+    float k[8];
+    if (valid) {
+        const int f0 = p.tup[2 * t], f1 = p.tup[2 * t + 1];
+        const float* a = p.proj + (size_t)(item * p.L + f0) * 512 + d0;
+        const float* b = p.proj + (size_t)(item * p.L + f1) * 512 + 128 + d0;
+        const float4 a0 = *reinterpret_cast<const float4*>(a), a1 = *reinterpret_cast<const float4*>(a + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(b), b1 = *reinterpret_cast<const float4*>(b + 4);
+        const float4 c0 = *reinterpret_cast<const float4*>(p.bk + d0), c1 = *reinterpret_cast<const float4*>(p.bk + d0 + 4);
+        k[0] = a0.x + b0.x + c0.x; k[1] = a0.y + b0.y + c0.y; k[2] = a0.z + b0.z + c0.z; k[3] = a0.w + b0.w + c0.w;
+        k[4] = a1.x + b1.x + c1.x; k[5] = a1.y + b1.y + c1.y; k[6] = a1.z + b1.z + c1.z; k[7] = a1.w + b1.w + c1.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) k[e] = 0.f;
+    }
+    const int slot = ks * 2 + h;
+    // LayerNorm over the 128 features of the tuple (two-pass, like nn.LayerNorm; model.py:46,81-82)
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += k[e];
+    red[slot][r] = s;
+    __syncthreads();
+    float mean = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) mean += red[q][r];
+    mean *= (1.f / 128.f);
+    __syncthreads();
+    float v = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float c = k[e] - mean; v += c * c; }
+    red[slot][r] = v;
+    __syncthreads();
+    float var = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) var += red[q][r];
+    var *= (1.f / 128.f);
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    uint16_t hi[8], lo[8];
+    float nrm = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float y = 0.f;
+        if (valid) y = ((k[e] - mean) * rstd * p.gamma[d0 + e] + p.beta[d0 + e]) * p.kscale;
+        hi[e] = f2bf(y);
+        const float yh = bf2f(hi[e]);
+        lo[e] = f2bf(y - yh);
+        const float used = p.KF_lo ? yh + bf2f(lo[e]) : yh;
+        nrm += used * used;
+    }
+    const size_t off = ((((size_t)item * p.NT + it) * 8 + ks) * 64 + lane) * 8;
+    uint4 o;
+    o.x = hi[0] | ((uint32_t)hi[1] << 16); o.y = hi[2] | ((uint32_t)hi[3] << 16);
+    o.z = hi[4] | ((uint32_t)hi[5] << 16); o.w = hi[6] | ((uint32_t)hi[7] << 16);
+    *reinterpret_cast<uint4*>(p.KF + off) = o;
+    if (p.KF_lo) {
+        o.x = lo[0] | ((uint32_t)lo[1] << 16); o.y = lo[2] | ((uint32_t)lo[3] << 16);
+        o.z = lo[4] | ((uint32_t)lo[5] << 16); o.w = lo[6] | ((uint32_t)lo[7] << 16);
+        *reinterpret_cast<uint4*>(p.KF_lo + off) = o;
+    }
+    if (p.ub) {   // support side: ub[item][t] = |kc_t| * bound(|kq'|)
+        __syncthreads();
+        red[slot][r] = nrm;
+        __syncthreads();
+        if (slot == 0) {
+            float n2 = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) n2 += red[q][r];
+            p.ub[(size_t)item * p.NT * 32 + t] = sqrtf(n2) * p.qnorm_bound;
+        }
+    }
+}
+
+// V^T fragment image of the support tuples. grid (NT, n_items), block 512:
+// thread = (dt = tid>>7, s = (tid>>6)&1, lane): 8 tuples j of feature d = 32 dt + (lane&31)
+__global__ __launch_bounds__(512) void ar_tuples_vt_kernel(ArTupleArgs p) {
+    const int tid = threadIdx.x;
+    const int dt = tid >> 7, s = (tid >> 6) & 1, lane = tid & 63, h = lane >> 5, r = lane & 31;
+    const int jt = blockIdx.x, item = blockIdx.y;
+    const int d = 32 * dt + r;
+    const float bias = p.bv[d];
+    uint16_t hi[8], lo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int j = jt * 32 + 16 * s + 8 * (e >> 2) + 4 * h + (e & 3);
+        float y = 0.f;
+        if (j < p.T) {
+            const int f0 = p.tup[2 * j], f1 = p.tup[2 * j + 1];
+            y = p.proj[(size_t)(item * p.L + f0) * 512 + 256 + d] +
+                p.proj[(size_t)(item * p.L + f1) * 512 + 384 + d] + bias;
+        }
+        hi[e] = f2bf(y);
+        lo[e] = f2bf(y - bf2f(hi[e]));
+    }
+    const size_t off = (((((size_t)item * p.NT + jt) * 4 + dt) * 2 + s) * 64 + lane) * 8;
+    uint4 o;
+    o.x = hi[0] | ((uint32_t)hi[1] << 16); o.y = hi[2] | ((uint32_t)hi[3] << 16);
+    o.z = hi[4] | ((uint32_t)hi[5] << 16); o.w = hi[6] | ((uint32_t)hi[7] << 16);
+    *reinterpret_cast<uint4*>(p.VtF + off) = o;
+    if (p.VtF_lo) {
+        o.x = lo[0] | ((uint32_t)lo[1] << 16); o.y = lo[2] | ((uint32_t)lo[3] << 16);
+        o.z = lo[4] | ((uint32_t)lo[5] << 16); o.w = lo[6] | ((uint32_t)lo[7] << 16);
+        *reinterpret_cast<uint4*>(p.VtF_lo + off) = o;
+    }
+}
+
+int launch_ar_tuples(const ArTupleArgs& a, hipStream_t st) {
+    dim3 grid(a.NT, a.n_items);
+    hipLaunchKernelGGL(ar_tuples_k_kernel, grid, dim3(512), 0, st, a);
+    if (a.VtF) hipLaunchKernelGGL(ar_tuples_vt_kernel, grid, dim3(512), 0, st, a);
+    ISB_HIP(hipGetLastError());
+    return ISB_OK;
+}
+
+// =====================================================================================
+// stats: lse2[b,c,j] = log2 sum_{i<T} exp2(s'[j,i]),  s' = Kc_j . Kq'_i
+// grid (ceil(n*NT/8), B), block 512 = 8 waves; wave = one (class, j-tile) slot of window b.
+// The window's Kq fragment tiles stream through a double-buffered LDS ring shared by the 8 waves.
+// =====================================================================================
+template <bool X3, bool ONLINE>
+__global__ __launch_bounds__(512, 2) void ar_stats_kernel(ArStatsArgs p) {
+    constexpr int TILE_U16 = 8 * 64 * 8;                  // one K tile: 8 chunks of 1 KiB
+    constexpr int NBUF_U16 = TILE_U16 * (X3 ? 2 : 1);
+    __shared__ __attribute__((aligned(16))) uint16_t lds[2 * NBUF_U16];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, r = lane & 31;
+    const int b = blockIdx.y;
+    const int slot = blockIdx.x * 8 + wave;
+    const bool active = slot < p.n * p.NT;
+    const int c = active ? slot / p.NT : 0, jt = active ? slot % p.NT : 0;
+    const int Tp = p.NT * 32;
+
+    bf16x8 a_hi[8], a_lo[8];
+    {
+        const uint16_t* base = p.KcF + (((size_t)c * p.NT + jt) * 8 * 64 + lane) * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) a_hi[ks] = ld_frag(base + ks * 512);
+        if (X3) {
+            const uint16_t* bl = p.KcF_lo + (((size_t)c * p.NT + jt) * 8 * 64 + lane) * 8;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) a_lo[ks] = ld_frag(bl + ks * 512);
+        }
+    }
+    float ubr[16], lsum[16], mrun[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 u = *reinterpret_cast<const float4*>(p.ub + (size_t)c * Tp + jt * 32 + 8 * q + 4 * h);
+        ubr[4 * q + 0] = u.x; ubr[4 * q + 1] = u.y; ubr[4 * q + 2] = u.z; ubr[4 * q + 3] = u.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { lsum[i] = 0.f; mrun[i] = -3.0e38f; }
+
+    const uint16_t* gq = p.KqF + (size_t)b * p.NT * TILE_U16 + tid * 8;
+    const uint16_t* gq_lo = X3 ? p.KqF_lo + (size_t)b * p.NT * TILE_U16 + tid * 8 : nullptr;
+    uint4 st_hi = *reinterpret_cast<const uint4*>(gq), st_lo;
+    if (X3) st_lo = *reinterpret_cast<const uint4*>(gq_lo);
+    *reinterpret_cast<uint4*>(lds + tid * 8) = st_hi;
+    if (X3) *reinterpret_cast<uint4*>(lds + TILE_U16 + tid * 8) = st_lo;
+    __syncthreads();
+
+    for (int it = 0; it < p.NT; ++it) {
+        const int cur = it & 1;
+        const bool more = it + 1 < p.NT;
+        if (more) {
+            st_hi = *reinterpret_cast<const uint4*>(gq + (size_t)(it + 1) * TILE_U16);
+            if (X3) st_lo = *reinterpret_cast<const uint4*>(gq_lo + (size_t)(it + 1) * TILE_U16);
+        }
+        if (active) {
+            const uint16_t* bt = lds + cur * NBUF_U16 + lane * 8;
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const bf16x8 bh = ld_frag(bt + ks * 512);
+                acc = MFMA_BF16(a_hi[ks], bh, acc);
+                if (X3) {
+                    const bf16x8 bl = ld_frag(bt + TILE_U16 + ks * 512);
+                    acc = MFMA_BF16(a_hi[ks], bl, acc);
+                    acc = MFMA_BF16(a_lo[ks], bh, acc);
+                }
+            }
+            const bool ivalid = it * 32 + r < p.T;
+            if (!ONLINE) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float e = __builtin_amdgcn_exp2f(acc[i] - ubr[i]);
+                    lsum[i] += ivalid ? e : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float sv = ivalid ? acc[i] : -3.0e38f;
+                    const float mn = fmaxf(mrun[i], sv);
+                    lsum[i] = lsum[i] * __builtin_amdgcn_exp2f(mrun[i] - mn) +
+                              (ivalid ? __builtin_amdgcn_exp2f(sv - mn) : 0.f);
+                    mrun[i] = mn;
+                }
+            }
+        }
+        if (more) {
+            uint16_t* nb = lds + (cur ^ 1) * NBUF_U16;
+            *reinterpret_cast<uint4*>(nb + tid * 8) = st_hi;
+            if (X3) *reinterpret_cast<uint4*>(nb + TILE_U16 + tid * 8) = st_lo;
+        }
+        __syncthreads();
+    }
+    if (!active) return;
+    // combine the 32 lanes (i within the tile) of each half-wave
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float l = lsum[i], m = ONLINE ? mrun[i] : ubr[i];
+#pragma unroll
+        for (int sh = 1; sh < 32; sh <<= 1) {
+            const float lo = __shfl_xor(l, sh, 64);
+            if (ONLINE) {
+                const float mo = __shfl_xor(m, sh, 64);
+                const float mn = fmaxf(m, mo);
+                l = l * __builtin_amdgcn_exp2f(m - mn) + lo * __builtin_amdgcn_exp2f(mo - mn);
+                m = mn;
+            } else {
+                l += lo;
+            }
+        }
+        if (r == 0) p.lse2[((size_t)b * p.n + c) * Tp + jt * 32 + acc_row(i, h)] = m + log2f(l);
+    }
+}
+
+int launch_ar_stats(const ArStatsArgs& a, hipStream_t st) {
+    const bool online = a.online != 0;
+    dim3 grid(cdiv(a.n * a.NT, 8), a.B);
+    if (a.x3) {
+        if (online) hipLaunchKernelGGL((ar_stats_kernel<true, true>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((ar_stats_kernel<true, false>), grid, dim3(512), 0, st, a);
+    } else {
+        if (online) hipLaunchKernelGGL((ar_stats_kernel<false, true>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((ar_stats_kernel<false, false>), grid, dim3(512), 0, st, a);
+    }
+    ISB_HIP(hipGetLastError());
+    return ISB_OK;
+}
+
+// =====================================================================================
+// proto: P^T = V^T A^T with A^T = exp2(S^T - lse2), fused distance / diff epilogue.
+// ALL mode   : grid (ceil(B*NT/8), n); wave = one (window, i-tile) slot, class = blockIdx.y;
+//              the class's Kc / V^T fragment tiles stream through LDS shared by the 8 waves;
+//              out: part[b,c,it] = sum_{i in tile, d} (Vq - P)^2
+// CHOSEN mode: grid (ceil(B*NT/8), 1); class = chosen[b] per wave, operands straight from L2;
+//              out: diff[b,i,:] (input of the Discriminator, model.py:324)
+// =====================================================================================
+template <bool X3, bool CHOSEN>
+__global__ __launch_bounds__(512, 2) void ar_proto_kernel(ArProtoArgs p) {
+    constexpr int KT_U16 = 8 * 64 * 8;                    // Kc tile (8 KiB)
+    constexpr int VT_U16 = 4 * 2 * 64 * 8;                // V^T tile (8 KiB)
+    constexpr int PART_U16 = KT_U16 + VT_U16;
+    constexpr int NBUF_U16 = PART_U16 * (X3 ? 2 : 1);
+    __shared__ __attribute__((aligned(16))) uint16_t lds[CHOSEN ? 8 : 2 * NBUF_U16];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, r = lane & 31;
+    const int slot = blockIdx.x * 8 + wave;
+    const bool active = slot < p.B * p.NT;
+    const int b = active ? slot / p.NT : 0, it = active ? slot % p.NT : 0;
+    const int c = CHOSEN ? p.chosen[b] : blockIdx.y;
+    const int Tp = p.NT * 32;
+
+    bf16x8 q_hi[8], q_lo[8];
+    {
+        const uint16_t* base = p.KqF + (((size_t)b * p.NT + it) * 8 * 64 + lane) * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) q_hi[ks] = ld_frag(base + ks * 512);
+        if (X3) {
+            const uint16_t* bl = p.KqF_lo + (((size_t)b * p.NT + it) * 8 * 64 + lane) * 8;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) q_lo[ks] = ld_frag(bl + ks * 512);
+        }
+    }
+    f32x16 pacc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pacc[dt][i] = 0.f;
+
+    const float* lse_row = p.lse2 + ((size_t)b * p.n + c) * Tp + 4 * h;
+
+    // staging (ALL mode): thread tid moves 16 B of the Kc tile and 16 B of the V^T tile
+    const uint16_t* gk = p.KcF + (size_t)c * p.NT * KT_U16 + tid * 8;
+    const uint16_t* gv = p.VtF + (size_t)c * p.NT * VT_U16 + tid * 8;
+    const uint16_t* gk_lo = X3 ? p.KcF_lo + (size_t)c * p.NT * KT_U16 + tid * 8 : nullptr;
+    const uint16_t* gv_lo = X3 ? p.VtF_lo + (size_t)c * p.NT * VT_U16 + tid * 8 : nullptr;
+    uint4 sk, sv, skl, svl;
+    if (!CHOSEN) {
+        sk = *reinterpret_cast<const uint4*>(gk);
+        sv = *reinterpret_cast<const uint4*>(gv);
+        *reinterpret_cast<uint4*>(lds + tid * 8) = sk;
+        *reinterpret_cast<uint4*>(lds + KT_U16 + tid * 8) = sv;
+        if (X3) {
+            skl = *reinterpret_cast<const uint4*>(gk_lo);
+            svl = *reinterpret_cast<const uint4*>(gv_lo);
+            *reinterpret_cast<uint4*>(lds + PART_U16 + tid * 8) = skl;
+            *reinterpret_cast<uint4*>(lds + PART_U16 + KT_U16 + tid * 8) = svl;
+        }
+        __syncthreads();
+    }
+
+    for (int jt = 0; jt < p.NT; ++jt) {
+        const int cur = jt & 1;
+        const bool more = jt + 1 < p.NT;
+        if (!CHOSEN && more) {
+            sk = *reinterpret_cast<const uint4*>(gk + (size_t)(jt + 1) * KT_U16);
+            sv = *reinterpret_cast<const uint4*>(gv + (size_t)(jt + 1) * VT_U16);
+            if (X3) {
+                skl = *reinterpret_cast<const uint4*>(gk_lo + (size_t)(jt + 1) * KT_U16);
+                svl = *reinterpret_cast<const uint4*>(gv_lo + (size_t)(jt + 1) * VT_U16);
+            }
+        }
+        if (active) {
+            const uint16_t* kt;
+            const uint16_t* vt;
+            const uint16_t* kt_lo = nullptr;
+            const uint16_t* vt_lo = nullptr;
+            if (CHOSEN) {
+                kt = p.KcF + ((size_t)c * p.NT + jt) * KT_U16 + lane * 8;
+                vt = p.VtF + ((size_t)c * p.NT + jt) * VT_U16 + lane * 8;
+                if (X3) {
+                    kt_lo = p.KcF_lo + ((size_t)c * p.NT + jt) * KT_U16 + lane * 8;
+                    vt_lo = p.VtF_lo + ((size_t)c * p.NT + jt) * VT_U16 + lane * 8;
+                }
+            } else {
+                kt = lds + cur * NBUF_U16 + lane * 8;
+                vt = kt + KT_U16;
+                if (X3) { kt_lo = kt + PART_U16; vt_lo = vt + PART_U16; }
+            }
+            // lse2 of the 16 support tuples this lane's accumulator rows belong to
+            float lse[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 u = *reinterpret_cast<const float4*>(lse_row + jt * 32 + 8 * q);
+                lse[4 * q + 0] = u.x; lse[4 * q + 1] = u.y; lse[4 * q + 2] = u.z; lse[4 * q + 3] = u.w;
+            }
+            // S^T tile = Kc[jt] * Kq[it]^T
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const bf16x8 ah = ld_frag(kt + ks * 512);
+                acc = MFMA_BF16(ah, q_hi[ks], acc);
+                if (X3) {
+                    const bf16x8 al = ld_frag(kt_lo + ks * 512);
+                    acc = MFMA_BF16(ah, q_lo[ks], acc);
+                    acc = MFMA_BF16(al, q_hi[ks], acc);
+                }
+            }
+            // A^T = exp2(S^T - lse2): accumulator rows 8s..8s+7 become k-step s of the B operand
+            bf16x8 a_hi[2], a_lo[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float pe = __builtin_amdgcn_exp2f(acc[8 * s + e] - lse[8 * s + e]);
+                    const __bf16 ph = (__bf16)pe;
+                    a_hi[s][e] = ph;
+                    if (X3) a_lo[s][e] = (__bf16)(pe - (float)ph);
+                }
+            // P^T += V^T[jt] * A^T
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bf16x8 vh = ld_frag(vt + (dt * 2 + s) * 512);
+                    pacc[dt] = MFMA_BF16(vh, a_hi[s], pacc[dt]);
+                    if (X3) {
+                        const bf16x8 vl = ld_frag(vt_lo + (dt * 2 + s) * 512);
+                        pacc[dt] = MFMA_BF16(vh, a_lo[s], pacc[dt]);
+                        pacc[dt] = MFMA_BF16(vl, a_hi[s], pacc[dt]);
+                    }
+                }
+        }
+        if (!CHOSEN) {
+            if (more) {
+                uint16_t* nb = lds + (cur ^ 1) * NBUF_U16;
+                *reinterpret_cast<uint4*>(nb + tid * 8) = sk;
+                *reinterpret_cast<uint4*>(nb + KT_U16 + tid * 8) = sv;
+                if (X3) {
+                    *reinterpret_cast<uint4*>(nb + PART_U16 + tid * 8) = skl;
+                    *reinterpret_cast<uint4*>(nb + PART_U16 + KT_U16 + tid * 8) = svl;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (!active) return;
+
+    // epilogue: lane owns query tuple i = 32 it + r; pacc[dt][reg] = P[i][32 dt + acc_row(reg,h)]
+    const int i = it * 32 + r;
+    const bool ivalid = i < p.T;
+    float ss = 0.f;
+    if (ivalid) {
+        const int f0 = p.tup[2 * i], f1 = p.tup[2 * i + 1];
+        const float* av = p.proj + (size_t)(b * p.L + f0) * 512 + 256 + 4 * h;
+        const float* bvp = p.proj + (size_t)(b * p.L + f1) * 512 + 384 + 4 * h;
+        const float* bias = p.bv + 4 * h;
+        float* dout = CHOSEN ? p.diff + ((size_t)b * p.T + i) * 128 + 4 * h : nullptr;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int d = 32 * dt + 8 * q;
+                const float4 x = *reinterpret_cast<const float4*>(av + d);
+                const float4 y = *reinterpret_cast<const float4*>(bvp + d);
+                const float4 z = *reinterpret_cast<const float4*>(bias + d);
+                float4 df;
+                df.x = (x.x + y.x + z.x) - pacc[dt][4 * q + 0];
+                df.y = (x.y + y.y + z.y) - pacc[dt][4 * q + 1];
+                df.z = (x.z + y.z + z.z) - pacc[dt][4 * q + 2];
+                df.w = (x.w + y.w + z.w) - pacc[dt][4 * q + 3];
+                if (CHOSEN) *reinterpret_cast<float4*>(dout + d) = df;
+                ss += df.x * df.x + df.y * df.y + df.z * df.z + df.w * df.w;
+            }
+    }
+    if (!CHOSEN) {
+#pragma unroll
+        for (int sh = 32; sh >= 1; sh >>= 1) ss += __shfl_xor(ss, sh, 64);
+        if (lane == 0) p.part[((size_t)b * p.n + c) * p.NT + it] = ss;
+    }
+}
+
+int launch_ar_proto(const ArProtoArgs& a, hipStream_t st) {
+    const bool chosen = a.chosen != nullptr;
+    dim3 grid(cdiv(a.B * a.NT, 8), chosen ? 1 : a.n);
+    if (a.x3) {
+        if (chosen) hipLaunchKernelGGL((ar_proto_kernel<true, true>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((ar_proto_kernel<true, false>), grid, dim3(512), 0, st, a);
+    } else {
+        if (chosen) hipLaunchKernelGGL((ar_proto_kernel<false, true>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((ar_proto_kernel<false, false>), grid, dim3(512), 0, st, a);
+    }
+    ISB_HIP(hipGetLastError());
+    return ISB_OK;
+}
+
+// =====================================================================================
+// finalize: logits[b,c] = -(sum_it part) / T, chosen[b] = first argmax (model.py:133-137,323)
+// one wave per window
+// =====================================================================================
+__global__ __launch_bounds__(64) void ar_finalize_kernel(ArFinalArgs p) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+    for (int c = lane; c < p.n; c += 64) {
+        const float* pp = p.part + ((size_t)b * p.n + c) * p.NT;
+        float s = 0.f;
+        for (int t = 0; t < p.NT; ++t) s += pp[t];
+        const float lg = -s / (float)p.T;
+        p.logits[(size_t)b * p.n + c] = lg;
+        if (lg > best || (lg == best && c < besti) || besti == 0x7fffffff) { best = lg; besti = c; }
+    }
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) {
+        const float ob = __shfl_xor(best, sh, 64);
+        const int oi = __shfl_xor(besti, sh, 64);
+        if (oi != 0x7fffffff && (besti == 0x7fffffff || ob > best || (ob == best && oi < besti))) { best = ob; besti = oi; }
+    }
+    if (lane == 0) p.chosen[b] = besti;
+}
+
+int launch_ar_finalize(const ArFinalArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(ar_finalize_kernel, dim3(a.B), dim3(64), 0, st, a);
+    ISB_HIP(hipGetLastError());
+    return ISB_OK;
+}
+
+// =====================================================================================
+// Discriminator tail: fc2 + ReLU + fc3 + sigmoid (model.py:199-203); one wave per window
+// =====================================================================================
+__global__ __launch_bounds__(64) void ar_disc_tail_kernel(ArDiscTailArgs p) {
+    __shared__ float hrow[256];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    for (int k = lane; k < 256; k += 64) hrow[k] = p.h1[(size_t)b * 256 + k];
+    __syncthreads();
+    const float* w = p.w2 + (size_t)lane * 256;
+    float acc = 0.f;
+    for (int k = 0; k < 256; ++k) acc = fmaf(hrow[k], w[k], acc);
+    acc += p.b2[lane];
+    acc = acc > 0.f ? acc : 0.f;
+    float y = acc * p.w3[lane];
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) y += __shfl_xor(y, sh, 64);
+    if (lane == 0) {
+        y += p.b3[0];
+        p.is_true[b] = 1.0f / (1.0f + expf(-y));
+    }
+}
+
+int launch_ar_disc_tail(const ArDiscTailArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(ar_disc_tail_kernel, dim3(a.B), dim3(64), 0, st, a);
+    ISB_HIP(hipGetLastError());
+    return ISB_OK;
+}
+
+}  // namespace isb

@@ -1,0 +1,95 @@
+// Shared host-side helpers of libisbfsar_hip.so: error channel, HIP checks, ISBW blob reader,
+// device buffers.  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/isbfsar.h"
+
+namespace isb {
+
+void set_error(const char* fmt, ...);
+
+#define ISB_HIP(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            isb::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                           __LINE__);                                                        \
+            return ISB_ERR_HIP;                                                              \
+        }                                                                                    \
+    } while (0)
+
+#define ISB_REQUIRE(cond, code, ...)       \
+    do {                                   \
+        if (!(cond)) {                     \
+            isb::set_error(__VA_ARGS__);   \
+            return (code);                 \
+        }                                  \
+    } while (0)
+
+#define ISB_TRY(expr)              \
+    do {                           \
+        int _rc = (expr);          \
+        if (_rc != ISB_OK) return _rc; \
+    } while (0)
+
+struct BlobTensor {
+    const float* data = nullptr;
+    uint32_t ndim = 0;
+    uint32_t dims[4] = {1, 1, 1, 1};
+    size_t numel() const { return (size_t)dims[0] * dims[1] * dims[2] * dims[3]; }
+};
+
+// Parses an ISBW v1 blob (isbfsar_amd/weights.py) in place; pointers reference the blob.
+int parse_blob(const void* blob, size_t nbytes, std::map<std::string, BlobTensor>& out);
+// Fetch + shape-check one tensor.
+int blob_get(const std::map<std::string, BlobTensor>& m, const char* name, uint32_t d0, uint32_t d1,
+             const BlobTensor** out);
+
+// Owning device allocation.
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    int alloc(size_t n) {
+        release();
+        if (n == 0) n = 16;
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) {
+            p = nullptr;
+            set_error("hipMalloc(%zu) failed: %s", n, hipGetErrorString(e));
+            return ISB_ERR_NOMEM;
+        }
+        bytes = n;
+        return ISB_OK;
+    }
+    template <class T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+inline int upload(DevBuf& b, const void* src, size_t n) {
+    ISB_TRY(b.alloc(n));
+    ISB_HIP(hipMemcpy(b.p, src, n, hipMemcpyHostToDevice));
+    return ISB_OK;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t cdivz(size_t a, size_t b) { return (a + b - 1) / b; }
+
+}  // namespace isb

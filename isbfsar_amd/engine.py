@@ -1,0 +1,128 @@
+"""Thin object wrappers over the C ABI handles (include/isbfsar.h).
+
+numpy arrays go through the ``*_host`` entry points (H2D + kernels + D2H, like the reference's
+``Runner.__call__``, utils/tensorrt_runner.py:64-77); torch CUDA tensors are passed by device
+pointer on torch's current stream -- torch is only the owner of device memory and streams here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Mapping, Optional, Tuple, Union
+
+import numpy as np
+
+from . import _lib
+from .weights import pack_blob
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32c(a, shape=None) -> np.ndarray:
+    out = np.ascontiguousarray(a, dtype=np.float32)
+    if shape is not None and tuple(out.shape) != tuple(shape):
+        raise ValueError(f"expected shape {tuple(shape)}, got {tuple(out.shape)}")
+    return out
+
+
+class ArEngine:
+    """TRXOS (skeleton branch + Discriminator) on one MI355X. Mirrors ``TRXOS.forward``
+    (reference modules/ar/utils/model.py:291-328) for B windows sharing one support set."""
+
+    def __init__(self, seq_len: int, n_joints: int, way_max: int, device: int = 0,
+                 precision: Union[int, str] = "bf16", max_batch: int = 1024):
+        prec = {"bf16": _lib.ISB_AR_PREC_BF16, "bf16x3": _lib.ISB_AR_PREC_BF16X3}.get(precision, precision)
+        self.L, self.J, self.way_max, self.device = seq_len, n_joints, way_max, device
+        self.precision = "bf16x3" if prec == _lib.ISB_AR_PREC_BF16X3 else "bf16"
+        self.n = 0
+        self._h = C.c_void_p()
+        cfg = _lib.isb_ar_cfg(seq_len, n_joints, way_max, device, prec, max_batch)
+        _lib.check(_lib.lib().isb_ar_create(C.byref(cfg), C.byref(self._h)), "isb_ar_create")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            _lib.lib().isb_ar_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- weights -------------------------------------------------------------------------
+    def load_weights(self, state: Union[bytes, Mapping[str, np.ndarray]]):
+        blob = state if isinstance(state, (bytes, bytearray)) else pack_blob(state)
+        buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+        _lib.check(_lib.lib().isb_ar_load_weights(self._h, C.cast(buf, C.c_void_p), len(blob)),
+                   "isb_ar_load_weights")
+        self.n = 0
+
+    # -- support set ---------------------------------------------------------------------
+    def set_support(self, poses: Optional[np.ndarray] = None, features: Optional[np.ndarray] = None):
+        if (poses is None) == (features is None):
+            raise ValueError("give exactly one of poses [n,L,3J] / features [n,L,256]")
+        if poses is not None:
+            poses = _f32c(poses)
+            n = poses.shape[0]
+            _f32c(poses, (n, self.L, 3 * self.J))
+        else:
+            features = _f32c(features)
+            n = features.shape[0]
+            _f32c(features, (n, self.L, 256))
+        _lib.check(_lib.lib().isb_ar_set_support(self._h, _ptr(poses), _ptr(features), n), "isb_ar_set_support")
+        self.n = n
+
+    def support_features(self) -> np.ndarray:
+        out = np.empty((self.n, self.L, 256), np.float32)
+        _lib.check(_lib.lib().isb_ar_get_support_features(self._h, _ptr(out)), "isb_ar_get_support_features")
+        return out
+
+    # -- inference -----------------------------------------------------------------------
+    def infer(self, windows, want_embed: bool = False):
+        """windows [B,L,3J]: numpy -> numpy results; torch CUDA tensor -> torch CUDA results
+        (asynchronous on the current stream). Returns (logits [B,n], is_true [B], embed|None)."""
+        if isinstance(windows, np.ndarray):
+            w = _f32c(windows)
+            B = w.shape[0]
+            _f32c(w, (B, self.L, 3 * self.J))
+            logits = np.empty((B, self.n), np.float32)
+            is_true = np.empty((B,), np.float32)
+            embed = np.empty((B, self.L, 256), np.float32) if want_embed else None
+            _lib.check(_lib.lib().isb_ar_infer_host(self._h, _ptr(w), B, _ptr(logits), _ptr(is_true), _ptr(embed)),
+                       "isb_ar_infer_host")
+            return logits, is_true, embed
+        import torch
+
+        if not (isinstance(windows, torch.Tensor) and windows.is_cuda):
+            raise TypeError("windows must be a numpy array or a torch CUDA tensor")
+        if windows.device.index != self.device:
+            raise ValueError(f"windows live on cuda:{windows.device.index}, engine on cuda:{self.device}")
+        w = windows.contiguous().float()
+        B = w.shape[0]
+        if tuple(w.shape) != (B, self.L, 3 * self.J):
+            raise ValueError(f"expected [B,{self.L},{3 * self.J}], got {tuple(w.shape)}")
+        logits = torch.empty((B, self.n), dtype=torch.float32, device=w.device)
+        is_true = torch.empty((B,), dtype=torch.float32, device=w.device)
+        embed = torch.empty((B, self.L, 256), dtype=torch.float32, device=w.device) if want_embed else None
+        stream = torch.cuda.current_stream(w.device).cuda_stream
+        _lib.check(_lib.lib().isb_ar_infer(self._h, w.data_ptr(), B, logits.data_ptr(), is_true.data_ptr(),
+                                           embed.data_ptr() if want_embed else None, C.c_void_p(stream)),
+                   "isb_ar_infer")
+        return logits, is_true, embed
+
+    def last_chosen(self, B: int) -> np.ndarray:
+        out = np.empty((B,), np.int32)
+        _lib.check(_lib.lib().isb_ar_last_chosen(self._h, _ptr(out), B), "isb_ar_last_chosen")
+        return out
+
+    # -- profiling of the tuple-attention kernels (bench.py roofline) ------------------------
+    def profile(self, enable: bool):
+        _lib.check(_lib.lib().isb_ar_profile(self._h, int(enable)), "isb_ar_profile")
+
+    def profile_read(self) -> Tuple[float, int]:
+        ms = C.c_double()
+        n = C.c_int64()
+        _lib.check(_lib.lib().isb_ar_profile_read(self._h, C.byref(ms), C.byref(n)), "isb_ar_profile_read")
+        return ms.value, n.value

@@ -12,7 +12,7 @@ Blob layout (little endian), consumed by ``isb_ar_load_weights`` / ``isb_hpe_loa
     u32      version = 1
     u32      n_tensors
     u32      reserved
-    n_tensors x { char[96] name (NUL padded); u32 ndim; u32 dims[4]; u64 offset; u64 nbytes }
+    n_tensors x { char[96] name (NUL padded); u32 ndim; u32 dims[4]; u32 pad; u64 offset; u64 nbytes }
     payload  fp32 tensors, each 64-byte aligned, offsets relative to blob start
 
 The generator is counter based (splitmix64 over ``fnv1a(name) ^ seed + index``) so that any
@@ -29,7 +29,7 @@ import numpy as np
 MAGIC = b"ISBW"
 VERSION = 1
 _NAME_LEN = 96
-_ENTRY = struct.Struct("<96sI4IQQ")
+_ENTRY = struct.Struct("<96sI4I4xQQ")
 _HEADER = struct.Struct("<4sIII")
 
 _M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
