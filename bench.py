@@ -106,7 +106,7 @@ class ArWorkload:
     def cpu_baseline(self, sample):
         from oracle.ar_oracle import TRXOSOracle
         import torch
-        n = sample or 32
+        n = sample or 128
         cores = os.cpu_count() or 1
         torch.set_num_threads(cores)
         net = TRXOSOracle(self.state, self.L, self.J)

@@ -61,6 +61,13 @@ def lib() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise IsbError(f"{LIB_PATH} is missing: run `python -m isbfsar_amd.build` (hipcc, gfx950). "
                            "There is no CPU fallback.")
+        # torch bundles its own libamdhip64.so (same SONAME as /opt/rocm's). Both the device
+        # pointers torch hands us and our kernels must live in ONE HIP runtime instance, so let
+        # torch's copy load first; the dynamic linker then binds our NEEDED entry to it.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(_lib, name)
