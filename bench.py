@@ -107,7 +107,8 @@ class ArWorkload:
         from oracle.ar_oracle import TRXOSOracle
         import torch
         n = sample or 128
-        cores = os.cpu_count() or 1
+        from bench_workloads import usable_cores
+        cores = usable_cores()
         torch.set_num_threads(cores)
         net = TRXOSOracle(self.state, self.L, self.J)
         sf = net.mlp(self.ss)
@@ -131,12 +132,8 @@ class ArWorkload:
 
 def pick_workload(name):
     if name in ("auto", "pipeline", "hpe"):
-        try:
-            from isbfsar_amd import bench_pipeline  # appears once the HPE stage exists
-            return bench_pipeline.get(name)
-        except ImportError:
-            if name != "auto":
-                raise
+        import bench_workloads
+        return bench_workloads.get(name)
     return ArWorkload
 
 

@@ -1,0 +1,210 @@
+"""bench.py workloads that include the pose stage (bench support, not product code: the
+cpu_baseline legs import oracle/).
+
+pipeline : BASELINE.json configs[3] per-GPU shard -- 256 synthetic 640x480 frames per GPU (8 cameras
+           x 32 time steps) -> HPE (122 joints) -> 30-deep ring per camera -> 256 skeleton windows ->
+           AR embed + 60-class tuple cross-attention match + open-set score (-> all-gather when N>1)
+hpe      : BASELINE.json configs[1] -- 256 frames, pose stage only
+"""
+from __future__ import annotations
+
+import json
+import os
+import time
+
+import numpy as np
+
+from isbfsar_amd import effnetv2, synth, weights
+from isbfsar_amd.engine import ArEngine
+from isbfsar_amd.hpe_engine import HpeEngine, pose_windows
+
+MFMA_PEAK_TFLOPS_BF16 = 2500.0     # MI355X_MICROARCH.md, dense
+_ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "isbfsar_amd", "assets")
+
+
+def usable_cores() -> int:
+    """CPU threads this process may actually use (affinity mask and cgroup quota), not the host's."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+            if q != "max":
+                n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def igemm_macs_per_crop() -> int:
+    """MACs executed by conv_igemm_kernel per crop (all 3x3/1x1 convs except the f32 stem)."""
+    m = 0
+    for b in effnetv2.blocks():
+        o = b.out_hw * b.out_hw
+        if b.kind == "fused":
+            m += o * 9 * b.cin * b.cexp
+            if b.cexp != b.cin:
+                m += o * b.cexp * b.cout
+        else:
+            m += b.in_hw * b.in_hw * b.cin * b.cexp + o * b.cexp * b.cout
+    return m + 64 * 640 * effnetv2.HEAD_OUT
+
+
+class _HpeBase:
+    L, J = 30, 122
+    precision = "bf16"
+
+    def _setup_hpe(self, args, rank, dev):
+        import torch
+        self.torch = torch
+        self.B = args.batch or 256
+        self.dev = dev
+        self.bb_state = effnetv2.make_state(0)
+        self.hpe = HpeEngine(device=dev, max_batch=min(self.B, 256))
+        self.hpe.load_weights(self.bb_state)
+        self.hpe.set_joint_map(np.load(os.path.join(_ASSETS, "32_to_122.npy")), None)   # skeleton=None -> 122 joints
+        self.frames_host = synth.frames(self.B, seed=10_000 * rank)
+        self.bbox_host = synth.bboxes(self.B, seed=10_000 * rank)
+        self.frames = torch.from_numpy(self.frames_host).cuda(dev)
+        self.bbox = torch.from_numpy(self.bbox_host).cuda(dev)
+
+    def _hpe_roofline(self, steps):
+        self.hpe.profile(True)
+        for _ in range(steps):
+            self.step()
+        self.torch.cuda.synchronize()
+        ms, launches = self.hpe.profile_read()
+        self.hpe.profile(False)
+        flops = 2.0 * igemm_macs_per_crop() * self.B * steps
+        achieved = flops / (ms / 1e3) / 1e12
+        return {"bound": "mfma", "kernel": "conv_igemm_kernel (all launches of a forward pass)",
+                "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS_BF16, "unit": "TFLOP/s",
+                "frac": round(achieved / MFMA_PEAK_TFLOPS_BF16, 4), "traffic": None,
+                "avg_launch_ms": round(ms / max(launches, 1), 5), "launches": int(launches),
+                "flops_per_step": flops / steps}
+
+    def _cpu_hpe_seconds_per_frame(self, n):
+        from oracle import hpe_oracle as ho
+        from oracle.effnetv2_oracle import EffNetV2LOracle
+        import torch
+        torch.set_num_threads(usable_cores())
+        K = ho.intrinsics_matrix(384.025146484375, 384.025146484375, 319.09661865234375, 237.75723266601562)
+        net = EffNetV2LOracle(self.bb_state, "f32")
+        W = np.load(os.path.join(_ASSETS, "32_to_122.npy"))
+        t0 = time.perf_counter()
+        for i in range(n):
+            nk, r, H = ho.crop_params(self.bbox_host[i], K)
+            crop = ho.warp(self.frames_host[i], H[0])
+            lg = net.head(net.backbone(crop[None]))
+            ho.postprocess(lg, nk, r, W, None)
+        return (time.perf_counter() - t0) / n
+
+
+class HpeWorkload(_HpeBase):
+    name = "hpe"
+    metric = "frames/sec (640x480 frame -> crop -> EfficientNetV2-L -> 3D pose, 122 joints)"
+    unit = "frames/s"
+
+    def __init__(self, args, rank, world, dev):
+        self._setup_hpe(args, rank, dev)
+        self.world = world
+
+    def units_per_step(self):
+        return self.B
+
+    def step(self):
+        self.out = self.hpe.forward(self.frames, self.bbox)
+
+    def roofline(self, steps):
+        return self._hpe_roofline(steps)
+
+    def cpu_baseline(self, sample):
+        n = sample or 8
+        self._cpu_hpe_seconds_per_frame(1)
+        spf = self._cpu_hpe_seconds_per_frame(n)
+        return {"value": round(1.0 / spf, 3), "unit": "frames/s", "cores": usable_cores(), "kind": "port",
+                "sample": f"{n} frames through the fp32 CPU oracle (numpy geometry + torch-CPU EfficientNetV2-L), {spf * n:.1f} s"}
+
+    def config(self, world):
+        return {"workload": f"BASELINE configs[1]: B={self.B} synthetic 640x480 frames/GPU, HPE only "
+                            "(homography crop, EfficientNetV2-L bf16, head, decode, reconstruction)",
+                "per_gpu_batch": self.B, "n_joints": self.J, "parallelism": f"dp{world}"}
+
+
+class PipelineWorkload(_HpeBase):
+    name = "pipeline"
+    metric = "end-to-end pipelines/sec (frame -> 3D pose -> 30-frame window embed -> 60-class match + open-set score)"
+    unit = "pipelines/s"
+    N_CAM = 8
+
+    def __init__(self, args, rank, world, dev):
+        import torch
+        self._setup_hpe(args, rank, dev)
+        self.world = world
+        self.way = args.way
+        self.ar_precision = args.precision
+        if self.B % self.N_CAM:
+            raise SystemExit(f"--batch must be a multiple of {self.N_CAM} cameras")
+        self.steps_per_cam = self.B // self.N_CAM
+        self.ar_state = weights.make_ar_state(self.L, self.J, seed=1)
+        self.ss = synth.skeleton_windows(self.way, self.L, self.J, seed=101)
+        self.ar = ArEngine(self.L, self.J, self.way, device=dev, precision=self.ar_precision, max_batch=self.B)
+        self.ar.load_weights(self.ar_state)
+        self.ar.set_support(poses=self.ss)
+        # per-camera ring: L-1 poses of history + this step's poses
+        hist = synth.skeleton_windows(self.N_CAM, self.L - 1, self.J, seed=555 + rank).reshape(self.N_CAM, self.L - 1, self.J, 3)
+        self.ring = torch.zeros((self.N_CAM, self.L - 1 + self.steps_per_cam, self.J, 3), dtype=torch.float32, device=f"cuda:{dev}")
+        self.ring[:, : self.L - 1] = torch.from_numpy(hist).cuda(dev)
+        self.checked = False
+
+    def units_per_step(self):
+        return self.B
+
+    def step(self):
+        torch = self.torch
+        joints, valid = self.hpe.forward(self.frames, self.bbox)                 # [B,122,3]
+        if not self.checked:
+            assert bool(valid.all().item()), "synthetic frames are expected to give in-FOV poses"
+            self.checked = True
+        self.ring[:, self.L - 1:] = joints.view(self.N_CAM, self.steps_per_cam, self.J, 3)
+        windows = pose_windows(self.ring, self.L)                                 # [B,L,3J], root-centred
+        logits, is_true, embed = self.ar.infer(windows, want_embed=self.world > 1)
+        self.ring[:, : self.L - 1] = self.ring[:, self.steps_per_cam:].clone()     # slide the history
+        if self.world > 1:
+            import torch.distributed as dist
+            rec = torch.cat([logits, is_true[:, None], embed.reshape(self.B, -1)], dim=1)
+            out = torch.empty((self.world * self.B, rec.shape[1]), dtype=rec.dtype, device=rec.device)
+            dist.all_gather_into_tensor(out, rec)
+            self.out = out
+        else:
+            self.out = (logits, is_true)
+
+    def roofline(self, steps):
+        return self._hpe_roofline(steps)
+
+    def cpu_baseline(self, sample):
+        from oracle.ar_oracle import TRXOSOracle
+        n = sample or 6
+        self._cpu_hpe_seconds_per_frame(1)
+        spf = self._cpu_hpe_seconds_per_frame(n)
+        net = TRXOSOracle(self.ar_state, self.L, self.J)
+        sf = net.mlp(self.ss)
+        q = synth.skeleton_windows(32, self.L, self.J, seed=9)
+        net.forward(None, self.way, q[:2], ss_features=sf)
+        t0 = time.perf_counter()
+        net.forward(None, self.way, q, ss_features=sf)
+        spw = (time.perf_counter() - t0) / len(q)
+        return {"value": round(1.0 / (spf + spw), 3), "unit": "pipelines/s", "cores": usable_cores(), "kind": "port",
+                "sample": f"{n} frames through the fp32 pose oracle ({spf * 1e3:.0f} ms/frame) + {len(q)} windows through "
+                          f"the AR oracle ({spw * 1e3:.0f} ms/window); pipelines/s = 1/(sum)"}
+
+    def config(self, world):
+        return {"workload": f"BASELINE configs[3] per-GPU shard: {self.B} synthetic 640x480 frames/GPU "
+                            f"({self.N_CAM} cameras x {self.steps_per_cam} steps) -> HPE (EfficientNetV2-L bf16, 122 joints) -> "
+                            f"30-frame windows -> AR (way={self.way}) -> open-set score",
+                "per_gpu_batch": self.B, "seq_len": self.L, "n_joints": self.J, "way": self.way,
+                "ar_precision": self.ar_precision,
+                "parallelism": f"dp{world} (frames sharded; one all-gather of per-window records)"}
+
+
+def get(name: str):
+    return HpeWorkload if name == "hpe" else PipelineWorkload

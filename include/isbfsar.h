@@ -14,8 +14,9 @@
  *   - pointers named d_* are DEVICE pointers (HBM of the handle's device); h_* are host
  *     pointers.  The caller owns every buffer it passes; the library never returns internal
  *     pointers and keeps no reference to host memory after a call returns.
- *   - `stream` is a hipStream_t passed as void* (NULL = the handle's own stream).  Calls are
- *     asynchronous on that stream unless documented otherwise (the *_host variants synchronise).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the HIP null stream, which is what
+ *     PyTorch's default stream is).  Calls are asynchronous on that stream unless documented
+ *     otherwise; the *_host variants run on a private stream and synchronise before returning.
  *   - a handle is bound to one device and is not thread safe: one handle per process / rank.
  */
 #ifndef ISBFSAR_H
@@ -102,6 +103,75 @@ int isb_ar_last_chosen(isb_ar* h, int32_t* h_chosen, int32_t B);
  * Used by bench.py's roofline object. */
 int isb_ar_profile(isb_ar* h, int32_t enable);
 int isb_ar_profile_read(isb_ar* h, double* ms_total, int64_t* launches);
+
+/* ------------------------------------------------------------------------------------------
+ * Human pose estimation: crop homography -> warp -> EfficientNetV2-L -> pose head -> soft-argmax
+ * decode -> absolute reconstruction -> joint expansion/selection
+ *   replaces  HumanPoseEstimator.__init__  modules/hpe/hpe.py:15-46  (K, joint assets, 4 engines)
+ *             HumanPoseEstimator.estimate  modules/hpe/hpe.py:76-173 (everything after the detector)
+ *   and the four Runner(...) calls it makes (utils/tensorrt_runner.py:64-77; hpe.py:97,103,106).
+ * The YOLOv4 detector (hpe.py:51-73) is bypassed: the caller supplies the person box
+ * (x1,x2,y1,y2 pixel ints, the order estimate() returns them in, hpe.py:173).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct isb_hpe isb_hpe;
+
+typedef struct isb_hpe_cfg {
+    float fx, fy, ppx, ppy;   /* RealSenseIntrinsics (utils/params.py:40-47) -> K, hpe.py:28-33 */
+    int32_t width, height;    /* frame size (640 x 480) */
+    int32_t device;           /* HIP device ordinal */
+    int32_t max_batch;        /* frames per internal micro-batch (activation workspace); 0 = 64 */
+    int32_t n_out_joints;     /* informational: joints per pose after selection (30 / 122) */
+    int32_t reserved;
+} isb_hpe_cfg;
+
+int isb_hpe_create(const isb_hpe_cfg* cfg, isb_hpe** out);
+void isb_hpe_destroy(isb_hpe* h);
+/* ISBW blob with bbone.* (EfficientNetV2-L, folded BN) and head.{weight,bias} (Linear(1280,288),
+ * modules/hpe/setup/4_create_heads_onnx.py:10,22-25). Replaces the bbone1/heads1 engine
+ * deserialisation (hpe.py:45-46). Synchronous. */
+int isb_hpe_load_weights(isb_hpe* h, const void* h_blob, size_t nbytes);
+/* assets/32_to_122.npy [32,122] and skeleton_types[...]['indices'] (hpe.py:37-39,162-164);
+ * h_indices NULL = keep all 122 joints (skeleton=None) */
+int isb_hpe_set_joint_map(isb_hpe* h, const float* h_expand, const int32_t* h_indices, int32_t n_out);
+
+/* estimate() for B frames:
+ *   d_frames [B,height,width,3] u8 BGR    the frame main.py:74 puts on the HPE queue
+ *   d_bbox   [B,4] i32  x1,x2,y1,y2       detector result (hpe.py:76-79)
+ *   d_joints [B,n_out,3] f32              result["pose"] (un-centred; hpe.py:169,171)
+ *   d_valid  [B] u8                       0 where estimate() would return None (hpe.py:152-153)
+ * Asynchronous on `stream`; internally micro-batched by max_batch. */
+int isb_hpe_forward(isb_hpe* h, const uint8_t* d_frames, const int32_t* d_bbox, int32_t B, float* d_joints,
+                    uint8_t* d_valid, void* stream);
+int isb_hpe_forward_host(isb_hpe* h, const uint8_t* h_frames, const int32_t* h_bbox, int32_t B, float* h_joints,
+                         uint8_t* h_valid);
+
+/* stage-level entry points (host buffers, synchronous, B <= max_batch): each stage can be pinned
+ * against the oracle on its own.
+ *   crop_params : misc.homography + hpe.py:96       -> H f32 [B,9], new_K f64 [B,9], R f64 [B,9]
+ *   warp        : hpe.py:97-100                      -> crops f32 [B,256,256,3] in [0,1], BGR
+ *   backbone    : hpe.py:103,106                     crops -> features f32 [B,8,8,1280] (may be NULL),
+ *                                                              head logits f32 [B,8,8,288] (may be NULL)
+ *   post        : hpe.py:109-169                     head logits + bbox -> joints, valid,
+ *                                                    optional pred f64 [B,32,5] = pred2d(x,y), pred3d(x,y,z) */
+int isb_hpe_crop_params_host(isb_hpe* h, const int32_t* h_bbox, int32_t B, float* h_H, double* h_newK, double* h_R);
+int isb_hpe_warp_host(isb_hpe* h, const uint8_t* h_frames, const int32_t* h_bbox, int32_t B, float* h_crops);
+int isb_hpe_backbone_host(isb_hpe* h, const float* h_crops, int32_t B, float* h_features, float* h_logits);
+int isb_hpe_post_host(isb_hpe* h, const float* h_logits, const int32_t* h_bbox, int32_t B, float* h_joints,
+                      uint8_t* h_valid, double* h_pred);
+
+/* device time of the dominant kernel family (conv_igemm_kernel, every launch of a forward pass),
+ * HIP events on the launch stream; used by bench.py's roofline object */
+int isb_hpe_profile(isb_hpe* h, int32_t enable);
+int isb_hpe_profile_read(isb_hpe* h, double* ms_total, int64_t* launches);
+
+/* ------------------------------------------------------------------------------------------
+ * Glue between the two stages (main.py:102-105 + ar.py:42-50): root-centre every pose on joint 0,
+ * flatten to 3J and cut sliding windows of L consecutive frames per camera.
+ *   d_joints  [n_cam, n_frames, J, 3] f32
+ *   d_windows [n_cam * (n_frames - L + 1), L, 3J] f32   (camera-major, oldest frame first)
+ * ---------------------------------------------------------------------------------------- */
+int isb_pose_windows(const float* d_joints, int32_t n_cam, int32_t n_frames, int32_t J, int32_t L,
+                     float* d_windows, void* stream);
 
 #ifdef __cplusplus
 }

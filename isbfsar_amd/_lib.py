@@ -47,11 +47,22 @@ SIGNATURES = {
     "isb_ar_last_chosen": (C.c_int, [_P, _P, C.c_int32]),
     "isb_ar_profile": (C.c_int, [_P, C.c_int32]),
     "isb_ar_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "isb_hpe_create": (C.c_int, [C.POINTER(isb_hpe_cfg), C.POINTER(_P)]),
+    "isb_hpe_destroy": (None, [_P]),
+    "isb_hpe_load_weights": (C.c_int, [_P, _P, C.c_size_t]),
+    "isb_hpe_set_joint_map": (C.c_int, [_P, _P, _P, C.c_int32]),
+    "isb_hpe_forward": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P]),
+    "isb_hpe_forward_host": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P]),
+    "isb_hpe_crop_params_host": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P]),
+    "isb_hpe_warp_host": (C.c_int, [_P, _P, _P, C.c_int32, _P]),
+    "isb_hpe_backbone_host": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
+    "isb_hpe_post_host": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P]),
+    "isb_hpe_profile": (C.c_int, [_P, C.c_int32]),
+    "isb_hpe_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "isb_pose_windows": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
 }
-
-
-def register(extra: dict) -> None:
-    SIGNATURES.update(extra)
+# NOTE: every entry point must be listed here BEFORE the first lib() call: a function without
+# argtypes silently truncates Python-int pointers (torch data_ptr()) to 32 bits.
 
 
 def lib() -> C.CDLL:

@@ -38,6 +38,8 @@ struct isb_ar {
 
 namespace {
 
+constexpr int kDiscMaxSplits = 64;
+
 int ensure_ws(isb_ar* h, int Bc) {
     if (Bc <= h->ws_B) return ISB_OK;
     const size_t B = Bc, L = h->L, nmax = h->cfg.way_max;
@@ -51,7 +53,7 @@ int ensure_ws(isb_ar* h, int Bc) {
     ISB_TRY(h->part.alloc(B * nmax * h->NT * 4));
     ISB_TRY(h->diff.alloc(B * h->T * 128 * 4));
     ISB_TRY(h->y1.alloc(B * h->T * L * 4));
-    ISB_TRY(h->f1.alloc(B * 256 * 4));
+    ISB_TRY(h->f1.alloc(B * 256 * 4 * kDiscMaxSplits));
     ISB_TRY(h->logits_tmp.alloc(B * nmax * 4));
     h->ws_B = Bc;
     return ISB_OK;
@@ -279,7 +281,7 @@ extern "C" int isb_ar_infer(isb_ar* h, const float* d_windows, int32_t B, float*
     ISB_REQUIRE(B >= 1, ISB_ERR_INVALID, "batch %d < 1", B);
     ISB_REQUIRE(h->weights && h->support, ISB_ERR_STATE, "isb_ar_infer needs weights and a support set");
     ISB_HIP(hipSetDevice(h->cfg.device));
-    hipStream_t st = stream ? (hipStream_t)stream : h->own_stream;
+    hipStream_t st = (hipStream_t)stream;   // NULL = the HIP null stream (torch's default stream)
     const int Bc_max = std::min<int>(B, h->cfg.max_batch);
     ISB_TRY(ensure_ws(h, Bc_max));
     if (B > h->chosen_cap) {
@@ -343,9 +345,16 @@ extern "C" int isb_ar_infer(isb_ar* h, const float* d_windows, int32_t B, float*
         ISB_TRY(launch_ar_proto(pa, st));
         ISB_TRY(gemm(st, h->diff.as<float>(), 128, h->wd.as<float>(), 128, h->bd.as<float>(), h->y1.as<float>(), L,
                      Bc * T, L, 128, GEMM_ACT_NONE));
-        ISB_TRY(gemm(st, h->y1.as<float>(), T * L, h->wf1.as<float>(), T * L, h->bf1.as<float>(), h->f1.as<float>(),
-                     256, Bc, 256, T * L, GEMM_ACT_RELU));
+        // fc1 is a long-K, skinny GEMM: split K over the grid, partials summed in order by the tail kernel
+        const int nkt = cdiv(T * L, 32);
+        const int splits = std::max(1, std::min(std::min(nkt, kDiscMaxSplits), 512 / std::max(1, cdiv(Bc, 128) * 2)));
+        GemmF32Args g1{};
+        g1.A = h->y1.as<float>(); g1.lda = T * L; g1.W = h->wf1.as<float>(); g1.ldw = T * L; g1.C = h->f1.as<float>();
+        g1.ldc = 256; g1.M = Bc; g1.N = 256; g1.K = T * L; g1.add_period = 1; g1.act = GEMM_ACT_NONE;
+        g1.splits = splits; g1.split_stride = (size_t)Bc * 256;
+        ISB_TRY(launch_gemm_f32(g1, st));
         ArDiscTailArgs da{};
+        da.b1 = h->bf1.as<float>(); da.n_parts = splits; da.part_stride = (size_t)Bc * 256;
         da.h1 = h->f1.as<float>(); da.w2 = h->wf2.as<float>(); da.b2 = h->bf2.as<float>();
         da.w3 = h->wf3.as<float>(); da.b3 = h->bf3.as<float>(); da.is_true = d_is_true + b0; da.B = Bc;
         ISB_TRY(launch_ar_disc_tail(da, st));

@@ -169,7 +169,7 @@ int launch_ar_tuples(const ArTupleArgs& a, hipStream_t st) {
     dim3 grid(a.NT, a.n_items);
     hipLaunchKernelGGL(ar_tuples_k_kernel, grid, dim3(512), 0, st, a);
     if (a.VtF) hipLaunchKernelGGL(ar_tuples_vt_kernel, grid, dim3(512), 0, st, a);
-    ISB_HIP(hipGetLastError());
+    ISB_LAUNCHED("ar_tuples", st);
     return ISB_OK;
 }
 
@@ -296,7 +296,7 @@ int launch_ar_stats(const ArStatsArgs& a, hipStream_t st) {
         if (online) hipLaunchKernelGGL((ar_stats_kernel<false, true>), grid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((ar_stats_kernel<false, false>), grid, dim3(512), 0, st, a);
     }
-    ISB_HIP(hipGetLastError());
+    ISB_LAUNCHED("ar_stats", st);
     return ISB_OK;
 }
 
@@ -494,7 +494,7 @@ int launch_ar_proto(const ArProtoArgs& a, hipStream_t st) {
         if (chosen) hipLaunchKernelGGL((ar_proto_kernel<false, true>), grid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((ar_proto_kernel<false, false>), grid, dim3(512), 0, st, a);
     }
-    ISB_HIP(hipGetLastError());
+    ISB_LAUNCHED("ar_proto", st);
     return ISB_OK;
 }
 
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(64) void ar_finalize_kernel(ArFinalArgs p) {
 
 int launch_ar_finalize(const ArFinalArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(ar_finalize_kernel, dim3(a.B), dim3(64), 0, st, a);
-    ISB_HIP(hipGetLastError());
+    ISB_LAUNCHED("ar_finalize", st);
     return ISB_OK;
 }
 
@@ -535,7 +535,11 @@ int launch_ar_finalize(const ArFinalArgs& a, hipStream_t st) {
 __global__ __launch_bounds__(64) void ar_disc_tail_kernel(ArDiscTailArgs p) {
     __shared__ float hrow[256];
     const int b = blockIdx.x, lane = threadIdx.x;
-    for (int k = lane; k < 256; k += 64) hrow[k] = p.h1[(size_t)b * 256 + k];
+    for (int k = lane; k < 256; k += 64) {
+        float v = p.b1[k];
+        for (int s = 0; s < p.n_parts; ++s) v += p.h1[(size_t)s * p.part_stride + (size_t)b * 256 + k];
+        hrow[k] = v > 0.f ? v : 0.f;                       // fc1 bias + ReLU (model.py:197-198)
+    }
     __syncthreads();
     const float* w = p.w2 + (size_t)lane * 256;
     float acc = 0.f;
@@ -553,7 +557,7 @@ __global__ __launch_bounds__(64) void ar_disc_tail_kernel(ArDiscTailArgs p) {
 
 int launch_ar_disc_tail(const ArDiscTailArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(ar_disc_tail_kernel, dim3(a.B), dim3(64), 0, st, a);
-    ISB_HIP(hipGetLastError());
+    ISB_LAUNCHED("ar_disc_tail", st);
     return ISB_OK;
 }
 

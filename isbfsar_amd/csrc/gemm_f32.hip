@@ -19,6 +19,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int GEMM_BK = 32;
 constexpr int GEMM_LDK = GEMM_BK + 1;
 
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == GEMM_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == GEMM_ACT_SILU) return v / (1.0f + expf(-v));
+    if (act == GEMM_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+    return v;
+}
+
 template <int TM, int TN, int WGM, int WGN>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args p) {
     constexpr int BM = 32 * TM * WGM;
@@ -52,6 +59,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args p) {
             float v = 0.f;
             if (kin && m < p.M) {
                 v = p.A[(size_t)m * p.lda + k];
+                for (int s = 1; s < p.a_parts; ++s) v += p.A[(size_t)s * p.a_part_stride + (size_t)m * p.lda + k];
+                if (p.a_bias) v += p.a_bias[k];
+                v = apply_act(v, p.a_act);
                 if (p.Aadd) v += p.Aadd[(size_t)(m % p.add_period) * p.ldadd + k];
             }
             ra[i] = v;
@@ -71,11 +81,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nkt = (p.K + GEMM_BK - 1) / GEMM_BK;
-    gload(0);
+    const int nkt_all = (p.K + GEMM_BK - 1) / GEMM_BK;
+    int kt_begin = 0, nkt = nkt_all;
+    const bool split = p.splits > 1;
+    if (split) {
+        const int per = (nkt_all + p.splits - 1) / p.splits;
+        kt_begin = blockIdx.z * per;
+        nkt = min(nkt_all, kt_begin + per);
+    }
+    float* Cout = split ? p.C + (size_t)blockIdx.z * p.split_stride : p.C;
+    if (kt_begin < nkt) gload(kt_begin);
     const int lr = lane & 31;
     const int lh = lane >> 5;
-    for (int kt = 0; kt < nkt; ++kt) {
+    for (int kt = kt_begin; kt < nkt; ++kt) {
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i) As[(sr + 8 * i) * GEMM_LDK + sk] = ra[i];
 #pragma unroll
@@ -105,7 +123,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args p) {
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + (wn * TN + j) * 32 + lr;
         if (n >= p.N) continue;
-        const float bv = p.bias ? p.bias[n] : 0.f;
+        const float bv = (p.bias && !split) ? p.bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int mb = m0 + (wm * TM + i) * 32 + 4 * lh;
@@ -114,12 +132,29 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args p) {
                 const int m = mb + (r & 3) + 8 * (r >> 2);
                 if (m < p.M) {
                     float v = acc[i][j][r] + bv;
-                    if (p.act == GEMM_ACT_RELU) v = v > 0.f ? v : 0.f;
-                    p.C[(size_t)m * p.ldc + n] = v;
+                    if (!split) v = apply_act(v, p.act);
+                    Cout[(size_t)m * p.ldc + n] = v;
                 }
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void reduce_parts_kernel(const float* parts, int n_parts, size_t stride, const float* bias, int act,
+                                                           float* out, int M, int N) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)M * N) return;
+    float v = bias ? bias[i % N] : 0.f;
+    for (int s = 0; s < n_parts; ++s) v += parts[(size_t)s * stride + i];
+    out[i] = apply_act(v, act);
+}
+
+int launch_reduce_parts(const float* parts, int n_parts, size_t stride, const float* bias, int act, float* out, int M, int N,
+                        hipStream_t st) {
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdivz((size_t)M * N, 256)), dim3(256), 0, st, parts, n_parts, stride, bias,
+                       act, out, M, N);
+    ISB_LAUNCHED("reduce_parts", st);
+    return ISB_OK;
 }
 
 int launch_gemm_f32(const GemmF32Args& a, hipStream_t st) {
@@ -127,17 +162,18 @@ int launch_gemm_f32(const GemmF32Args& a, hipStream_t st) {
         set_error("gemm_f32: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
         return ISB_ERR_INVALID;
     }
+    const int z = a.splits > 1 ? a.splits : 1;
     if (a.N <= 32) {
-        dim3 grid(cdiv(a.M, 256), cdiv(a.N, 32));
+        dim3 grid(cdiv(a.M, 256), cdiv(a.N, 32), z);
         hipLaunchKernelGGL((gemm_f32_kernel<2, 1, 4, 1>), grid, dim3(256), 0, st, a);
     } else if (a.N <= 64) {
-        dim3 grid(cdiv(a.M, 128), cdiv(a.N, 64));
+        dim3 grid(cdiv(a.M, 128), cdiv(a.N, 64), z);
         hipLaunchKernelGGL((gemm_f32_kernel<2, 1, 2, 2>), grid, dim3(256), 0, st, a);
     } else {
-        dim3 grid(cdiv(a.M, 128), cdiv(a.N, 128));
+        dim3 grid(cdiv(a.M, 128), cdiv(a.N, 128), z);
         hipLaunchKernelGGL((gemm_f32_kernel<2, 2, 2, 2>), grid, dim3(256), 0, st, a);
     }
-    ISB_HIP(hipGetLastError());
+    ISB_LAUNCHED("gemm_f32", st);
     return ISB_OK;
 }
 

@@ -1,0 +1,498 @@
+// C-ABI glue of the pose stage (include/isbfsar.h, isb_hpe_*): EfficientNetV2-L plan built from
+// the weight blob, activation workspace, per-micro-batch launch sequence, stage-level test hooks.
+#include <algorithm>
+#include <cstdlib>
+#include <cmath>
+#include <memory>
+#include <utility>
+
+#include "isb_common.h"
+#include "kernels.h"
+
+using namespace isb;
+
+namespace {
+
+constexpr int kSeMaxSplits = 32;
+
+struct ConvW {
+    DevBuf w16, bias;
+    int cout = 0, cin = 0, k = 0;
+};
+
+struct BlockW {
+    bool fused = false, residual = false;
+    int cin = 0, cout = 0, cexp = 0, stride = 1, cse = 0, in_hw = 0, out_hw = 0;
+    ConvW expand, project;
+    DevBuf dw_w, dw_b, se_w1, se_b1, se_w2, se_b2;
+};
+
+// public efficientnetv2-l table (mirrors isbfsar_amd/effnetv2.py::STAGES)
+struct StageDef { bool fused; int repeats, expand, stride, cin, cout; bool se; };
+const StageDef kStages[] = {
+    {true, 4, 1, 1, 32, 32, false},   {true, 7, 4, 2, 32, 64, false},   {true, 7, 4, 2, 64, 96, false},
+    {false, 10, 4, 2, 96, 192, true}, {false, 19, 6, 1, 192, 224, true}, {false, 25, 6, 2, 224, 384, true},
+    {false, 7, 6, 1, 384, 640, true},
+};
+
+}  // namespace
+
+struct isb_hpe {
+    isb_hpe_cfg cfg{};
+    hipStream_t own_stream = nullptr;
+    bool weights = false, jointmap = false;
+    int n_out = 0;
+    double K[9] = {0};
+    // weights
+    DevBuf stem_w, stem_b;
+    std::vector<std::unique_ptr<BlockW>> blocks;
+    ConvW headconv;
+    DevBuf head_w, head_b;
+    DevBuf expand, indices;
+    bool has_indices = false;
+    // workspace (per micro-batch)
+    int ws_B = 0;
+    DevBuf H, newK, R, crops, bufX, bufY, bufE, bufD, pooled, semid, semid2, gate, feat, logits;
+    DevBuf frames_tmp, bbox_tmp, joints_tmp, valid_tmp;
+    // profiling of conv_igemm launches
+    bool prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
+    double prof_ms = 0.0;
+    int64_t prof_launches = 0;
+};
+
+namespace {
+
+int upload_conv(const std::map<std::string, BlobTensor>& m, const std::string& prefix, int cout, int k, int cin,
+                ConvW& cw, hipStream_t st) {
+    const BlobTensor *w, *sc, *sh;
+    {
+        auto it = m.find(prefix + ".w");
+        ISB_REQUIRE(it != m.end(), ISB_ERR_WEIGHTS, "weight tensor '%s.w' missing", prefix.c_str());
+        w = &it->second;
+        ISB_REQUIRE((int)w->dims[0] == cout && (int)w->dims[1] == k && (int)w->dims[2] == k && (int)w->dims[3] == cin,
+                    ISB_ERR_WEIGHTS, "'%s.w' has shape [%u,%u,%u,%u], expected [%d,%d,%d,%d]", prefix.c_str(), w->dims[0],
+                    w->dims[1], w->dims[2], w->dims[3], cout, k, k, cin);
+    }
+    ISB_TRY(blob_get(m, (prefix + ".scale").c_str(), cout, 1, &sc));
+    ISB_TRY(blob_get(m, (prefix + ".shift").c_str(), cout, 1, &sh));
+    DevBuf tmp, dsc;
+    ISB_TRY(upload(tmp, w->data, w->numel() * 4));
+    ISB_TRY(upload(dsc, sc->data, (size_t)cout * 4));
+    ISB_TRY(cw.w16.alloc(w->numel() * 2));
+    ISB_TRY(launch_f32_to_bf16_rows(tmp.as<float>(), dsc.as<float>(), cw.w16.as<uint16_t>(), cout, (size_t)k * k * cin, st));
+    ISB_HIP(hipStreamSynchronize(st));
+    ISB_TRY(upload(cw.bias, sh->data, (size_t)cout * 4));
+    cw.cout = cout; cw.cin = cin; cw.k = k;
+    return ISB_OK;
+}
+
+int ensure_ws(isb_hpe* h, int Bm) {
+    if (Bm <= h->ws_B) return ISB_OK;
+    const size_t B = Bm;
+    ISB_TRY(h->H.alloc(B * 9 * 4));
+    ISB_TRY(h->newK.alloc(B * 9 * 8));
+    ISB_TRY(h->R.alloc(B * 9 * 8));
+    ISB_TRY(h->crops.alloc(B * 256 * 256 * 3 * 4));
+    ISB_TRY(h->bufX.alloc(B * 128 * 128 * 32 * 2));
+    ISB_TRY(h->bufY.alloc(B * 128 * 128 * 32 * 2));
+    ISB_TRY(h->bufE.alloc(B * 64 * 64 * 256 * 2));
+    ISB_TRY(h->bufD.alloc(B * 32 * 32 * 384 * 2));
+    ISB_TRY(h->pooled.alloc(B * 3840 * 4));
+    ISB_TRY(h->semid.alloc(B * 160 * 4 * kSeMaxSplits));
+    ISB_TRY(h->gate.alloc(B * 3840 * 4));
+    ISB_TRY(h->semid2.alloc(B * 160 * 4));
+    ISB_TRY(h->feat.alloc(B * 64 * 1280 * 4));
+    ISB_TRY(h->logits.alloc(B * 64 * 288 * 4));
+    h->ws_B = Bm;
+    return ISB_OK;
+}
+
+int conv(isb_hpe* h, hipStream_t st, const ConvW& cw, const void* in, int B, int H, int W, int stride, bool act,
+         const void* res, const float* gate, void* out, bool out_f32) {
+    ConvArgs a{};
+    a.in = (const uint16_t*)in; a.w = cw.w16.as<uint16_t>(); a.bias = cw.bias.as<float>();
+    a.res = (const uint16_t*)res; a.gate = gate; a.out = out;
+    a.B = B; a.H = H; a.W = W; a.Cin = cw.cin; a.Cout = cw.cout; a.KH = cw.k; a.KW = cw.k; a.stride = stride;
+    a.OH = H / stride; a.OW = W / stride;
+    a.pad = (cw.k == 3 && stride == 1) ? 1 : 0;          // TF SAME: stride 2 on an even input pads bottom/right only
+    a.M = B * a.OH * a.OW; a.K = cw.k * cw.k * cw.cin;
+    a.act = act ? 1 : 0; a.out_f32 = out_f32 ? 1 : 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->prof) {
+        ISB_HIP(hipEventCreate(&e0));
+        ISB_HIP(hipEventCreate(&e1));
+        ISB_HIP(hipEventRecord(e0, st));
+    }
+    ISB_TRY(launch_conv_igemm(a, st));
+    if (h->prof) {
+        ISB_HIP(hipEventRecord(e1, st));
+        h->prof_ev.emplace_back(e0, e1);
+        h->prof_launches += 1;
+    }
+    return ISB_OK;
+}
+
+int gemm(hipStream_t st, const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M,
+         int N, int K, int act) {
+    GemmF32Args g{};
+    g.A = A; g.W = W; g.bias = bias; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldc = ldc;
+    g.add_period = 1; g.act = act;
+    return launch_gemm_f32(g, st);
+}
+
+// squeeze-excite FCs: mid = W1 pooled (split-K partials, summed in order by the consumer so the
+// result does not depend on scheduling), gate = sigmoid(W2 silu(mid + b1) + b2)
+int se_fcs(isb_hpe* h, hipStream_t st, const BlockW& b, int B) {
+    const int nkt = cdiv(b.cexp, 32);
+    const int tiles = cdiv(B, b.cse <= 32 ? 256 : 128) * cdiv(b.cse, b.cse <= 32 ? 32 : (b.cse <= 64 ? 64 : 128));
+    const int splits = std::max(1, std::min(std::min(nkt, kSeMaxSplits), 256 / std::max(1, tiles)));
+    GemmF32Args g{};
+    g.A = h->pooled.as<float>(); g.lda = b.cexp; g.W = b.se_w1.as<float>(); g.ldw = b.cexp; g.bias = nullptr;
+    g.C = h->semid.as<float>(); g.ldc = b.cse; g.M = B; g.N = b.cse; g.K = b.cexp; g.add_period = 1; g.act = GEMM_ACT_NONE;
+    g.splits = splits; g.split_stride = (size_t)B * b.cse;
+    ISB_TRY(launch_gemm_f32(g, st));
+    ISB_TRY(launch_reduce_parts(h->semid.as<float>(), splits, (size_t)B * b.cse, b.se_b1.as<float>(), GEMM_ACT_SILU,
+                                h->semid2.as<float>(), B, b.cse, st));
+    return gemm(st, h->semid2.as<float>(), b.cse, b.se_w2.as<float>(), b.cse, b.se_b2.as<float>(), h->gate.as<float>(), b.cexp,
+                B, b.cexp, b.cse, GEMM_ACT_SIGMOID);
+}
+
+// crops f32 [B,256,256,3] (device) -> feat f32 [B*64,1280], logits f32 [B*64,288]
+int run_backbone(isb_hpe* h, hipStream_t st, const float* crops, int B) {
+    StemArgs sa{};
+    sa.in = crops; sa.w = h->stem_w.as<float>(); sa.bias = h->stem_b.as<float>(); sa.out = h->bufX.as<uint16_t>();
+    sa.B = B; sa.H = 256; sa.W = 256;
+    ISB_TRY(launch_stem(sa, st));
+    void* X = h->bufX.p;
+    void* Y = h->bufY.p;
+    for (auto& up : h->blocks) {
+        BlockW& b = *up;
+        const void* res = b.residual ? X : nullptr;
+        if (b.fused) {
+            if (b.cexp == b.cin) {
+                ISB_TRY(conv(h, st, b.expand, X, B, b.in_hw, b.in_hw, b.stride, true, res, nullptr, Y, false));
+            } else {
+                ISB_TRY(conv(h, st, b.expand, X, B, b.in_hw, b.in_hw, b.stride, true, nullptr, nullptr, h->bufE.p, false));
+                ISB_TRY(conv(h, st, b.project, h->bufE.p, B, b.out_hw, b.out_hw, 1, false, res, nullptr, Y, false));
+            }
+        } else {
+            ISB_TRY(conv(h, st, b.expand, X, B, b.in_hw, b.in_hw, 1, true, nullptr, nullptr, h->bufE.p, false));
+            DwArgs d{};
+            d.in = h->bufE.as<uint16_t>(); d.w = b.dw_w.as<float>(); d.bias = b.dw_b.as<float>(); d.out = h->bufD.as<uint16_t>();
+            d.B = B; d.H = b.in_hw; d.W = b.in_hw; d.C = b.cexp; d.OH = b.out_hw; d.OW = b.out_hw; d.stride = b.stride;
+            d.pad = b.stride == 1 ? 1 : 0;
+            ISB_TRY(launch_dwconv3x3(d, st));
+            PoolArgs pa{};
+            pa.in = h->bufD.as<uint16_t>(); pa.out = h->pooled.as<float>(); pa.B = B; pa.HW = b.out_hw * b.out_hw; pa.C = b.cexp;
+            ISB_TRY(launch_se_pool(pa, st));
+            ISB_TRY(se_fcs(h, st, b, B));
+            ISB_TRY(conv(h, st, b.project, h->bufD.p, B, b.out_hw, b.out_hw, 1, false, res, h->gate.as<float>(), Y, false));
+        }
+        std::swap(X, Y);
+    }
+    ISB_TRY(conv(h, st, h->headconv, X, B, 8, 8, 1, true, nullptr, nullptr, h->feat.p, true));
+    ISB_TRY(gemm(st, h->feat.as<float>(), 1280, h->head_w.as<float>(), 1280, h->head_b.as<float>(), h->logits.as<float>(), 288,
+                 B * 64, 288, 1280, GEMM_ACT_NONE));
+    return ISB_OK;
+}
+
+int run_post(isb_hpe* h, hipStream_t st, const float* logits, int B, float* joints, uint8_t* valid, double* dbg) {
+    PostArgs a{};
+    a.logits = logits; a.newK = h->newK.as<double>(); a.R = h->R.as<double>(); a.expand = h->expand.as<float>();
+    a.indices = h->has_indices ? h->indices.as<int32_t>() : nullptr;
+    a.joints = joints; a.valid = valid; a.dbg = dbg; a.B = B; a.n_out = h->n_out;
+    return launch_hpe_post(a, st);
+}
+
+int run_crop_params(isb_hpe* h, hipStream_t st, const int32_t* d_bbox, int B) {
+    CropParamArgs a{};
+    a.bbox = d_bbox;
+    for (int i = 0; i < 9; ++i) a.K[i] = h->K[i];
+    a.H = h->H.as<float>(); a.newK = h->newK.as<double>(); a.R = h->R.as<double>(); a.B = B;
+    return launch_crop_params(a, st);
+}
+
+int run_warp(isb_hpe* h, hipStream_t st, const uint8_t* d_frames, int B) {
+    WarpArgs a{};
+    a.frames = d_frames; a.H = h->H.as<float>(); a.crops = h->crops.as<float>();
+    a.B = B; a.FH = h->cfg.height; a.FW = h->cfg.width;
+    return launch_warp(a, st);
+}
+
+}  // namespace
+
+extern "C" int isb_hpe_create(const isb_hpe_cfg* cfg, isb_hpe** out) {
+    ISB_REQUIRE(cfg && out, ISB_ERR_INVALID, "isb_hpe_create: null argument");
+    ISB_REQUIRE(cfg->width >= 16 && cfg->height >= 16 && cfg->width <= 8192 && cfg->height <= 8192, ISB_ERR_INVALID,
+                "frame size %dx%d unsupported", cfg->width, cfg->height);
+    ISB_REQUIRE(cfg->fx > 0 && cfg->fy > 0, ISB_ERR_INVALID, "focal lengths must be positive");
+    int ndev = 0;
+    ISB_HIP(hipGetDeviceCount(&ndev));
+    ISB_REQUIRE(cfg->device >= 0 && cfg->device < ndev, ISB_ERR_INVALID, "device %d not in [0,%d)", cfg->device, ndev);
+    ISB_HIP(hipSetDevice(cfg->device));
+    std::unique_ptr<isb_hpe> h(new (std::nothrow) isb_hpe());
+    ISB_REQUIRE(h, ISB_ERR_NOMEM, "out of host memory");
+    h->cfg = *cfg;
+    if (h->cfg.max_batch <= 0) h->cfg.max_batch = 64;
+    // K as float32 values (hpe.py:28-33)
+    h->K[0] = (double)cfg->fx; h->K[2] = (double)cfg->ppx; h->K[4] = (double)cfg->fy; h->K[5] = (double)cfg->ppy; h->K[8] = 1.0;
+    ISB_HIP(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    *out = h.release();
+    return ISB_OK;
+}
+
+extern "C" void isb_hpe_destroy(isb_hpe* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device);
+    (void)hipDeviceSynchronize();
+    for (auto& e : h->prof_ev) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+extern "C" int isb_hpe_load_weights(isb_hpe* h, const void* blob, size_t nbytes) {
+    ISB_REQUIRE(h, ISB_ERR_INVALID, "null handle");
+    ISB_HIP(hipSetDevice(h->cfg.device));
+    hipStream_t st = h->own_stream;
+    std::map<std::string, BlobTensor> m;
+    ISB_TRY(parse_blob(blob, nbytes, m));
+    h->weights = false;
+    h->blocks.clear();
+    // stem: f32 [32][27] with the BN scale folded
+    {
+        auto it = m.find("bbone.stem.w");
+        ISB_REQUIRE(it != m.end() && it->second.numel() == 32 * 27, ISB_ERR_WEIGHTS, "bbone.stem.w missing or mis-shaped");
+        const BlobTensor *sc, *sh;
+        ISB_TRY(blob_get(m, "bbone.stem.scale", 32, 1, &sc));
+        ISB_TRY(blob_get(m, "bbone.stem.shift", 32, 1, &sh));
+        std::vector<float> w(32 * 27);
+        for (int o = 0; o < 32; ++o)
+            for (int k = 0; k < 27; ++k) w[o * 27 + k] = it->second.data[o * 27 + k] * sc->data[o];
+        ISB_TRY(upload(h->stem_w, w.data(), w.size() * 4));
+        ISB_TRY(upload(h->stem_b, sh->data, 32 * 4));
+    }
+    int idx = 0, hw = 128;
+    for (const StageDef& s : kStages) {
+        for (int r = 0; r < s.repeats; ++r, ++idx) {
+            std::unique_ptr<BlockW> b(new BlockW());
+            b->fused = s.fused;
+            b->cin = r == 0 ? s.cin : s.cout;
+            b->cout = s.cout;
+            b->cexp = b->cin * s.expand;
+            b->stride = r == 0 ? s.stride : 1;
+            b->cse = s.se ? std::max(1, (int)(b->cin * 0.25)) : 0;
+            b->residual = b->stride == 1 && b->cin == b->cout;
+            b->in_hw = hw;
+            b->out_hw = hw / b->stride;
+            hw = b->out_hw;
+            const std::string p = "bbone.b" + std::to_string(idx);
+            if (b->fused) {
+                if (b->cexp == b->cin) {
+                    ISB_TRY(upload_conv(m, p + ".expand", b->cout, 3, b->cin, b->expand, st));
+                } else {
+                    ISB_TRY(upload_conv(m, p + ".expand", b->cexp, 3, b->cin, b->expand, st));
+                    ISB_TRY(upload_conv(m, p + ".project", b->cout, 1, b->cexp, b->project, st));
+                }
+            } else {
+                ISB_TRY(upload_conv(m, p + ".expand", b->cexp, 1, b->cin, b->expand, st));
+                ISB_TRY(upload_conv(m, p + ".project", b->cout, 1, b->cexp, b->project, st));
+                auto it = m.find(p + ".dw.w");
+                ISB_REQUIRE(it != m.end() && it->second.numel() == (size_t)b->cexp * 9, ISB_ERR_WEIGHTS,
+                            "%s.dw.w missing or mis-shaped", p.c_str());
+                const BlobTensor *sc, *sh, *w1, *b1, *w2, *b2;
+                ISB_TRY(blob_get(m, (p + ".dw.scale").c_str(), b->cexp, 1, &sc));
+                ISB_TRY(blob_get(m, (p + ".dw.shift").c_str(), b->cexp, 1, &sh));
+                std::vector<float> wt((size_t)9 * b->cexp);      // tap-major, scale folded
+                for (int c = 0; c < b->cexp; ++c)
+                    for (int t = 0; t < 9; ++t) wt[(size_t)t * b->cexp + c] = it->second.data[(size_t)c * 9 + t] * sc->data[c];
+                ISB_TRY(upload(b->dw_w, wt.data(), wt.size() * 4));
+                ISB_TRY(upload(b->dw_b, sh->data, (size_t)b->cexp * 4));
+                ISB_TRY(blob_get(m, (p + ".se.w1").c_str(), b->cse, b->cexp, &w1));
+                ISB_TRY(blob_get(m, (p + ".se.b1").c_str(), b->cse, 1, &b1));
+                ISB_TRY(blob_get(m, (p + ".se.w2").c_str(), b->cexp, b->cse, &w2));
+                ISB_TRY(blob_get(m, (p + ".se.b2").c_str(), b->cexp, 1, &b2));
+                ISB_TRY(upload(b->se_w1, w1->data, w1->numel() * 4));
+                ISB_TRY(upload(b->se_b1, b1->data, b1->numel() * 4));
+                ISB_TRY(upload(b->se_w2, w2->data, w2->numel() * 4));
+                ISB_TRY(upload(b->se_b2, b2->data, b2->numel() * 4));
+            }
+            h->blocks.push_back(std::move(b));
+        }
+    }
+    ISB_REQUIRE(hw == 8, ISB_ERR_WEIGHTS, "internal: backbone plan ends at %dx%d", hw, hw);
+    ISB_TRY(upload_conv(m, "bbone.head", 1280, 1, 640, h->headconv, st));
+    const BlobTensor *hwt, *hb;
+    ISB_TRY(blob_get(m, "head.weight", 288, 1280, &hwt));
+    ISB_TRY(blob_get(m, "head.bias", 288, 1, &hb));
+    ISB_TRY(upload(h->head_w, hwt->data, hwt->numel() * 4));
+    ISB_TRY(upload(h->head_b, hb->data, 288 * 4));
+    h->weights = true;
+    return ISB_OK;
+}
+
+extern "C" int isb_hpe_set_joint_map(isb_hpe* h, const float* expand, const int32_t* indices, int32_t n_out) {
+    ISB_REQUIRE(h && expand, ISB_ERR_INVALID, "null argument");
+    ISB_REQUIRE(n_out >= 1 && n_out <= 122, ISB_ERR_INVALID, "n_out %d outside [1,122]", n_out);
+    ISB_REQUIRE(indices || n_out == 122, ISB_ERR_INVALID, "without indices n_out must be 122");
+    if (indices)
+        for (int i = 0; i < n_out; ++i)
+            ISB_REQUIRE(indices[i] >= 0 && indices[i] < 122, ISB_ERR_INVALID, "joint index %d outside [0,122)", indices[i]);
+    ISB_HIP(hipSetDevice(h->cfg.device));
+    ISB_TRY(upload(h->expand, expand, 32 * 122 * 4));
+    h->has_indices = indices != nullptr;
+    if (indices) ISB_TRY(upload(h->indices, indices, (size_t)n_out * 4));
+    h->n_out = n_out;
+    h->jointmap = true;
+    return ISB_OK;
+}
+
+extern "C" int isb_hpe_forward(isb_hpe* h, const uint8_t* d_frames, const int32_t* d_bbox, int32_t B, float* d_joints,
+                               uint8_t* d_valid, void* stream) {
+    ISB_REQUIRE(h && d_frames && d_bbox && d_joints && d_valid, ISB_ERR_INVALID, "null argument");
+    ISB_REQUIRE(B >= 1, ISB_ERR_INVALID, "batch %d < 1", B);
+    ISB_REQUIRE(h->weights && h->jointmap, ISB_ERR_STATE, "isb_hpe_forward needs weights and a joint map");
+    ISB_HIP(hipSetDevice(h->cfg.device));
+    hipStream_t st = (hipStream_t)stream;   // NULL = the HIP null stream (torch's default stream)
+    const int Bm_max = std::min<int>(B, h->cfg.max_batch);
+    ISB_TRY(ensure_ws(h, Bm_max));
+    const size_t fsz = (size_t)h->cfg.height * h->cfg.width * 3;
+    for (int b0 = 0; b0 < B; b0 += Bm_max) {
+        const int Bm = std::min(Bm_max, B - b0);
+        ISB_TRY(run_crop_params(h, st, d_bbox + (size_t)b0 * 4, Bm));
+        ISB_TRY(run_warp(h, st, d_frames + (size_t)b0 * fsz, Bm));
+        ISB_TRY(run_backbone(h, st, h->crops.as<float>(), Bm));
+        ISB_TRY(run_post(h, st, h->logits.as<float>(), Bm, d_joints + (size_t)b0 * h->n_out * 3, d_valid + b0, nullptr));
+    }
+    return ISB_OK;
+}
+
+extern "C" int isb_hpe_forward_host(isb_hpe* h, const uint8_t* frames, const int32_t* bbox, int32_t B, float* joints,
+                                    uint8_t* valid) {
+    ISB_REQUIRE(h && frames && bbox && joints && valid, ISB_ERR_INVALID, "null argument");
+    ISB_REQUIRE(B >= 1, ISB_ERR_INVALID, "batch %d < 1", B);
+    ISB_REQUIRE(h->weights && h->jointmap, ISB_ERR_STATE, "isb_hpe_forward_host needs weights and a joint map");
+    ISB_HIP(hipSetDevice(h->cfg.device));
+    hipStream_t st = h->own_stream;
+    const size_t fsz = (size_t)h->cfg.height * h->cfg.width * 3;
+    DevBuf df, db, dj, dv;
+    ISB_TRY(df.alloc(fsz * B));
+    ISB_TRY(db.alloc((size_t)B * 16));
+    ISB_TRY(dj.alloc((size_t)B * h->n_out * 12));
+    ISB_TRY(dv.alloc((size_t)B));
+    ISB_HIP(hipMemcpyAsync(df.p, frames, fsz * B, hipMemcpyHostToDevice, st));
+    ISB_HIP(hipMemcpyAsync(db.p, bbox, (size_t)B * 16, hipMemcpyHostToDevice, st));
+    ISB_TRY(isb_hpe_forward(h, df.as<uint8_t>(), db.as<int32_t>(), B, dj.as<float>(), dv.as<uint8_t>(), st));
+    ISB_HIP(hipMemcpyAsync(joints, dj.p, (size_t)B * h->n_out * 12, hipMemcpyDeviceToHost, st));
+    ISB_HIP(hipMemcpyAsync(valid, dv.p, (size_t)B, hipMemcpyDeviceToHost, st));
+    ISB_HIP(hipStreamSynchronize(st));
+    return ISB_OK;
+}
+
+// ---------------------------------------------------------------- stage-level hooks (tests)
+extern "C" int isb_hpe_crop_params_host(isb_hpe* h, const int32_t* bbox, int32_t B, float* H, double* newK, double* R) {
+    ISB_REQUIRE(h && bbox && H && newK && R && B >= 1, ISB_ERR_INVALID, "bad argument");
+    ISB_HIP(hipSetDevice(h->cfg.device));
+    hipStream_t st = h->own_stream;
+    ISB_TRY(ensure_ws(h, std::min<int>(B, h->cfg.max_batch)));
+    ISB_REQUIRE(B <= h->ws_B, ISB_ERR_INVALID, "B %d exceeds max_batch %d", B, h->cfg.max_batch);
+    DevBuf db;
+    ISB_TRY(upload(db, bbox, (size_t)B * 16));
+    ISB_TRY(run_crop_params(h, st, db.as<int32_t>(), B));
+    ISB_HIP(hipStreamSynchronize(st));
+    ISB_HIP(hipMemcpy(H, h->H.p, (size_t)B * 36, hipMemcpyDeviceToHost));
+    ISB_HIP(hipMemcpy(newK, h->newK.p, (size_t)B * 72, hipMemcpyDeviceToHost));
+    ISB_HIP(hipMemcpy(R, h->R.p, (size_t)B * 72, hipMemcpyDeviceToHost));
+    return ISB_OK;
+}
+
+extern "C" int isb_hpe_warp_host(isb_hpe* h, const uint8_t* frames, const int32_t* bbox, int32_t B, float* crops) {
+    ISB_REQUIRE(h && frames && bbox && crops && B >= 1, ISB_ERR_INVALID, "bad argument");
+    ISB_HIP(hipSetDevice(h->cfg.device));
+    hipStream_t st = h->own_stream;
+    ISB_TRY(ensure_ws(h, std::min<int>(B, h->cfg.max_batch)));
+    ISB_REQUIRE(B <= h->ws_B, ISB_ERR_INVALID, "B %d exceeds max_batch %d", B, h->cfg.max_batch);
+    const size_t fsz = (size_t)h->cfg.height * h->cfg.width * 3;
+    DevBuf df, db;
+    ISB_TRY(upload(df, frames, fsz * B));
+    ISB_TRY(upload(db, bbox, (size_t)B * 16));
+    ISB_TRY(run_crop_params(h, st, db.as<int32_t>(), B));
+    ISB_TRY(run_warp(h, st, df.as<uint8_t>(), B));
+    ISB_HIP(hipStreamSynchronize(st));
+    ISB_HIP(hipMemcpy(crops, h->crops.p, (size_t)B * 256 * 256 * 3 * 4, hipMemcpyDeviceToHost));
+    return ISB_OK;
+}
+
+extern "C" int isb_hpe_backbone_host(isb_hpe* h, const float* crops, int32_t B, float* features, float* logits) {
+    ISB_REQUIRE(h && crops && B >= 1, ISB_ERR_INVALID, "bad argument");
+    ISB_REQUIRE(h->weights, ISB_ERR_STATE, "isb_hpe_backbone_host before isb_hpe_load_weights");
+    ISB_HIP(hipSetDevice(h->cfg.device));
+    hipStream_t st = h->own_stream;
+    ISB_TRY(ensure_ws(h, std::min<int>(B, h->cfg.max_batch)));
+    ISB_REQUIRE(B <= h->ws_B, ISB_ERR_INVALID, "B %d exceeds max_batch %d", B, h->cfg.max_batch);
+    ISB_HIP(hipMemcpy(h->crops.p, crops, (size_t)B * 256 * 256 * 3 * 4, hipMemcpyHostToDevice));
+    ISB_TRY(run_backbone(h, st, h->crops.as<float>(), B));
+    ISB_HIP(hipStreamSynchronize(st));
+    if (features) ISB_HIP(hipMemcpy(features, h->feat.p, (size_t)B * 64 * 1280 * 4, hipMemcpyDeviceToHost));
+    if (logits) ISB_HIP(hipMemcpy(logits, h->logits.p, (size_t)B * 64 * 288 * 4, hipMemcpyDeviceToHost));
+    return ISB_OK;
+}
+
+extern "C" int isb_hpe_post_host(isb_hpe* h, const float* logits, const int32_t* bbox, int32_t B, float* joints,
+                                 uint8_t* valid, double* pred) {
+    ISB_REQUIRE(h && logits && bbox && joints && valid && B >= 1, ISB_ERR_INVALID, "bad argument");
+    ISB_REQUIRE(h->jointmap, ISB_ERR_STATE, "isb_hpe_post_host before isb_hpe_set_joint_map");
+    ISB_HIP(hipSetDevice(h->cfg.device));
+    hipStream_t st = h->own_stream;
+    ISB_TRY(ensure_ws(h, std::min<int>(B, h->cfg.max_batch)));
+    ISB_REQUIRE(B <= h->ws_B, ISB_ERR_INVALID, "B %d exceeds max_batch %d", B, h->cfg.max_batch);
+    DevBuf db, dl, dj, dv, dd;
+    ISB_TRY(upload(db, bbox, (size_t)B * 16));
+    ISB_TRY(upload(dl, logits, (size_t)B * 64 * 288 * 4));
+    ISB_TRY(dj.alloc((size_t)B * h->n_out * 12));
+    ISB_TRY(dv.alloc((size_t)B));
+    if (pred) ISB_TRY(dd.alloc((size_t)B * 32 * 5 * 8));
+    ISB_TRY(run_crop_params(h, st, db.as<int32_t>(), B));
+    ISB_TRY(run_post(h, st, dl.as<float>(), B, dj.as<float>(), dv.as<uint8_t>(), pred ? dd.as<double>() : nullptr));
+    ISB_HIP(hipStreamSynchronize(st));
+    ISB_HIP(hipMemcpy(joints, dj.p, (size_t)B * h->n_out * 12, hipMemcpyDeviceToHost));
+    ISB_HIP(hipMemcpy(valid, dv.p, (size_t)B, hipMemcpyDeviceToHost));
+    if (pred) ISB_HIP(hipMemcpy(pred, dd.p, (size_t)B * 32 * 5 * 8, hipMemcpyDeviceToHost));
+    return ISB_OK;
+}
+
+extern "C" int isb_hpe_profile(isb_hpe* h, int32_t enable) {
+    ISB_REQUIRE(h, ISB_ERR_INVALID, "null handle");
+    h->prof = enable != 0;
+    return ISB_OK;
+}
+
+extern "C" int isb_hpe_profile_read(isb_hpe* h, double* ms_total, int64_t* launches) {
+    ISB_REQUIRE(h && ms_total && launches, ISB_ERR_INVALID, "null argument");
+    ISB_HIP(hipSetDevice(h->cfg.device));
+    for (auto& e : h->prof_ev) {
+        ISB_HIP(hipEventSynchronize(e.second));
+        float ms = 0.f;
+        ISB_HIP(hipEventElapsedTime(&ms, e.first, e.second));
+        h->prof_ms += ms;
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    h->prof_ev.clear();
+    *ms_total = h->prof_ms;
+    *launches = h->prof_launches;
+    h->prof_ms = 0.0;
+    h->prof_launches = 0;
+    return ISB_OK;
+}
+
+extern "C" int isb_pose_windows(const float* d_joints, int32_t n_cam, int32_t n_frames, int32_t J, int32_t L,
+                                float* d_windows, void* stream) {
+    ISB_REQUIRE(d_joints && d_windows, ISB_ERR_INVALID, "null argument");
+    ISB_REQUIRE(n_cam >= 1 && J >= 1 && L >= 1 && n_frames >= L, ISB_ERR_INVALID,
+                "bad shape n_cam=%d n_frames=%d J=%d L=%d", n_cam, n_frames, J, L);
+    return launch_pose_windows(d_joints, n_cam, n_frames, J, L, d_windows, (hipStream_t)stream);
+}

@@ -1,0 +1,296 @@
+// Pose-estimation stages around the backbone (all HBM/latency bound, no MFMA):
+//   crop_params : bbox -> (new_K, R, H)            reference modules/hpe/utils/misc.py:243-296, hpe.py:85,96
+//   warp        : homography gather, nearest/trunc modules/hpe/setup/6_create_image_transformation_onnx.py:23-56, hpe.py:97-100
+//   hpe_post    : soft-argmax decode, FOV gate, absolute reconstruction, un-rotate, 32->122 joint
+//                 expansion + selection            hpe.py:109-169, misc.py:141-220
+// The reference does the geometry in float64 numpy on the host with two float32 islands (K and its
+// inverse, new_K.astype(float32) and its inverse); the same dtypes are kept here, on the device, so
+// no host round trip is needed between detector box and crop.
+#include "isb_common.h"
+#include "kernels.h"
+
+namespace isb {
+
+// ------------------------------------------------------------------------------------------
+// crop_params: one thread per frame, float64
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void mat3_mul(const double* a, const double* b, double* c) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) c[i * 3 + j] = a[i * 3 + 0] * b[0 * 3 + j] + a[i * 3 + 1] * b[1 * 3 + j] + a[i * 3 + 2] * b[2 * 3 + j];
+}
+
+__device__ __forceinline__ void mat3_inv(const double* m, double* o) {
+    const double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
+    const double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
+    const double id = 1.0 / det;
+    o[0] = c00 * id; o[1] = (m[2] * m[7] - m[1] * m[8]) * id; o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+    o[3] = c01 * id; o[4] = (m[0] * m[8] - m[2] * m[6]) * id; o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+    o[6] = c02 * id; o[7] = (m[1] * m[6] - m[0] * m[7]) * id; o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+}
+
+__global__ void crop_params_kernel(CropParamArgs p) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= p.B) return;
+    const double x1 = p.bbox[4 * b + 0], x2 = p.bbox[4 * b + 1], y1 = p.bbox[4 * b + 2], y2 = p.bbox[4 * b + 3];
+    const double* K = p.K;
+    // numpy inverts the float32 K in float32 (one correctly rounded division per entry)
+    const float fx = (float)K[0], fy = (float)K[4], cx = (float)K[2], cy = (float)K[5];
+    const double i00 = (double)__fdiv_rn(1.0f, fx), i02 = (double)(-__fdiv_rn(cx, fx));
+    const double i11 = (double)__fdiv_rn(1.0f, fy), i12 = (double)(-__fdiv_rn(cy, fy));
+    const double mx = (x1 + x2) / 2, my = (y1 + y2) / 2;
+    const double px[5] = {mx, mx, x2, mx, x1};
+    const double py[5] = {my, y1, my, y2, my};
+    double cam[5][2];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        cam[i][0] = px[i] * i00 + py[i] * 0.0 + i02;
+        cam[i][1] = px[i] * 0.0 + py[i] * i11 + i12;
+    }
+    // look-at rotation towards the box centre, up = (0,-1,0)   (misc.py:223-236)
+    double z[3] = {cam[0][0], cam[0][1], 1.0};
+    const double zn = sqrt(z[0] * z[0] + z[1] * z[1] + z[2] * z[2]);
+    z[0] /= zn; z[1] /= zn; z[2] /= zn;
+    double x[3] = {z[1] * 0.0 - z[2] * (-1.0), z[2] * 0.0 - z[0] * 0.0, z[0] * (-1.0) - z[1] * 0.0};
+    double xn = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    if (xn == 0.0) { x[0] = z[2]; x[1] = 0.0; x[2] = -z[0]; xn = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]); }
+    x[0] /= xn; x[1] /= xn; x[2] /= xn;
+    const double y[3] = {z[1] * x[2] - z[2] * x[1], z[2] * x[0] - z[0] * x[2], z[0] * x[1] - z[1] * x[0]};
+    const double R[9] = {x[0], x[1], x[2], y[0], y[1], y[2], z[0], z[1], z[2]};
+    double KR[9];
+    mat3_mul(K, R, KR);
+    double pr[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double sx = cam[i + 1][0], sy = cam[i + 1][1];
+        const double u = sx * KR[0] + sy * KR[1] + KR[2];
+        const double v = sx * KR[3] + sy * KR[4] + KR[5];
+        const double w = sx * KR[6] + sy * KR[7] + KR[8];
+        pr[i][0] = u / w; pr[i][1] = v / w;
+    }
+    const double vs = sqrt((pr[0][0] - pr[2][0]) * (pr[0][0] - pr[2][0]) + (pr[0][1] - pr[2][1]) * (pr[0][1] - pr[2][1]));
+    const double hs = sqrt((pr[1][0] - pr[3][0]) * (pr[1][0] - pr[3][0]) + (pr[1][1] - pr[3][1]) * (pr[1][1] - pr[3][1]));
+    const double scale = 256.0 / fmax(vs, hs);
+    const double nK[9] = {K[0] * scale, K[1] * scale, 128.0, K[3] * scale, K[4] * scale, 128.0, 0.0, 0.0, 1.0};
+    double M[9], Mi[9], H[9];
+    mat3_mul(nK, R, M);
+    mat3_inv(M, Mi);
+    mat3_mul(K, Mi, H);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        p.H[9 * b + i] = (float)H[i];
+        p.newK[9 * b + i] = nK[i];
+        p.R[9 * b + i] = R[i];
+    }
+}
+
+int launch_crop_params(const CropParamArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(crop_params_kernel, dim3(cdiv(a.B, 64)), dim3(64), 0, st, a);
+    ISB_LAUNCHED("crop_params", st);
+    return ISB_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// warp: thread per output pixel; float32 arithmetic in the reference's op order, no contraction
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void warp_kernel(WarpArgs p) {
+    const int b = blockIdx.y;
+    const int pix = blockIdx.x * 256 + threadIdx.x;      // 0..65535
+    const int y = pix >> 8, x = pix & 255;
+    const float* H = p.H + 9 * b;
+    const float h8 = H[8];
+    const float t0 = __fdiv_rn(H[0], h8), t1 = __fdiv_rn(H[1], h8), t2 = __fdiv_rn(H[2], h8);
+    const float t3 = __fdiv_rn(H[3], h8), t4 = __fdiv_rn(H[4], h8), t5 = __fdiv_rn(H[5], h8);
+    const float t6 = __fdiv_rn(H[6], h8), t7 = __fdiv_rn(H[7], h8);
+    const float xf = (float)x, yf = (float)y;
+    const float k = __fadd_rn(__fadd_rn(__fmul_rn(t6, xf), __fmul_rn(t7, yf)), 1.0f);
+    const float xs = __fdiv_rn(__fadd_rn(__fadd_rn(__fmul_rn(t0, xf), __fmul_rn(t1, yf)), t2), k);
+    const float ys = __fdiv_rn(__fadd_rn(__fadd_rn(__fmul_rn(t3, xf), __fmul_rn(t4, yf)), t5), k);
+    // torch .int(): truncation toward zero; keep huge/NaN values out of range
+    const bool finite = fabsf(xs) < 1.0e9f && fabsf(ys) < 1.0e9f;
+    const int xi = finite ? (int)xs : -1, yi = finite ? (int)ys : -1;
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+    if (xi >= 0 && xi < p.FW && yi >= 0 && yi < p.FH) {
+        const uint8_t* s = p.frames + (((size_t)b * p.FH + yi) * p.FW + xi) * 3;
+        o0 = (float)((double)s[0] / 255.0);                // hpe.py:100 (int / 255.0 in f64, cast to f32)
+        o1 = (float)((double)s[1] / 255.0);
+        o2 = (float)((double)s[2] / 255.0);
+    }
+    float* d = p.crops + ((size_t)b * 65536 + pix) * 3;
+    d[0] = o0; d[1] = o1; d[2] = o2;
+}
+
+int launch_warp(const WarpArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(warp_kernel, dim3(256, a.B), dim3(256), 0, st, a);
+    ISB_LAUNCHED("warp", st);
+    return ISB_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// hpe_post: one wave per sample. lanes 0-31: joint j, 3D heatmap; lanes 32-63: joint j, 2D heatmap
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wsum32(double v) {
+#pragma unroll
+    for (int s = 16; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
+    return v;
+}
+
+// symmetric 3x3 eigen-decomposition (cyclic Jacobi) -> pseudo-inverse solve, like lstsq's
+// singular-value cut-off (misc.py:174, rcond=None)
+__device__ void solve_sym3_pinv(const double A[6], const double rhs[3], double out[3]) {
+    double a[3][3] = {{A[0], A[1], A[2]}, {A[1], A[3], A[4]}, {A[2], A[4], A[5]}};
+    double v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        for (int pq = 0; pq < 3; ++pq) {
+            const int pI = pq == 2 ? 1 : 0, qI = pq == 0 ? 1 : 2;
+            if (fabs(a[pI][qI]) < 1e-300) continue;
+            const double theta = (a[qI][qI] - a[pI][pI]) / (2.0 * a[pI][qI]);
+            const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+            const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+            for (int k = 0; k < 3; ++k) {
+                const double akp = a[k][pI], akq = a[k][qI];
+                a[k][pI] = c * akp - s * akq; a[k][qI] = s * akp + c * akq;
+            }
+            for (int k = 0; k < 3; ++k) {
+                const double apk = a[pI][k], aqk = a[qI][k];
+                a[pI][k] = c * apk - s * aqk; a[qI][k] = s * apk + c * aqk;
+            }
+            for (int k = 0; k < 3; ++k) {
+                const double vkp = v[k][pI], vkq = v[k][qI];
+                v[k][pI] = c * vkp - s * vkq; v[k][qI] = s * vkp + c * vkq;
+            }
+        }
+    }
+    const double lmax = fmax(fmax(a[0][0], a[1][1]), a[2][2]);
+    const double cut = lmax * (64.0 * 2.220446049250313e-16) * (64.0 * 2.220446049250313e-16);
+    out[0] = out[1] = out[2] = 0.0;
+    for (int i = 0; i < 3; ++i) {
+        const double lam = a[i][i];
+        if (lam <= cut) continue;
+        const double proj = (v[0][i] * rhs[0] + v[1][i] * rhs[1] + v[2][i] * rhs[2]) / lam;
+        out[0] += v[0][i] * proj; out[1] += v[1][i] * proj; out[2] += v[2][i] * proj;
+    }
+}
+
+__global__ __launch_bounds__(64) void hpe_post_kernel(PostArgs p) {
+    __shared__ double sh2d[32][2];
+    __shared__ double pose32[32][3];
+    const int b = blockIdx.x, lane = threadIdx.x, j = lane & 31, half = lane >> 5;
+    const float* lg = p.logits + (size_t)b * 64 * 288;
+
+    double c0 = 0, c1 = 0, c2 = 0;
+    if (half == 0) {          // 3D: softmax jointly over (h, w, d), hpe.py:114-129
+        float mx = -INFINITY;
+        for (int hw = 0; hw < 64; ++hw)
+            for (int d = 0; d < 8; ++d) mx = fmaxf(mx, lg[hw * 288 + 32 + d * 32 + j]);
+        double den = 0;
+        for (int hw = 0; hw < 64; ++hw)
+            for (int d = 0; d < 8; ++d) den += (double)expf(lg[hw * 288 + 32 + d * 32 + j] - mx);
+        const float denf = (float)den;
+        for (int hw = 0; hw < 64; ++hw) {
+            const int hh = hw >> 3, ww = hw & 7;
+            for (int d = 0; d < 8; ++d) {
+                const double r = (double)__fdiv_rn(expf(lg[hw * 288 + 32 + d * 32 + j] - mx), denf);
+                c0 += r * ((double)ww / 7.0); c1 += r * ((double)hh / 7.0); c2 += r * ((double)d / 7.0);
+            }
+        }
+    } else {                  // 2D: softmax over (h, w), hpe.py:131-146
+        float mx = -INFINITY;
+        for (int hw = 0; hw < 64; ++hw) mx = fmaxf(mx, lg[hw * 288 + j]);
+        double den = 0;
+        for (int hw = 0; hw < 64; ++hw) den += (double)expf(lg[hw * 288 + j] - mx);
+        const float denf = (float)den;
+        for (int hw = 0; hw < 64; ++hw) {
+            const double r = (double)__fdiv_rn(expf(lg[hw * 288 + j] - mx), denf);
+            c0 += r * ((double)(hw & 7) / 7.0); c1 += r * ((double)(hw >> 3) / 7.0);
+        }
+        sh2d[j][0] = c0 * 255.0; sh2d[j][1] = c1 * 255.0;
+    }
+    __syncthreads();
+    const double x2 = sh2d[j][0], y2 = sh2d[j][1];
+    if (p.dbg && half == 0) {
+        double* d = p.dbg + ((size_t)b * 32 + j) * 5;
+        d[0] = x2; d[1] = y2; d[2] = c0; d[3] = c1; d[4] = c2;
+    }
+    // FOV mask (misc.py:212-220) and visibility gate (hpe.py:149-153)
+    const bool infov = x2 >= 18.0 && x2 <= 238.0 && y2 >= 18.0 && y2 <= 238.0;
+    const unsigned long long bal = __ballot(infov && half == 0);
+    const int nvis = __popcll(bal);
+    const bool ok = nvis >= 8;
+    if (lane == 0) p.valid[b] = ok ? 1 : 0;
+
+    // reconstruct_absolute (misc.py:183-204): inverse of new_K.astype(float32) in float32
+    const double* nK = p.newK + 9 * b;
+    const float f0 = (float)nK[0], f1 = (float)nK[4], pp0 = (float)nK[2], pp1 = (float)nK[5];
+    const double i00 = (double)__fdiv_rn(1.0f, f0), i02 = (double)(-__fdiv_rn(pp0, f0));
+    const double i11 = (double)__fdiv_rn(1.0f, f1), i12 = (double)(-__fdiv_rn(pp1, f1));
+    const double nx = x2 * i00 + i02, ny = y2 * i11 + i12;
+    // rms scales over the 64 interleaved coordinates (misc.py:156-168)
+    const double rbx = nx * c2 - c0, rby = ny * c2 - c1;
+    const double s2d = sqrt(wsum32(nx * nx + ny * ny) / 64.0);
+    const double srb = sqrt(wsum32(rbx * rbx + rby * rby) / 64.0);
+    const double xh = nx / s2d, yh = ny / s2d, bx = rbx / srb, by = rby / srb;
+    const double wj = (double)((infov ? 1.0f : 0.0f) + 1e-4f);
+    const double w2 = wj * wj;
+    double A[6], rhs[3], ref[3];
+    A[0] = wsum32(w2); A[1] = 0.0; A[2] = wsum32(-w2 * xh);
+    A[3] = A[0]; A[4] = wsum32(-w2 * yh); A[5] = wsum32(w2 * (xh * xh + yh * yh));
+    rhs[0] = wsum32(w2 * bx); rhs[1] = wsum32(w2 * by); rhs[2] = wsum32(-w2 * (xh * bx + yh * by));
+    solve_sym3_pinv(A, rhs, ref);
+    ref[0] *= srb; ref[1] *= srb; ref[2] = ref[2] / s2d * srb;
+    double ax, ay, az;
+    if (infov) { const double dz = c2 + ref[2]; ax = nx * dz; ay = ny * dz; az = dz; }
+    else { ax = c0 + ref[0]; ay = c1 + ref[1]; az = c2 + ref[2]; }
+    const double* R = p.R + 9 * b;                          // pred3d @ homo_inv, hpe.py:159
+    if (half == 0) {
+        pose32[j][0] = ax * R[0] + ay * R[3] + az * R[6];
+        pose32[j][1] = ax * R[1] + ay * R[4] + az * R[7];
+        pose32[j][2] = ax * R[2] + ay * R[5] + az * R[8];
+    }
+    __syncthreads();
+    // joint expansion 32 -> 122 and selection (hpe.py:162-164)
+    for (int q = lane; q < p.n_out; q += 64) {
+        const int src = p.indices ? p.indices[q] : q;
+        double o0 = 0, o1 = 0, o2 = 0;
+        for (int jj = 0; jj < 32; ++jj) {
+            const double w = (double)p.expand[jj * 122 + src];
+            o0 += w * pose32[jj][0]; o1 += w * pose32[jj][1]; o2 += w * pose32[jj][2];
+        }
+        float* o = p.joints + ((size_t)b * p.n_out + q) * 3;
+        o[0] = ok ? (float)o0 : 0.f; o[1] = ok ? (float)o1 : 0.f; o[2] = ok ? (float)o2 : 0.f;
+    }
+}
+
+int launch_hpe_post(const PostArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(hpe_post_kernel, dim3(a.B), dim3(64), 0, st, a);
+    ISB_LAUNCHED("hpe_post", st);
+    return ISB_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// pose_windows: root-centre (main.py:103) + flatten (main.py:105) + sliding windows (ar.py:42-50)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pose_windows_kernel(const float* joints, int n_cam, int n_frames, int J, int L, float* windows) {
+    const int nw = n_frames - L + 1;
+    const size_t total = (size_t)n_cam * nw * L * J * 3;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int d3 = J * 3;
+    const int e = (int)(idx % d3);
+    size_t rest = idx / d3;
+    const int l = (int)(rest % L); rest /= L;
+    const int w = (int)(rest % nw);
+    const int cam = (int)(rest / nw);
+    const float* pose = joints + ((size_t)cam * n_frames + w + l) * d3;
+    windows[idx] = pose[e] - pose[e % 3];
+}
+
+int launch_pose_windows(const float* joints, int n_cam, int n_frames, int J, int L, float* windows, hipStream_t st) {
+    const size_t total = (size_t)n_cam * (n_frames - L + 1) * L * J * 3;
+    hipLaunchKernelGGL(pose_windows_kernel, dim3((unsigned)cdivz(total, 256)), dim3(256), 0, st, joints, n_cam, n_frames, J, L, windows);
+    ISB_LAUNCHED("pose_windows", st);
+    return ISB_OK;
+}
+
+}  // namespace isb

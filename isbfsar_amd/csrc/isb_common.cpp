@@ -1,6 +1,8 @@
 // Error channel, version and ISBW blob reader of libisbfsar_hip.so.
 #include "isb_common.h"
 
+#include <cstdlib>
+
 namespace isb {
 
 static thread_local char g_err[512] = "";
@@ -60,6 +62,22 @@ int blob_get(const std::map<std::string, BlobTensor>& m, const char* name, uint3
                 "weight tensor '%s' has shape [%u,%u,%u,%u], expected [%u,%u]", name, t.dims[0], t.dims[1],
                 t.dims[2], t.dims[3], d0, d1);
     *out = &t;
+    return ISB_OK;
+}
+
+int post_launch(const char* what, hipStream_t st) {
+    static const bool dbg = getenv("ISB_DEBUG_SYNC") != nullptr;
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && dbg) {
+        fprintf(stderr, "[isb] %s ...", what);
+        fflush(stderr);
+        e = hipStreamSynchronize(st);
+        fprintf(stderr, " %s\n", e == hipSuccess ? "ok" : hipGetErrorString(e));
+    }
+    if (e != hipSuccess) {
+        set_error("kernel %s failed: %s", what, hipGetErrorString(e));
+        return ISB_ERR_HIP;
+    }
     return ISB_OK;
 }
 

@@ -89,6 +89,11 @@ inline int upload(DevBuf& b, const void* src, size_t n) {
     return ISB_OK;
 }
 
+// After every kernel launch: surface launch errors; with ISB_DEBUG_SYNC=1 also wait for the kernel
+// and report it by name (debugging aid: pins an asynchronous fault to the launch that caused it).
+int post_launch(const char* what, hipStream_t st);
+#define ISB_LAUNCHED(what, st) ISB_TRY(isb::post_launch(what, st))
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t cdivz(size_t a, size_t b) { return (a + b - 1) / b; }
 

@@ -8,7 +8,7 @@
 namespace isb {
 
 // ---------------------------------------------------------------- gemm_f32.hip
-enum { GEMM_ACT_NONE = 0, GEMM_ACT_RELU = 1 };
+enum { GEMM_ACT_NONE = 0, GEMM_ACT_RELU = 1, GEMM_ACT_SILU = 2, GEMM_ACT_SIGMOID = 3 };
 struct GemmF32Args {
     const float* A;      // [M,K], row stride lda
     const float* W;      // [N,K], row stride ldw (torch Linear weight)
@@ -19,8 +19,19 @@ struct GemmF32Args {
     int lda, ldw, ldc, ldadd;
     int add_period;
     int act;
+    // split-K: grid.z = splits, split z covers a contiguous range of k-tiles and writes its raw
+    // partial sums (no bias / act) to C + z * split_stride; the consumer adds the parts in order
+    int splits;            // 0/1 = off
+    size_t split_stride;
+    // A-operand transform on load: v = a_act( sum_{s < a_parts} A[s * a_part_stride + m*lda + k] + a_bias[k] )
+    const float* a_bias;   // [K] or null
+    int a_act;             // GEMM_ACT_*
+    int a_parts;           // 0/1 = plain A
+    size_t a_part_stride;
 };
 int launch_gemm_f32(const GemmF32Args& a, hipStream_t st);
+// out[m,n] = act(bias[n] + sum_s parts[s*stride + m*N + n]) -- fixed-order reduction of split-K partials
+int launch_reduce_parts(const float* parts, int n_parts, size_t stride, const float* bias, int act, float* out, int M, int N, hipStream_t st);
 
 // ---------------------------------------------------------------- ar_kernels.hip
 // Fragment-ordered bf16 operand images (see ar_kernels.hip header):
@@ -85,7 +96,10 @@ struct ArFinalArgs {
 int launch_ar_finalize(const ArFinalArgs& a, hipStream_t st);
 
 struct ArDiscTailArgs {
-    const float* h1;        // [B][256] relu(fc1)
+    const float* h1;        // [n_parts][B][256] split-K partial sums of fc1 (bias/ReLU applied here)
+    const float* b1;        // [256] fc1 bias
+    int n_parts;
+    size_t part_stride;
     const float* w2;        // [64][256]
     const float* b2;        // [64]
     const float* w3;        // [64]
@@ -94,5 +108,79 @@ struct ArDiscTailArgs {
     int B;
 };
 int launch_ar_disc_tail(const ArDiscTailArgs& a, hipStream_t st);
+
+// ---------------------------------------------------------------- conv_kernels.hip
+struct ConvArgs {
+    const uint16_t* in;     // bf16 [B,H,W,Cin]
+    const uint16_t* w;      // bf16 [Cout, KH*KW*Cin] (BN scale folded)
+    const float* bias;      // [Cout] folded-BN shift
+    const uint16_t* res;    // bf16 [M,Cout] residual or null
+    const float* gate;      // f32 [B,Cin] squeeze-excite gate applied to the A operand, or null
+    void* out;              // bf16 (or f32 when out_f32) [M,Cout]
+    int B, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad;
+    int M, K;
+    int act;                // 1 = SiLU
+    int out_f32;
+};
+int launch_conv_igemm(const ConvArgs& a, hipStream_t st);
+
+struct DwArgs {
+    const uint16_t* in;     // bf16 [B,H,W,C]
+    const float* w;         // f32 [9][C] tap-major, BN scale folded
+    const float* bias;      // [C]
+    uint16_t* out;          // bf16 [B,OH,OW,C]
+    int B, H, W, C, OH, OW, stride, pad;
+};
+int launch_dwconv3x3(const DwArgs& a, hipStream_t st);
+
+struct PoolArgs {
+    const uint16_t* in;     // bf16 [B,HW,C]
+    float* out;             // f32 [B,C]
+    int B, HW, C;
+};
+int launch_se_pool(const PoolArgs& a, hipStream_t st);
+
+struct StemArgs {
+    const float* in;        // f32 [B,H,W,3]
+    const float* w;         // f32 [32][27], BN scale folded
+    const float* bias;      // [32]
+    uint16_t* out;          // bf16 [B,H/2,W/2,32]
+    int B, H, W;
+};
+int launch_stem(const StemArgs& a, hipStream_t st);
+int launch_f32_to_bf16_rows(const float* in, const float* row_scale, uint16_t* out, size_t rows, size_t cols, hipStream_t st);
+
+// ---------------------------------------------------------------- hpe_kernels.hip
+struct CropParamArgs {
+    const int32_t* bbox;    // [B,4] x1,x2,y1,y2
+    double K[9];            // camera intrinsics (float32 values, hpe.py:28-33)
+    float* H;               // out [B,9]  f32 homography, hpe.py:96-97
+    double* newK;           // out [B,9]
+    double* R;              // out [B,9]
+    int B;
+};
+int launch_crop_params(const CropParamArgs& a, hipStream_t st);
+
+struct WarpArgs {
+    const uint8_t* frames;  // [B,FH,FW,3]
+    const float* H;         // [B,9]
+    float* crops;           // out [B,256,256,3] f32 in [0,1]
+    int B, FH, FW;
+};
+int launch_warp(const WarpArgs& a, hipStream_t st);
+
+struct PostArgs {
+    const float* logits;    // [B,8,8,288] pose-head output
+    const double* newK;     // [B,9]
+    const double* R;        // [B,9]
+    const float* expand;    // [32,122] joint expansion (assets/32_to_122.npy)
+    const int32_t* indices; // [n_out] selected joints or null (-> all 122)
+    float* joints;          // out [B,n_out,3]
+    uint8_t* valid;         // out [B]
+    double* dbg;            // optional [B,32,5] pred2d(2) pred3d(3) or null
+    int B, n_out;
+};
+int launch_hpe_post(const PostArgs& a, hipStream_t st);
+int launch_pose_windows(const float* joints, int n_cam, int n_frames, int J, int L, float* windows, hipStream_t st);
 
 }  // namespace isb

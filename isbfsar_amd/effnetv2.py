@@ -1,0 +1,155 @@
+"""EfficientNetV2-L backbone description + deterministic synthetic weights.
+
+The reference names the backbone only by string: ``model_name = 'efficientnetv2-l'``,
+``get_model(..., include_top=False)`` from the un-vendored isarandi/metrabs repo
+(reference modules/hpe/setup/2_extract_bbone_heads.py:27,46-47), shipped as a TensorRT engine
+taking ``f32[B,256,256,3]`` NHWC and returning ``f32[B,8,8,1280]`` (7_create_engines.py:38-42,
+4_create_heads_onnx.py:13,19). Neither source nor weights are in the reference tree, so the block
+table below is the PUBLIC efficientnetv2-l configuration ("parity unpinned"):
+
+    stem  conv3x3/s2 3->32, BN, SiLU
+    r=4  FusedMBConv e1 k3 s1  32-> 32      r=7  FusedMBConv e4 k3 s2  32-> 64
+    r=7  FusedMBConv e4 k3 s2  64-> 96      r=10 MBConv e4 k3 s2 se.25  96->192
+    r=19 MBConv e6 k3 s1 se.25 192->224     r=25 MBConv e6 k3 s2 se.25 224->384
+    r=7  MBConv e6 k3 s1 se.25 384->640     head conv1x1 640->1280, BN, SiLU
+    BN eps 1e-3 (folded to per-channel scale/shift), TF "SAME" padding (stride 2: pad bottom/right
+    only), SE squeeze = max(1, int(block_in * 0.25)), residual when stride 1 and in == out.
+
+The same table exists in C++ (csrc/backbone.cpp) -- tests compare both through the blob names.
+
+Blob tensor names (all f32; conv weights are [cout, kh, kw, cin], i.e. K-contiguous rows):
+    bbone.stem.{w,scale,shift}
+    bbone.b{i}.expand.{w,scale,shift}     3x3 (fused) or 1x1 (MBConv); for e1 fused blocks this is the only conv
+    bbone.b{i}.dw.{w,scale,shift}         [c,3,3] depthwise (MBConv)
+    bbone.b{i}.se.{w1,b1,w2,b2}           [cse,c],[cse],[c,cse],[c]
+    bbone.b{i}.project.{w,scale,shift}    1x1
+    bbone.head.{w,scale,shift}
+    head.{weight,bias}                    MetrABS heatmap head Linear(1280,288) (4_create_heads_onnx.py:10)
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from dataclasses import dataclass
+from typing import List, Tuple
+
+import numpy as np
+
+from .weights import uniform
+
+# (kind, repeats, expand, stride, cin, cout, se)
+STAGES = [
+    ("fused", 4, 1, 1, 32, 32, 0.0),
+    ("fused", 7, 4, 2, 32, 64, 0.0),
+    ("fused", 7, 4, 2, 64, 96, 0.0),
+    ("mb", 10, 4, 2, 96, 192, 0.25),
+    ("mb", 19, 6, 1, 192, 224, 0.25),
+    ("mb", 25, 6, 2, 224, 384, 0.25),
+    ("mb", 7, 6, 1, 384, 640, 0.25),
+]
+STEM_OUT = 32
+HEAD_OUT = 1280
+N_HEAD_LOGITS = 288
+
+
+@dataclass
+class Block:
+    idx: int
+    kind: str       # "fused" | "mb"
+    cin: int
+    cout: int
+    cexp: int
+    stride: int
+    cse: int        # 0 = no SE
+    residual: bool
+    in_hw: int      # input spatial size for a 256x256 crop
+    out_hw: int
+
+
+def blocks(in_hw: int = 128) -> List[Block]:
+    out: List[Block] = []
+    hw = in_hw
+    i = 0
+    for kind, rep, e, s, cin, cout, se in STAGES:
+        for r in range(rep):
+            bi = cin if r == 0 else cout
+            st = s if r == 0 else 1
+            ohw = hw // st
+            out.append(Block(i, kind, bi, cout, bi * e, st, max(1, int(bi * se)) if se > 0 else 0,
+                             st == 1 and bi == cout, hw, ohw))
+            hw = ohw
+            i += 1
+    return out
+
+
+def macs_per_crop() -> int:
+    """MACs of the backbone + pose head for one 256x256 crop (15.99 G)."""
+    m = 128 * 128 * 27 * STEM_OUT
+    for b in blocks():
+        o = b.out_hw * b.out_hw
+        if b.kind == "fused":
+            m += o * 9 * b.cin * b.cexp
+            if b.cexp != b.cin:
+                m += o * b.cexp * b.cout
+        else:
+            m += b.in_hw * b.in_hw * b.cin * b.cexp + o * 9 * b.cexp + o * b.cexp * b.cout + 2 * b.cexp * b.cse
+    m += 64 * 640 * HEAD_OUT + 64 * HEAD_OUT * N_HEAD_LOGITS
+    return m
+
+
+def tensor_shapes() -> "OrderedDict[str, Tuple[int, ...]]":
+    s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+
+    def conv(prefix, cout, k, cin):
+        s[prefix + ".w"] = (cout, k, k, cin)
+        s[prefix + ".scale"] = (cout,)
+        s[prefix + ".shift"] = (cout,)
+
+    conv("bbone.stem", STEM_OUT, 3, 3)
+    for b in blocks():
+        p = f"bbone.b{b.idx}"
+        if b.kind == "fused":
+            if b.cexp == b.cin:                      # expand ratio 1: a single 3x3 conv
+                conv(p + ".expand", b.cout, 3, b.cin)
+            else:
+                conv(p + ".expand", b.cexp, 3, b.cin)
+                conv(p + ".project", b.cout, 1, b.cexp)
+        else:
+            conv(p + ".expand", b.cexp, 1, b.cin)
+            s[p + ".dw.w"] = (b.cexp, 3, 3)
+            s[p + ".dw.scale"] = (b.cexp,)
+            s[p + ".dw.shift"] = (b.cexp,)
+            s[p + ".se.w1"] = (b.cse, b.cexp)
+            s[p + ".se.b1"] = (b.cse,)
+            s[p + ".se.w2"] = (b.cexp, b.cse)
+            s[p + ".se.b2"] = (b.cexp,)
+            conv(p + ".project", b.cout, 1, b.cexp)
+    conv("bbone.head", HEAD_OUT, 1, 640)
+    s["head.weight"] = (N_HEAD_LOGITS, HEAD_OUT)
+    s["head.bias"] = (N_HEAD_LOGITS,)
+    return s
+
+
+def make_state(seed: int = 0) -> "OrderedDict[str, np.ndarray]":
+    """Deterministic synthetic weights that keep activations O(1) through all 79 blocks:
+    activated convs get He-style gain, projections (no activation, added to the residual)
+    a small gain, folded-BN scale in [0.8,1.2] and shift in [-0.1,0.1]."""
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    for name, shape in tensor_shapes().items():
+        leaf = name.split(".")[-1]
+        if leaf == "scale":
+            out[name] = uniform(name, shape, 0.8, 1.2, seed)
+        elif leaf in ("shift", "b1", "b2", "bias"):
+            out[name] = uniform(name, shape, -0.1, 0.1, seed)
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            if ".project." in name:
+                gain = 0.35
+            elif name == "head.weight":
+                gain = 4.0                 # spread the pose-head logits so heatmaps are not flat
+            elif ".se.w2" in name:
+                gain = 1.0
+            else:
+                gain = 1.6
+            a = gain * np.sqrt(3.0 / fan_in)
+            out[name] = uniform(name, shape, -a, a, seed)
+    return out

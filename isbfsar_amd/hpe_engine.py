@@ -1,0 +1,159 @@
+"""Object wrapper over the isb_hpe_* / isb_pose_windows entry points (include/isbfsar.h)."""
+from __future__ import annotations
+
+import ctypes as C
+import json
+from typing import Mapping, Optional, Sequence, Union
+
+import numpy as np
+
+from . import _lib
+from .weights import pack_blob
+
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class HpeEngine:
+    """Everything ``HumanPoseEstimator.estimate`` does after the detector (reference
+    modules/hpe/hpe.py:76-173), batched, on one MI355X."""
+
+    def __init__(self, fx=384.025146484375, fy=384.025146484375, ppx=319.09661865234375,
+                 ppy=237.75723266601562, width=640, height=480, device: int = 0, max_batch: int = 64):
+        self.width, self.height, self.device, self.max_batch = width, height, device, max_batch
+        self.n_out = 0
+        self._h = C.c_void_p()
+        cfg = _lib.isb_hpe_cfg(fx, fy, ppx, ppy, width, height, device, max_batch, 0, 0)
+        _lib.check(_lib.lib().isb_hpe_create(C.byref(cfg), C.byref(self._h)), "isb_hpe_create")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            _lib.lib().isb_hpe_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_weights(self, state: Union[bytes, Mapping[str, np.ndarray]]):
+        blob = state if isinstance(state, (bytes, bytearray)) else pack_blob(state)
+        buf = np.frombuffer(blob, dtype=np.uint8)
+        _lib.check(_lib.lib().isb_hpe_load_weights(self._h, _ptr(buf), len(blob)), "isb_hpe_load_weights")
+
+    def set_joint_map(self, expand: np.ndarray, indices: Optional[Sequence[int]]):
+        e = np.ascontiguousarray(expand, dtype=np.float32)
+        if e.shape != (32, 122):
+            raise ValueError(f"expand must be [32,122], got {e.shape}")
+        idx = None if indices is None else np.ascontiguousarray(indices, dtype=np.int32)
+        n = 122 if idx is None else int(idx.shape[0])
+        _lib.check(_lib.lib().isb_hpe_set_joint_map(self._h, _ptr(e), _ptr(idx), n), "isb_hpe_set_joint_map")
+        self.n_out = n
+
+    # -- full stage -----------------------------------------------------------------------
+    def forward(self, frames, bboxes):
+        """frames uint8 [B,H,W,3] BGR, bboxes int32 [B,4] (x1,x2,y1,y2). numpy -> numpy, torch CUDA
+        -> torch CUDA (asynchronous). Returns (joints f32 [B,n_out,3], valid u8 [B])."""
+        if isinstance(frames, np.ndarray):
+            f = np.ascontiguousarray(frames, dtype=np.uint8)
+            bb = np.ascontiguousarray(bboxes, dtype=np.int32)
+            B = f.shape[0]
+            if f.shape != (B, self.height, self.width, 3) or bb.shape != (B, 4):
+                raise ValueError(f"bad shapes {f.shape} {bb.shape}")
+            joints = np.empty((B, self.n_out, 3), np.float32)
+            valid = np.empty((B,), np.uint8)
+            _lib.check(_lib.lib().isb_hpe_forward_host(self._h, _ptr(f), _ptr(bb), B, _ptr(joints), _ptr(valid)),
+                       "isb_hpe_forward_host")
+            return joints, valid
+        import torch
+        if not (isinstance(frames, torch.Tensor) and frames.is_cuda and frames.dtype == torch.uint8):
+            raise TypeError("frames must be a uint8 numpy array or a uint8 torch CUDA tensor")
+        f = frames.contiguous()
+        bb = bboxes.contiguous()
+        B = f.shape[0]
+        if tuple(f.shape) != (B, self.height, self.width, 3) or tuple(bb.shape) != (B, 4) or bb.dtype != torch.int32:
+            raise ValueError(f"bad shapes/dtypes {tuple(f.shape)} {tuple(bb.shape)} {bb.dtype}")
+        joints = torch.empty((B, self.n_out, 3), dtype=torch.float32, device=f.device)
+        valid = torch.empty((B,), dtype=torch.uint8, device=f.device)
+        stream = torch.cuda.current_stream(f.device).cuda_stream
+        _lib.check(_lib.lib().isb_hpe_forward(self._h, f.data_ptr(), bb.data_ptr(), B, joints.data_ptr(),
+                                              valid.data_ptr(), C.c_void_p(stream)), "isb_hpe_forward")
+        return joints, valid
+
+    # -- stage-level hooks ----------------------------------------------------------------
+    def crop_params(self, bboxes):
+        bb = np.ascontiguousarray(bboxes, dtype=np.int32)
+        B = bb.shape[0]
+        H = np.empty((B, 3, 3), np.float32)
+        newK = np.empty((B, 3, 3), np.float64)
+        R = np.empty((B, 3, 3), np.float64)
+        _lib.check(_lib.lib().isb_hpe_crop_params_host(self._h, _ptr(bb), B, _ptr(H), _ptr(newK), _ptr(R)),
+                   "isb_hpe_crop_params_host")
+        return H, newK, R
+
+    def warp(self, frames, bboxes):
+        f = np.ascontiguousarray(frames, dtype=np.uint8)
+        bb = np.ascontiguousarray(bboxes, dtype=np.int32)
+        B = f.shape[0]
+        crops = np.empty((B, 256, 256, 3), np.float32)
+        _lib.check(_lib.lib().isb_hpe_warp_host(self._h, _ptr(f), _ptr(bb), B, _ptr(crops)), "isb_hpe_warp_host")
+        return crops
+
+    def backbone(self, crops, want_features=True):
+        c = np.ascontiguousarray(crops, dtype=np.float32)
+        B = c.shape[0]
+        if c.shape != (B, 256, 256, 3):
+            raise ValueError(f"crops must be [B,256,256,3], got {c.shape}")
+        feat = np.empty((B, 8, 8, 1280), np.float32) if want_features else None
+        logits = np.empty((B, 8, 8, 288), np.float32)
+        _lib.check(_lib.lib().isb_hpe_backbone_host(self._h, _ptr(c), B, _ptr(feat), _ptr(logits)),
+                   "isb_hpe_backbone_host")
+        return feat, logits
+
+    def post(self, logits, bboxes, want_pred=False):
+        lg = np.ascontiguousarray(logits, dtype=np.float32)
+        bb = np.ascontiguousarray(bboxes, dtype=np.int32)
+        B = lg.shape[0]
+        if lg.shape != (B, 8, 8, 288):
+            raise ValueError(f"logits must be [B,8,8,288], got {lg.shape}")
+        joints = np.empty((B, self.n_out, 3), np.float32)
+        valid = np.empty((B,), np.uint8)
+        pred = np.empty((B, 32, 5), np.float64) if want_pred else None
+        _lib.check(_lib.lib().isb_hpe_post_host(self._h, _ptr(lg), _ptr(bb), B, _ptr(joints), _ptr(valid), _ptr(pred)),
+                   "isb_hpe_post_host")
+        return joints, valid, pred
+
+    def profile(self, enable: bool):
+        _lib.check(_lib.lib().isb_hpe_profile(self._h, int(enable)), "isb_hpe_profile")
+
+    def profile_read(self):
+        ms = C.c_double()
+        n = C.c_int64()
+        _lib.check(_lib.lib().isb_hpe_profile_read(self._h, C.byref(ms), C.byref(n)), "isb_hpe_profile_read")
+        return ms.value, n.value
+
+
+def pose_windows(joints, seq_len: int):
+    """joints torch CUDA f32 [n_cam, n_frames, J, 3] -> windows [n_cam*(n_frames-L+1), L, 3J]
+    (root-centred on joint 0, main.py:103; window assembly, ar.py:42-50)."""
+    import torch
+    j = joints.contiguous().float()
+    n_cam, n_frames, J, _ = j.shape
+    nw = n_frames - seq_len + 1
+    out = torch.empty((n_cam * nw, seq_len, 3 * J), dtype=torch.float32, device=j.device)
+    stream = torch.cuda.current_stream(j.device).cuda_stream
+    _lib.check(_lib.lib().isb_pose_windows(j.data_ptr(), n_cam, n_frames, J, seq_len, out.data_ptr(), C.c_void_p(stream)),
+               "isb_pose_windows")
+    return out
+
+
+def load_joint_assets(expand_path: str, skeleton_types_path: str, skeleton: Optional[str]):
+    expand = np.load(expand_path)
+    with open(skeleton_types_path) as f:
+        st = json.load(f)
+    if skeleton is None:
+        return expand, None, None
+    return expand, st[skeleton]["indices"], [tuple(e) for e in st[skeleton]["edges"]]

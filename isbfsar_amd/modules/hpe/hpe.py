@@ -1,0 +1,84 @@
+"""Drop-in for the reference's ``modules/hpe/hpe.py::HumanPoseEstimator`` (lines 15-173) on top
+of libisbfsar_hip.so.  Same constructor and ``estimate(frame)`` contract, so the reference's
+worker loop (``main.py:336-342``: ``x = module(*configurations); y = x.estimate(input_queue.get())``)
+and the per-frame consumer (``main.py:77-105``) run unmodified:
+
+    estimate(frame uint8[480,640,3] BGR) -> None | {"pose": float64[n,3], "edges": [...], "bbox": (x1,x2,y1,y2)}
+    just_box mode                         -> {"bbox": (x1,y1,x2,y2)}            (hpe.py:82-83)
+
+The YOLOv4 detector (hpe.py:51-73) is out of scope for this round: the person box
+comes from ``bbox_provider(frame) -> (x1,x2,y1,y2) | None`` (default: ``model_config.fixed_bbox``
+or the whole frame). Everything after the box runs on the GPU; there is no CPU path.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from ... import effnetv2
+from ...hpe_engine import HpeEngine, load_joint_assets
+from ...weights import unpack_blob
+
+
+class HumanPoseEstimator:
+    def __init__(self, model_config, cam_config, just_box=None, bbox_provider=None):
+        if just_box is None:
+            self.just_box = model_config.just_box
+        else:
+            self.just_box = just_box
+        self.yolo_thresh = model_config.yolo_thresh
+        self.nms_thresh = model_config.nms_thresh
+        self.num_aug = model_config.num_aug
+        if self.num_aug > 0:
+            raise NotImplementedError("test-time augmentation (num_aug>0, hpe.py:88-93) is a 'next' row (SURVEY.md 8f)")
+        self.n_test = 1
+
+        # Intrinsics and K matrix of RealSense (hpe.py:28-33)
+        self.K = np.zeros((3, 3), np.float32)
+        self.K[0][0] = cam_config.fx
+        self.K[0][2] = cam_config.ppx
+        self.K[1][1] = cam_config.fy
+        self.K[1][2] = cam_config.ppy
+        self.K[2][2] = 1
+
+        self.skeleton = model_config.skeleton
+        self.expand_joints, indices, self.edges = load_joint_assets(
+            model_config.expand_joints_path, model_config.skeleton_types_path, self.skeleton)
+        self.bbox_provider = bbox_provider
+        self.fixed_bbox = getattr(model_config, "fixed_bbox", None)
+
+        self.engine = None
+        if not self.just_box:
+            self.engine = HpeEngine(cam_config.fx, cam_config.fy, cam_config.ppx, cam_config.ppy,
+                                    cam_config.width, cam_config.height,
+                                    device=getattr(model_config, "device", 0),
+                                    max_batch=getattr(model_config, "max_batch", 64))
+            w = getattr(model_config, "weights", None)
+            if w is None and getattr(model_config, "weights_path", None):
+                with open(model_config.weights_path, "rb") as f:
+                    w = f.read()
+            if w is None:   # no MetrABS export available (reference .gitignore:12-18): synthetic weights
+                w = effnetv2.make_state(getattr(model_config, "weights_seed", 0))
+            self.engine.load_weights(w)
+            self.engine.set_joint_map(self.expand_joints, indices)
+
+    def _bbox(self, frame):
+        if self.bbox_provider is not None:
+            return self.bbox_provider(frame)
+        if self.fixed_bbox is not None:
+            return self.fixed_bbox
+        return 0, frame.shape[1] - 1, 0, frame.shape[0] - 1
+
+    def estimate(self, frame):
+        box = self._bbox(frame)
+        if box is None:                                   # no human found (hpe.py:72-73)
+            return None
+        x1, x2, y1, y2 = (int(v) if int(v) > 0 else 0 for v in box)      # hpe.py:76-79
+        if self.just_box:                                 # hpe.py:82-83 (note the different order)
+            return {"bbox": (x1, y1, x2, y2)}
+        joints, valid = self.engine.forward(np.asarray(frame, dtype=np.uint8)[None],
+                                            np.array([[x1, x2, y1, y2]], np.int32))
+        if not valid[0]:                                  # < 25 % of the joints in the FOV (hpe.py:152-153)
+            return None
+        return {"pose": joints[0].astype(np.float64),
+                "edges": self.edges,
+                "bbox": (x1, x2, y1, y2)}

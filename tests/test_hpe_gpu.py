@@ -1,0 +1,240 @@
+"""GPU parity tests of the pose stage, stage by stage through the C ABI, against the oracle
+(pinned by the reference's own outputs, tests/test_oracle_hpe_golden.py) and the committed goldens.
+
+Tolerances: warp and crop homography are index / float32 work -> bit-exact; decode and the
+float64 reconstruction -> 1e-5 (the reference's softmax sums run in float32, numpy pairwise order;
+ours accumulate in float64 -- observed difference 2e-6); backbone (bf16 storage, f32 accumulate)
+-> within the north star's 1e-3 on 3D joints against the bf16-faithful oracle."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from isbfsar_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _digest(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def assets():
+    a = os.path.join(ROOT, "isbfsar_amd", "assets")
+    return np.load(os.path.join(a, "32_to_122.npy")), json.load(open(os.path.join(a, "skeleton_types.json")))
+
+
+@pytest.fixture(scope="module")
+def eng(assets):
+    from isbfsar_amd.hpe_engine import HpeEngine
+    e = HpeEngine(device=0, max_batch=8)
+    e.set_joint_map(assets[0], assets[1]["smpl+head_30"]["indices"])
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def g(golden_dir):
+    return np.load(os.path.join(golden_dir, "hpe_post.npz"))
+
+
+def _K():
+    from oracle import hpe_oracle as ho
+    return ho.intrinsics_matrix(384.025146484375, 384.025146484375, 319.09661865234375, 237.75723266601562)
+
+
+def test_crop_params_match_reference(eng, g):
+    from oracle import hpe_oracle as ho
+    bbs = np.concatenate([g["bboxes"], synth.bboxes(60, seed=5)])
+    H, newK, R = [], [], []
+    for i in range(0, len(bbs), 8):
+        h, k, r = eng.crop_params(bbs[i:i + 8])
+        H.append(h); newK.append(k); R.append(r)
+    H, newK, R = np.concatenate(H), np.concatenate(newK), np.concatenate(R)
+    for i in range(4):     # reference known answers (misc.homography + hpe.py:96)
+        np.testing.assert_array_equal(H[i], g[f"hom{i}_H"][0])
+        np.testing.assert_allclose(newK[i], g[f"hom{i}_new_K"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(R[i], g[f"hom{i}_R"][0], rtol=0, atol=1e-12)
+    n_h_equal = 0
+    for i, bb in enumerate(bbs):
+        nk, r, h = ho.crop_params(bb, _K())
+        np.testing.assert_allclose(newK[i], nk, rtol=1e-13, atol=1e-10)
+        np.testing.assert_allclose(R[i], r[0], rtol=0, atol=1e-13)
+        np.testing.assert_allclose(H[i], h[0], rtol=2e-7, atol=1e-9)
+        n_h_equal += np.array_equal(H[i], h[0])
+    assert n_h_equal >= len(bbs) - 2          # f32 rounding of an f64 product: ties are measure-zero
+
+
+def test_warp_bit_exact_vs_reference(eng, g):
+    for i in range(int(g["n_cases"])):
+        frame = np.random.default_rng(int(g[f"c{i}_frame_seed"])).integers(0, 256, (480, 640, 3), dtype=np.uint8)
+        crop = eng.warp(frame[None], g[f"c{i}_bbox"][None])
+        assert _digest(crop) == str(g[f"c{i}_bbone_in_digest"])       # == what the reference fed its backbone engine
+        u8 = np.rint(crop * 255.0).astype(np.uint8)
+        assert _digest(u8) == str(g[f"c{i}_warp_digest"])
+        np.testing.assert_array_equal(u8[0, :32, :32], g[f"c{i}_warp_patch"])
+
+
+def test_warp_batch_vs_oracle(eng):
+    from oracle import hpe_oracle as ho
+    fr = synth.frames(8, seed=40)
+    bb = synth.bboxes(8, seed=40)
+    bb[0] = (0, 639, 0, 479)            # whole frame
+    bb[1] = (600, 639, 440, 479)        # tiny corner box -> most of the crop falls outside the frame
+    crops = eng.warp(fr, bb)
+    n_diff = 0
+    for i in range(8):
+        ref = ho.warp(fr[i], ho.crop_params(bb[i], _K())[2][0])
+        n_diff += int((crops[i] != ref).any(axis=-1).sum())
+    assert n_diff == 0
+
+
+def test_post_matches_reference_estimate(eng, g, assets):
+    from isbfsar_amd.hpe_engine import HpeEngine
+    e122 = HpeEngine(device=0, max_batch=8)
+    e122.set_joint_map(assets[0], None)
+    for i in range(int(g["n_cases"])):
+        e = eng if str(g[f"c{i}_skeleton"]) == "30" else e122
+        joints, valid, pred = e.post(g[f"c{i}_head_logits"], g[f"c{i}_bbox"][None], want_pred=True)
+        assert bool(valid[0]) == bool(g[f"c{i}_valid"])
+        if valid[0]:
+            np.testing.assert_allclose(joints[0], g[f"c{i}_pose"], rtol=0, atol=1e-5)
+    e122.close()
+
+
+def test_post_batch_vs_oracle(eng, assets):
+    from oracle import hpe_oracle as ho
+    W, st = assets
+    idx = st["smpl+head_30"]["indices"]
+    rng = np.random.default_rng(77)
+    B = 8
+    lg = rng.normal(0, 3, (B, 8, 8, 288)).astype(np.float32)
+    for b in range(B):
+        for j in range(32):
+            hh, ww, dd = rng.integers(0, 8, 3)
+            lg[b, hh, ww, j] += 10.0
+            lg[b, hh, ww, 32 + dd * 32 + j] += 10.0
+    lg[3, 0, 0, :] += 40.0              # everything in the corner: out of FOV -> invalid
+    bb = synth.bboxes(B, seed=9)
+    joints, valid, pred = eng.post(lg, bb, want_pred=True)
+    for b in range(B):
+        p2, p3 = ho.decode(lg[b:b + 1])
+        np.testing.assert_allclose(pred[b, :, :2], p2[0], rtol=0, atol=1e-3)
+        np.testing.assert_allclose(pred[b, :, 2:], p3[0], rtol=0, atol=1e-5)
+        nk, r, _ = ho.crop_params(bb[b], _K())
+        ref = ho.postprocess(lg[b:b + 1], nk, r, W, idx)
+        assert bool(valid[b]) == (ref is not None)
+        if ref is not None:
+            np.testing.assert_allclose(joints[b], ref, rtol=0, atol=1e-5 * max(1.0, float(np.abs(ref).max())))
+    assert not valid[3] and valid.sum() >= 6
+
+
+@pytest.fixture(scope="module")
+def bbone_state():
+    from isbfsar_amd import effnetv2
+    return effnetv2.make_state(0)
+
+
+@pytest.fixture(scope="module")
+def eng_w(eng, bbone_state):
+    eng.load_weights(bbone_state)
+    return eng
+
+
+def test_backbone_vs_oracle(eng_w, bbone_state, assets):
+    """K2: HIP EfficientNetV2-L (bf16 storage / f32 accumulate) against our own CPU definition
+    (parity unpinned w.r.t. MetrABS: the reference has neither source nor weights)."""
+    from oracle import hpe_oracle as ho
+    from oracle.effnetv2_oracle import EffNetV2LOracle
+    fr = synth.frames(2, seed=0)
+    bb = synth.bboxes(2, seed=0)
+    crops = np.stack([ho.warp(fr[i], ho.crop_params(bb[i], _K())[2][0]) for i in range(2)])
+    feat, logits = eng_w.backbone(crops)
+    o16 = EffNetV2LOracle(bbone_state, "bf16")
+    f16 = o16.backbone(crops)
+    l16 = o16.head(f16)
+    scale = float(np.abs(f16).max())
+    err_feat = float(np.abs(feat - f16).max())
+    err_log = float(np.abs(logits - l16).max())
+    print(f"backbone: max|feat|={scale:.3f} err_feat={err_feat:.2e} err_logits={err_log:.2e}")
+    assert err_feat < 2e-2 * scale                      # bf16 re-rounding noise through 79 blocks
+    p2_g, p3_g = ho.decode(logits)
+    p2_o, p3_o = ho.decode(l16)
+    assert np.abs(p3_g - p3_o).max() < 1e-3             # north star: 3D joints within 1e-3
+    assert np.abs(p2_g - p2_o).max() < 0.255            # same bound in pixel units (x255)
+    # drift against the pure-fp32 definition, documented in DESIGN.md
+    o32 = EffNetV2LOracle(bbone_state, "f32")
+    l32 = o32.head(o32.backbone(crops))
+    p2_f, p3_f = ho.decode(l32)
+    drift = float(np.abs(p3_g - p3_f).max())
+    print(f"backbone: 3D joint drift vs fp32 definition = {drift:.2e}")
+    assert drift < 5e-3
+
+
+def test_forward_end_to_end_vs_oracle(eng_w, bbone_state, assets):
+    """estimate() for a batch: frames + boxes -> joints, against the oracle chain."""
+    from oracle import hpe_oracle as ho
+    from oracle.effnetv2_oracle import EffNetV2LOracle
+    W, st = assets
+    idx = st["smpl+head_30"]["indices"]
+    B = 3
+    fr = synth.frames(B, seed=20)
+    bb = synth.bboxes(B, seed=20)
+    joints, valid = eng_w.forward(fr, bb)
+    o16 = EffNetV2LOracle(bbone_state, "bf16")
+    for b in range(B):
+        nk, r, H = ho.crop_params(bb[b], _K())
+        lg = o16.head(o16.backbone(ho.warp(fr[b], H[0])[None]))
+        ref = ho.postprocess(lg, nk, r, W, idx)
+        assert bool(valid[b]) == (ref is not None)
+        if ref is not None:
+            # what the AR stage consumes is the root-centred pose (main.py:103): north-star 1e-3
+            np.testing.assert_allclose(joints[b] - joints[b][0], ref - ref[0], rtol=0, atol=1e-3)
+            # the absolute root depth comes out of a 64x3 least-squares fit that amplifies the
+            # bf16 re-rounding noise of the backbone (flat synthetic heatmaps: all joints within
+            # a few pixels) -- bounded separately, see DESIGN.md "Numerics"
+            np.testing.assert_allclose(joints[b], ref, rtol=0, atol=4e-3)
+    # micro-batching (max_batch=8 here) and the device-pointer path give identical results
+    import torch
+    j2, v2 = eng_w.forward(torch.from_numpy(fr).cuda(), torch.from_numpy(bb).cuda())
+    torch.cuda.synchronize()
+    assert np.array_equal(j2.cpu().numpy(), joints) and np.array_equal(v2.cpu().numpy(), valid)
+
+
+def test_pose_windows_kernel():
+    import torch
+    from isbfsar_amd.hpe_engine import pose_windows
+    rng = np.random.default_rng(3)
+    j = rng.normal(0, 1, (3, 20, 30, 3)).astype(np.float32)
+    w = pose_windows(torch.from_numpy(j).cuda(), 16).cpu().numpy()
+    assert w.shape == (3 * 5, 16, 90)
+    c = j - j[:, :, :1, :]
+    for cam in range(3):
+        for k in range(5):
+            assert np.array_equal(w[cam * 5 + k], c[cam, k:k + 16].reshape(16, 90))
+
+
+def test_human_pose_estimator_dropin(bbone_state, assets):
+    from isbfsar_amd.modules.hpe.hpe import HumanPoseEstimator
+    from isbfsar_amd.params import MetrabsHIPConfig, RealSenseIntrinsics
+    cfg = MetrabsHIPConfig()
+    cfg.weights = bbone_state
+    cfg.fixed_bbox = (192, 448, 48, 432)
+    cfg.max_batch = 2
+    est = HumanPoseEstimator(cfg, RealSenseIntrinsics())
+    frame = synth.frames(1, seed=0)[0]
+    res = est.estimate(frame)
+    assert res is not None
+    assert res["pose"].shape == (30, 3) and res["pose"].dtype == np.float64
+    assert len(res["edges"]) == 29 and res["bbox"] == (192, 448, 48, 432)
+    # main.py:102-105 consumes it like this
+    pose = res["pose"] - res["pose"][0, :]
+    assert pose.reshape(-1).shape == (90,)
+    jb = HumanPoseEstimator(cfg, RealSenseIntrinsics(), just_box=True)
+    assert jb.estimate(frame) == {"bbox": (192, 48, 448, 432)}
+    nob = HumanPoseEstimator(cfg, RealSenseIntrinsics(), just_box=True, bbox_provider=lambda f: None)
+    assert nob.estimate(frame) is None
