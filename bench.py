@@ -75,13 +75,9 @@ class ArWorkload:
     def step(self):
         logits, is_true, embed = self.eng.infer(self.q, want_embed=self.world > 1)
         if self.world > 1:
-            import torch.distributed as dist
-            torch = self.torch
+            from isbfsar_amd.dist import all_gather_records, pack_records
             # one fused all-gather of the packed per-window record
-            rec = torch.cat([logits, is_true[:, None], embed.reshape(self.B, -1)], dim=1)
-            gathered = torch.empty((self.world * self.B, rec.shape[1]), dtype=rec.dtype, device=rec.device)
-            dist.all_gather_into_tensor(gathered, rec)
-            self.out = gathered
+            self.out = all_gather_records(pack_records(logits, is_true, embed))
         else:
             self.out = (logits, is_true)
 

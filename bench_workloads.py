@@ -15,6 +15,7 @@ import time
 import numpy as np
 
 from isbfsar_amd import effnetv2, synth, weights
+from isbfsar_amd.dist import all_gather_records, pack_records
 from isbfsar_amd.engine import ArEngine
 from isbfsar_amd.hpe_engine import HpeEngine, pose_windows
 
@@ -170,11 +171,8 @@ class PipelineWorkload(_HpeBase):
         logits, is_true, embed = self.ar.infer(windows, want_embed=self.world > 1)
         self.ring[:, : self.L - 1] = self.ring[:, self.steps_per_cam:].clone()     # slide the history
         if self.world > 1:
-            import torch.distributed as dist
-            rec = torch.cat([logits, is_true[:, None], embed.reshape(self.B, -1)], dim=1)
-            out = torch.empty((self.world * self.B, rec.shape[1]), dtype=rec.dtype, device=rec.device)
-            dist.all_gather_into_tensor(out, rec)
-            self.out = out
+            # ONE all-gather of the packed per-window records over RCCL/xGMI
+            self.out = all_gather_records(pack_records(logits, is_true, embed))
         else:
             self.out = (logits, is_true)
 

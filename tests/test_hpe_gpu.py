@@ -205,6 +205,17 @@ def test_forward_end_to_end_vs_oracle(eng_w, bbone_state, assets):
     assert np.array_equal(j2.cpu().numpy(), joints) and np.array_equal(v2.cpu().numpy(), valid)
 
 
+def test_shard_invariance(eng_w):
+    """Frames are independent units: any split of a batch (what DP sharding across GPUs does)
+    gives bit-identical poses (SURVEY.md 8e correctness check)."""
+    fr = synth.frames(5, seed=70)
+    bb = synth.bboxes(5, seed=70)
+    j_all, v_all = eng_w.forward(fr, bb)
+    j_a, v_a = eng_w.forward(fr[:2], bb[:2])
+    j_b, v_b = eng_w.forward(fr[2:], bb[2:])
+    assert np.array_equal(np.concatenate([j_a, j_b]), j_all) and np.array_equal(np.concatenate([v_a, v_b]), v_all)
+
+
 def test_pose_windows_kernel():
     import torch
     from isbfsar_amd.hpe_engine import pose_windows
