@@ -38,7 +38,7 @@ struct isb_ar {
 
 namespace {
 
-constexpr int kDiscMaxSplits = 64;
+constexpr int kDiscMaxSplits = 32;
 
 int ensure_ws(isb_ar* h, int Bc) {
     if (Bc <= h->ws_B) return ISB_OK;
@@ -346,8 +346,8 @@ extern "C" int isb_ar_infer(isb_ar* h, const float* d_windows, int32_t B, float*
         ISB_TRY(gemm(st, h->diff.as<float>(), 128, h->wd.as<float>(), 128, h->bd.as<float>(), h->y1.as<float>(), L,
                      Bc * T, L, 128, GEMM_ACT_NONE));
         // fc1 is a long-K, skinny GEMM: split K over the grid, partials summed in order by the tail kernel
-        const int nkt = cdiv(T * L, 32);
-        const int splits = std::max(1, std::min(std::min(nkt, kDiscMaxSplits), 512 / std::max(1, cdiv(Bc, 128) * 2)));
+        // split count depends on the model only (not on Bc): sharding a batch cannot change the result
+        const int splits = std::max(1, std::min(cdiv(T * L, 32), kDiscMaxSplits));
         GemmF32Args g1{};
         g1.A = h->y1.as<float>(); g1.lda = T * L; g1.W = h->wf1.as<float>(); g1.ldw = T * L; g1.C = h->f1.as<float>();
         g1.ldc = 256; g1.M = Bc; g1.N = 256; g1.K = T * L; g1.add_period = 1; g1.act = GEMM_ACT_NONE;

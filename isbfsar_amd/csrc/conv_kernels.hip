@@ -2,8 +2,8 @@
 //   conv_igemm  : 3x3 / 1x1 convolution as an implicit GEMM on v_mfma_f32_32x32x16_bf16
 //                 (M = B*OH*OW output pixels, N = Cout, K = KH*KW*Cin), NHWC activations,
 //                 folded-BN bias + SiLU + residual epilogue, optional SE gate on the A operand
-//   dwconv3x3   : depthwise 3x3 (+bias, SiLU), HBM-bound
-//   se_pool     : global average pool feeding the squeeze-excite FCs (f32 GEMM)
+//   dwconv3x3   : depthwise 3x3 (+bias, SiLU) fused with the squeeze-excite average pool, HBM-bound
+//   se_fc1/fc2  : the two squeeze-excite FCs in f32 on the vector ALU
 //   stem        : conv3x3/s2 3->32 in f32 on the f32 crop
 // The backbone is what the reference runs as `bbone1.engine` (utils/params.py:29, hpe.py:103);
 // layer semantics follow the public efficientnetv2-l definition (isbfsar_amd/effnetv2.py).
@@ -13,7 +13,12 @@
 // sit in LDS as [row][64 B] with the 16-B chunk index XOR-swizzled by (row>>2)&3: with that the
 // ds_read_b128 fragment reads of the 32x32x16 MFMA (lane -> row lane&31, chunk 2*ks + lane>>5)
 // are bank-conflict free (4-way without it).  Two LDS buffers, next tile's global loads in
-// flight during the MFMAs, one barrier per k-tile.
+// flight during the MFMAs, one barrier per k-tile.  The MFMA computes the TRANSPOSED output tile
+// (weights as the A operand) so each lane ends up with 4 consecutive channels of one pixel: bias,
+// SiLU and the residual are applied in registers, the bf16 tile is staged through LDS (row stride
+// BN*2+16 B: conflict-free 8-byte writes) and leaves as full 16-byte pieces.
+#include <algorithm>
+
 #include "isb_common.h"
 #include "kernels.h"
 
@@ -31,6 +36,11 @@ constexpr int ROWB = 64;          // bytes per LDS row
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
+__device__ __forceinline__ float silu_fast(float x) {
+    // x * sigmoid(x) with v_exp_f32 / v_rcp_f32 (about 1 ulp each; the result is rounded to bf16)
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+
 template <int TM, int TN, int WGM, int WGN>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     constexpr int BM = 32 * TM * WGM;
@@ -39,8 +49,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     constexpr int B_CHUNKS = BN * 4;
     constexpr int B_PASS = (B_CHUNKS + 255) / 256;
     constexpr int BUF = (BM + BN) * ROWB;
+    constexpr int CROW = BN * 2 + 16;                     // staged C tile row (bf16) + pad: conflict-free b64 writes
+    constexpr int LDS_BYTES = (2 * BUF > BM * CROW) ? 2 * BUF : BM * CROW;
     static_assert(WGM * WGN == 4, "4 waves");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
@@ -48,20 +60,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int chunk = tid & 3;
 
-    // ---- per-thread A rows (fixed over the k loop): pixel coordinates
-    int a_b[A_PASS], a_iy[A_PASS], a_ix[A_PASS];
-    bool a_ok[A_PASS];
+    // ---- per-thread A rows (fixed over the k loop): pixel coordinates, 32-bit element offsets
+    int a_off[A_PASS], a_iy[A_PASS], a_ix[A_PASS], a_gate[A_PASS];
     const int ohw = p.OH * p.OW;
 #pragma unroll
     for (int i = 0; i < A_PASS; ++i) {
         const int m = m0 + (tid >> 2) + 64 * i;
-        a_ok[i] = m < p.M;
-        const int mm = a_ok[i] ? m : 0;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
         const int b = mm / ohw, rem = mm - b * ohw;
         const int oy = rem / p.OW, ox = rem - oy * p.OW;
-        a_b[i] = b;
-        a_iy[i] = oy * p.stride - p.pad;
+        a_iy[i] = ok ? oy * p.stride - p.pad : -100000;   // rows past M never pass the bounds test
         a_ix[i] = ox * p.stride - p.pad;
+        a_off[i] = ok ? ((b * p.H + a_iy[i]) * p.W + a_ix[i]) * p.Cin + chunk * 8 : 0;
+        a_gate[i] = b * p.Cin + chunk * 8;
     }
     uint4 ra[A_PASS], rb[B_PASS];
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
@@ -71,14 +83,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         const int tap = k0 / p.Cin;
         const int c0 = k0 - tap * p.Cin;
         const int ky = tap / p.KW, kx = tap - ky * p.KW;
+        const int tap_off = (ky * p.W + kx) * p.Cin + c0;
 #pragma unroll
         for (int i = 0; i < A_PASS; ++i) {
             const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
             uint4 v = zero4;
-            if (a_ok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
-                v = *reinterpret_cast<const uint4*>(p.in + ((size_t)(a_b[i] * p.H + iy) * p.W + ix) * p.Cin + c0 + chunk * 8);
+            if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
+                v = *reinterpret_cast<const uint4*>(p.in + (a_off[i] + tap_off));
                 if (p.gate) {      // squeeze-excite gate of the producing depthwise conv (1x1 convs only)
-                    const float* g = p.gate + (size_t)a_b[i] * p.Cin + c0 + chunk * 8;
+                    const float* g = p.gate + (a_gate[i] + c0);
                     const float4 g0 = *reinterpret_cast<const float4*>(g), g1 = *reinterpret_cast<const float4*>(g + 4);
                     uint32_t w[4] = {v.x, v.y, v.z, v.w};
                     const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
@@ -116,6 +129,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         }
     };
 
+    // accumulators hold the TRANSPOSED tile: D = W_tile (rows n) x X_tile^T (cols m), so a lane owns one
+    // pixel (m = lane&31) and 4 consecutive channels per register quad -> 8-byte packed bf16 pieces
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -146,36 +161,74 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < nkt) lstore(cur ^ 1);
         __syncthreads();
     }
 
-    // epilogue: D col = lane&31 -> n, row = (e&3) + 8*(e>>2) + 4*(lane>>5) -> m
-    uint16_t* out16 = reinterpret_cast<uint16_t*>(p.out);
-    float* out32 = reinterpret_cast<float*>(p.out);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + (wn * TN + j) * 32 + r;
-        if (n >= p.Cout) continue;
-        const float bias = p.bias[n];
+    // ---- epilogue. acc[i][j][e]: channel n = n0 + (wn*TN+j)*32 + 8*(e>>2) + 4*h + (e&3), pixel m = m0 + (wm*TM+i)*32 + r
+    if (p.out_f32) {          // f32 output (last 1x1 conv feeding the f32 pose head): direct stores
+        float* out32 = reinterpret_cast<float*>(p.out);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int mb = m0 + (wm * TM + i) * 32 + 4 * h;
+            const int m = m0 + (wm * TM + i) * 32 + r;
+            if (m >= p.M) continue;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = mb + (e & 3) + 8 * (e >> 2);
-                if (m < p.M) {
-                    float v = acc[i][j][e] + bias;
-                    if (p.act) v = silu_(v);
-                    const size_t o = (size_t)m * p.Cout + n;
-                    if (p.res) v += bf2f_(p.res[o]);
-                    if (p.out_f32) out32[o] = v;
-                    else out16[o] = f2bf_(v);
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = n0 + (wn * TN + j) * 32 + 8 * q + 4 * h;
+                    if (n >= p.Cout) continue;
+                    const float4 bs = *reinterpret_cast<const float4*>(p.bias + n);
+                    float4 v = make_float4(acc[i][j][4 * q] + bs.x, acc[i][j][4 * q + 1] + bs.y, acc[i][j][4 * q + 2] + bs.z,
+                                           acc[i][j][4 * q + 3] + bs.w);
+                    if (p.act) { v.x = silu_fast(v.x); v.y = silu_fast(v.y); v.z = silu_fast(v.z); v.w = silu_fast(v.w); }
+                    *reinterpret_cast<float4*>(out32 + (size_t)m * p.Cout + n) = v;
                 }
-            }
         }
+        return;
+    }
+    // bf16 output: bias + SiLU + residual in registers (one rounding), stage the tile in LDS, then
+    // write full 16-byte pieces, 256 B contiguous per pixel row
+    unsigned char* Cs = lds;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int ml = (wm * TM + i) * 32 + r;
+        const int m = m0 + ml;
+        const bool mok = m < p.M;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nl = (wn * TN + j) * 32 + 8 * q + 4 * h;
+                const int n = n0 + nl;
+                float v0 = acc[i][j][4 * q], v1 = acc[i][j][4 * q + 1], v2 = acc[i][j][4 * q + 2], v3 = acc[i][j][4 * q + 3];
+                if (n < p.Cout) {
+                    const float4 bs = *reinterpret_cast<const float4*>(p.bias + n);
+                    v0 += bs.x; v1 += bs.y; v2 += bs.z; v3 += bs.w;
+                    if (p.act) { v0 = silu_fast(v0); v1 = silu_fast(v1); v2 = silu_fast(v2); v3 = silu_fast(v3); }
+                    if (p.res && mok) {
+                        const uint2 rr = *reinterpret_cast<const uint2*>(p.res + (size_t)m * p.Cout + n);
+                        v0 += bf2f_((uint16_t)(rr.x & 0xffff)); v1 += bf2f_((uint16_t)(rr.x >> 16));
+                        v2 += bf2f_((uint16_t)(rr.y & 0xffff)); v3 += bf2f_((uint16_t)(rr.y >> 16));
+                    }
+                }
+                uint2 pk;
+                pk.x = (uint32_t)f2bf_(v0) | ((uint32_t)f2bf_(v1) << 16);
+                pk.y = (uint32_t)f2bf_(v2) | ((uint32_t)f2bf_(v3) << 16);
+                *reinterpret_cast<uint2*>(Cs + ml * CROW + nl * 2) = pk;
+            }
+    }
+    __syncthreads();
+    uint16_t* out16 = reinterpret_cast<uint16_t*>(p.out);
+    constexpr int CPR = BN / 8;                            // 16-byte pieces per tile row
+#pragma unroll 4
+    for (int id = tid; id < BM * CPR; id += 256) {
+        const int row = id / CPR, cc = id - row * CPR;
+        const int m = m0 + row, n = n0 + cc * 8;
+        if (m < p.M && n < p.Cout)
+            *reinterpret_cast<uint4*>(out16 + (size_t)m * p.Cout + n) = *reinterpret_cast<const uint4*>(Cs + row * CROW + cc * 16);
     }
 }
 
@@ -209,99 +262,178 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t st) {
 }
 
 // =====================================================================================
-// depthwise 3x3 (+ folded-BN bias + SiLU). thread = (output pixel, 8 channels)
-// weights tap-major f32 [9][C] (BN scale folded in)
+// depthwise 3x3 (+ folded-BN bias + SiLU) fused with the squeeze-excite average pool.
+// WG = one sample x a slab of CH 8-channel chunks x all output pixels; thread = (chunk, pixel-quad):
+// 4 horizontally adjacent outputs share their input columns ((4-1)*S+3 columns x 3 rows of 16-B loads
+// instead of 36). The per-(sample, channel) mean is reduced inside the WG in a fixed order (no atomics:
+// results do not depend on scheduling) and written straight to pooled[b][c].
+// weights tap-major f32 [9][C] (BN scale folded)
 // =====================================================================================
-__global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
-    const int cg = p.C >> 3;
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t total = (size_t)p.B * p.OH * p.OW * cg;
-    if (idx >= total) return;
-    const int c8 = (int)(idx % cg);
-    size_t pix = idx / cg;
-    const int ox = (int)(pix % p.OW); pix /= p.OW;
-    const int oy = (int)(pix % p.OH);
-    const int b = (int)(pix / p.OH);
-    const int c = c8 * 8;
-    float acc[8];
-    {
+template <int S>
+__global__ __launch_bounds__(256) void dwconv3x3_pool_kernel(DwArgs p) {
+    __shared__ float red[32][129];
+    constexpr int NCOL = 3 * S + 3;
+    const int nq = (p.OH * p.OW) >> 2;                    // pixel quads per sample
+    const int PQ = nq >= 32 ? 32 : nq;                    // quad slots in the WG
+    const int CH = 256 / PQ;                              // chunks per WG (8 or 16)
+    const int cl = threadIdx.x % CH, pq = threadIdx.x / CH;
+    const int b = blockIdx.y;
+    const int c = (blockIdx.x * CH + cl) * 8;
+    const bool cok = c < p.C;
+    float w[9][8], bias[8], psum[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) psum[e] = 0.f;
+    if (cok) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float4 w0 = *reinterpret_cast<const float4*>(p.w + (size_t)t * p.C + c), w1 = *reinterpret_cast<const float4*>(p.w + (size_t)t * p.C + c + 4);
+            w[t][0] = w0.x; w[t][1] = w0.y; w[t][2] = w0.z; w[t][3] = w0.w; w[t][4] = w1.x; w[t][5] = w1.y; w[t][6] = w1.z; w[t][7] = w1.w;
+        }
         const float4 s0 = *reinterpret_cast<const float4*>(p.bias + c), s1 = *reinterpret_cast<const float4*>(p.bias + c + 4);
-        acc[0] = s0.x; acc[1] = s0.y; acc[2] = s0.z; acc[3] = s0.w; acc[4] = s1.x; acc[5] = s1.y; acc[6] = s1.z; acc[7] = s1.w;
-    }
+        bias[0] = s0.x; bias[1] = s0.y; bias[2] = s0.z; bias[3] = s0.w; bias[4] = s1.x; bias[5] = s1.y; bias[6] = s1.z; bias[7] = s1.w;
+        const int qpr = p.OW >> 2;                        // quads per output row
+        for (int q = pq; q < nq; q += PQ) {
+            const int oy = q / qpr, ox0 = (q - oy * qpr) * 4;
+            float acc[4][8];
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-        const int iy = oy * p.stride - p.pad + ky;
-        if ((unsigned)iy >= (unsigned)p.H) continue;
+            for (int o = 0; o < 4; ++o)
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int ix = ox * p.stride - p.pad + kx;
-            if ((unsigned)ix >= (unsigned)p.W) continue;
-            const uint4 v = *reinterpret_cast<const uint4*>(p.in + ((size_t)(b * p.H + iy) * p.W + ix) * p.C + c);
-            const float* w = p.w + (size_t)(ky * 3 + kx) * p.C + c;
-            const float4 w0 = *reinterpret_cast<const float4*>(w), w1 = *reinterpret_cast<const float4*>(w + 4);
-            acc[0] = fmaf(bf2f_((uint16_t)(v.x & 0xffff)), w0.x, acc[0]);
-            acc[1] = fmaf(bf2f_((uint16_t)(v.x >> 16)), w0.y, acc[1]);
-            acc[2] = fmaf(bf2f_((uint16_t)(v.y & 0xffff)), w0.z, acc[2]);
-            acc[3] = fmaf(bf2f_((uint16_t)(v.y >> 16)), w0.w, acc[3]);
-            acc[4] = fmaf(bf2f_((uint16_t)(v.z & 0xffff)), w1.x, acc[4]);
-            acc[5] = fmaf(bf2f_((uint16_t)(v.z >> 16)), w1.y, acc[5]);
-            acc[6] = fmaf(bf2f_((uint16_t)(v.w & 0xffff)), w1.z, acc[6]);
-            acc[7] = fmaf(bf2f_((uint16_t)(v.w >> 16)), w1.w, acc[7]);
+                for (int e = 0; e < 8; ++e) acc[o][e] = bias[e];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = oy * S - p.pad + ky;
+                if ((unsigned)iy >= (unsigned)p.H) continue;
+                const uint16_t* rowp = p.in + ((size_t)(b * p.H + iy) * p.W) * p.C + c;
+#pragma unroll
+                for (int col = 0; col < NCOL; ++col) {
+                    const int ix = ox0 * S - p.pad + col;
+                    if ((unsigned)ix >= (unsigned)p.W) continue;
+                    const uint4 v = *reinterpret_cast<const uint4*>(rowp + (size_t)ix * p.C);
+                    float x[8];
+                    x[0] = bf2f_((uint16_t)(v.x & 0xffff)); x[1] = bf2f_((uint16_t)(v.x >> 16));
+                    x[2] = bf2f_((uint16_t)(v.y & 0xffff)); x[3] = bf2f_((uint16_t)(v.y >> 16));
+                    x[4] = bf2f_((uint16_t)(v.z & 0xffff)); x[5] = bf2f_((uint16_t)(v.z >> 16));
+                    x[6] = bf2f_((uint16_t)(v.w & 0xffff)); x[7] = bf2f_((uint16_t)(v.w >> 16));
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) {
+                        const int kx = col - o * S;       // tap of output o that reads this column
+                        if (kx >= 0 && kx < 3) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) acc[o][e] = fmaf(x[e], w[ky * 3 + kx][e], acc[o][e]);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                uint32_t pk[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint16_t lo = f2bf_(silu_fast(acc[o][2 * e])), hi = f2bf_(silu_fast(acc[o][2 * e + 1]));
+                    pk[e] = (uint32_t)lo | ((uint32_t)hi << 16);
+                    psum[2 * e] += bf2f_(lo);              // the pool sees the stored (rounded) activations
+                    psum[2 * e + 1] += bf2f_(hi);
+                }
+                *reinterpret_cast<uint4*>(p.out + (((size_t)(b * p.OH + oy) * p.OW + ox0 + o) * p.C + c)) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            }
         }
     }
-    uint32_t o[4];
+    if (p.pooled) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-        o[e] = (uint32_t)f2bf_(silu_(acc[2 * e])) | ((uint32_t)f2bf_(silu_(acc[2 * e + 1])) << 16);
-    *reinterpret_cast<uint4*>(p.out + (((size_t)(b * p.OH + oy) * p.OW + ox) * p.C + c)) = make_uint4(o[0], o[1], o[2], o[3]);
+        for (int e = 0; e < 8; ++e) red[pq][cl * 8 + e] = psum[e];
+        __syncthreads();
+        if ((int)threadIdx.x < CH * 8) {
+            const int cc = blockIdx.x * CH * 8 + threadIdx.x;
+            if (cc < p.C) {
+                float t = 0.f;
+                for (int s2 = 0; s2 < PQ; ++s2) t += red[s2][threadIdx.x];
+                p.pooled[(size_t)b * p.C + cc] = t / (float)(p.OH * p.OW);
+            }
+        }
+    }
 }
 
 int launch_dwconv3x3(const DwArgs& a, hipStream_t st) {
-    if (a.C % 8 != 0) {
-        set_error("dwconv3x3: C=%d not a multiple of 8", a.C);
+    if (a.C % 8 != 0 || a.OW % 4 != 0 || ((a.OH * a.OW) >> 2) < 8 || 256 % std::min(32, (a.OH * a.OW) >> 2) != 0) {
+        set_error("dwconv3x3: unsupported shape C=%d OH=%d OW=%d", a.C, a.OH, a.OW);
         return ISB_ERR_INVALID;
     }
-    const size_t total = (size_t)a.B * a.OH * a.OW * (a.C / 8);
-    hipLaunchKernelGGL(dwconv3x3_kernel, dim3((unsigned)cdivz(total, 256)), dim3(256), 0, st, a);
-    ISB_LAUNCHED("dwconv3x3", st);
+    const int nq = (a.OH * a.OW) >> 2;
+    const int CH = 256 / std::min(32, nq);
+    dim3 grid(cdiv(a.C / 8, CH), a.B);
+    if (a.stride == 1) hipLaunchKernelGGL(dwconv3x3_pool_kernel<1>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(dwconv3x3_pool_kernel<2>, grid, dim3(256), 0, st, a);
+    ISB_LAUNCHED("dwconv3x3_pool", st);
     return ISB_OK;
 }
 
 // =====================================================================================
-// SE squeeze: mean over HW per (b, c). grid (C/64, B), block 256 = 8 channel-chunks x 32 pixel lanes
+// squeeze-excite FCs in f32 on the vector ALU (tiny GEMMs: latency, not FLOPs, is what matters)
+//   se_fc1: mid[b][j]  = silu(b1[j] + sum_c pooled[b][c] * W1[j][c])    wave = (j, 8 samples)
+//   se_fc2: gate[b][c] = sigmoid(b2[c] + sum_j mid[b][j] * W2T[j][c])   thread = (c, 8 samples)
+// fixed summation order -> independent of scheduling and of how the batch is sharded
 // =====================================================================================
-__global__ __launch_bounds__(256) void se_pool_kernel(PoolArgs p) {
-    __shared__ float red[32][65];
-    const int b = blockIdx.y;
-    const int cchunk = threadIdx.x & 7, pl = threadIdx.x >> 3;
-    const int c = blockIdx.x * 64 + cchunk * 8;
-    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (c < p.C) {
-        for (int px = pl; px < p.HW; px += 32) {
-            const uint4 v = *reinterpret_cast<const uint4*>(p.in + ((size_t)b * p.HW + px) * p.C + c);
-            s[0] += bf2f_((uint16_t)(v.x & 0xffff)); s[1] += bf2f_((uint16_t)(v.x >> 16));
-            s[2] += bf2f_((uint16_t)(v.y & 0xffff)); s[3] += bf2f_((uint16_t)(v.y >> 16));
-            s[4] += bf2f_((uint16_t)(v.z & 0xffff)); s[5] += bf2f_((uint16_t)(v.z >> 16));
-            s[6] += bf2f_((uint16_t)(v.w & 0xffff)); s[7] += bf2f_((uint16_t)(v.w >> 16));
+__global__ __launch_bounds__(256) void se_fc1_kernel(SeFcArgs p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.x * 4 + wave;
+    const int b0 = blockIdx.y * 8;
+    if (j >= p.cse) return;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const float* wrow = p.w1 + (size_t)j * p.C;
+    for (int c = lane * 4; c < p.C; c += 256) {
+        const float4 wv = *reinterpret_cast<const float4*>(wrow + c);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if (b0 + s < p.B) {
+                const float4 x = *reinterpret_cast<const float4*>(p.pooled + (size_t)(b0 + s) * p.C + c);
+                acc[s] = fmaf(x.x, wv.x, fmaf(x.y, wv.y, fmaf(x.z, wv.z, fmaf(x.w, wv.w, acc[s]))));
+            }
         }
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) red[pl][cchunk * 8 + e] = s[e];
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        const int cc = blockIdx.x * 64 + threadIdx.x;
-        if (cc < p.C) {
-            float t = 0.f;
+    for (int s = 0; s < 8; ++s) {
+        float v = acc[s];
 #pragma unroll
-            for (int q = 0; q < 32; ++q) t += red[q][threadIdx.x];
-            p.out[(size_t)b * p.C + cc] = t / (float)p.HW;
+        for (int sh = 32; sh >= 1; sh >>= 1) v += __shfl_xor(v, sh, 64);
+        if (lane == 0 && b0 + s < p.B) {
+            v += p.b1[j];
+            p.mid[(size_t)(b0 + s) * p.cse + j] = v / (1.0f + expf(-v));
         }
     }
 }
 
-int launch_se_pool(const PoolArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(se_pool_kernel, dim3(cdiv(a.C, 64), a.B), dim3(256), 0, st, a);
-    ISB_LAUNCHED("se_pool", st);
+__global__ __launch_bounds__(256) void se_fc2_kernel(SeFcArgs p) {
+    __shared__ float mids[8][160];
+    const int b0 = blockIdx.y * 8;
+    for (int i = threadIdx.x; i < 8 * p.cse; i += 256) {
+        const int s = i / p.cse, j = i - s * p.cse;
+        mids[s][j] = (b0 + s < p.B) ? p.mid[(size_t)(b0 + s) * p.cse + j] : 0.f;
+    }
+    __syncthreads();
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= p.C) return;
+    float acc[8];
+    const float bias = p.b2[c];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) acc[s] = bias;
+    for (int j = 0; j < p.cse; ++j) {
+        const float wv = p.w2t[(size_t)j * p.C + c];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc[s] = fmaf(mids[s][j], wv, acc[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+        if (b0 + s < p.B) p.gate[(size_t)(b0 + s) * p.C + c] = 1.0f / (1.0f + expf(-acc[s]));
+}
+
+int launch_se_fcs(const SeFcArgs& a, hipStream_t st) {
+    if (a.cse > 160 || a.C % 4 != 0) {
+        set_error("se_fcs: unsupported shape cse=%d C=%d", a.cse, a.C);
+        return ISB_ERR_INVALID;
+    }
+    hipLaunchKernelGGL(se_fc1_kernel, dim3(cdiv(a.cse, 4), cdiv(a.B, 8)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(se_fc2_kernel, dim3(cdiv(a.C, 256), cdiv(a.B, 8)), dim3(256), 0, st, a);
+    ISB_LAUNCHED("se_fcs", st);
     return ISB_OK;
 }
 

@@ -13,8 +13,6 @@ using namespace isb;
 
 namespace {
 
-constexpr int kSeMaxSplits = 32;
-
 struct ConvW {
     DevBuf w16, bias;
     int cout = 0, cin = 0, k = 0;
@@ -52,7 +50,7 @@ struct isb_hpe {
     bool has_indices = false;
     // workspace (per micro-batch)
     int ws_B = 0;
-    DevBuf H, newK, R, crops, bufX, bufY, bufE, bufD, pooled, semid, semid2, gate, feat, logits;
+    DevBuf H, newK, R, crops, bufX, bufY, bufE, bufD, pooled, semid, gate, feat, logits;
     DevBuf frames_tmp, bbox_tmp, joints_tmp, valid_tmp;
     // profiling of conv_igemm launches
     bool prof = false;
@@ -99,9 +97,8 @@ int ensure_ws(isb_hpe* h, int Bm) {
     ISB_TRY(h->bufE.alloc(B * 64 * 64 * 256 * 2));
     ISB_TRY(h->bufD.alloc(B * 32 * 32 * 384 * 2));
     ISB_TRY(h->pooled.alloc(B * 3840 * 4));
-    ISB_TRY(h->semid.alloc(B * 160 * 4 * kSeMaxSplits));
+    ISB_TRY(h->semid.alloc(B * 160 * 4));
     ISB_TRY(h->gate.alloc(B * 3840 * 4));
-    ISB_TRY(h->semid2.alloc(B * 160 * 4));
     ISB_TRY(h->feat.alloc(B * 64 * 1280 * 4));
     ISB_TRY(h->logits.alloc(B * 64 * 288 * 4));
     h->ws_B = Bm;
@@ -141,23 +138,6 @@ int gemm(hipStream_t st, const float* A, int lda, const float* W, int ldw, const
     return launch_gemm_f32(g, st);
 }
 
-// squeeze-excite FCs: mid = W1 pooled (split-K partials, summed in order by the consumer so the
-// result does not depend on scheduling), gate = sigmoid(W2 silu(mid + b1) + b2)
-int se_fcs(isb_hpe* h, hipStream_t st, const BlockW& b, int B) {
-    const int nkt = cdiv(b.cexp, 32);
-    const int tiles = cdiv(B, b.cse <= 32 ? 256 : 128) * cdiv(b.cse, b.cse <= 32 ? 32 : (b.cse <= 64 ? 64 : 128));
-    const int splits = std::max(1, std::min(std::min(nkt, kSeMaxSplits), 256 / std::max(1, tiles)));
-    GemmF32Args g{};
-    g.A = h->pooled.as<float>(); g.lda = b.cexp; g.W = b.se_w1.as<float>(); g.ldw = b.cexp; g.bias = nullptr;
-    g.C = h->semid.as<float>(); g.ldc = b.cse; g.M = B; g.N = b.cse; g.K = b.cexp; g.add_period = 1; g.act = GEMM_ACT_NONE;
-    g.splits = splits; g.split_stride = (size_t)B * b.cse;
-    ISB_TRY(launch_gemm_f32(g, st));
-    ISB_TRY(launch_reduce_parts(h->semid.as<float>(), splits, (size_t)B * b.cse, b.se_b1.as<float>(), GEMM_ACT_SILU,
-                                h->semid2.as<float>(), B, b.cse, st));
-    return gemm(st, h->semid2.as<float>(), b.cse, b.se_w2.as<float>(), b.cse, b.se_b2.as<float>(), h->gate.as<float>(), b.cexp,
-                B, b.cexp, b.cse, GEMM_ACT_SIGMOID);
-}
-
 // crops f32 [B,256,256,3] (device) -> feat f32 [B*64,1280], logits f32 [B*64,288]
 int run_backbone(isb_hpe* h, hipStream_t st, const float* crops, int B) {
     StemArgs sa{};
@@ -182,11 +162,13 @@ int run_backbone(isb_hpe* h, hipStream_t st, const float* crops, int B) {
             d.in = h->bufE.as<uint16_t>(); d.w = b.dw_w.as<float>(); d.bias = b.dw_b.as<float>(); d.out = h->bufD.as<uint16_t>();
             d.B = B; d.H = b.in_hw; d.W = b.in_hw; d.C = b.cexp; d.OH = b.out_hw; d.OW = b.out_hw; d.stride = b.stride;
             d.pad = b.stride == 1 ? 1 : 0;
+            d.pooled = h->pooled.as<float>();
             ISB_TRY(launch_dwconv3x3(d, st));
-            PoolArgs pa{};
-            pa.in = h->bufD.as<uint16_t>(); pa.out = h->pooled.as<float>(); pa.B = B; pa.HW = b.out_hw * b.out_hw; pa.C = b.cexp;
-            ISB_TRY(launch_se_pool(pa, st));
-            ISB_TRY(se_fcs(h, st, b, B));
+            SeFcArgs se{};
+            se.pooled = h->pooled.as<float>(); se.w1 = b.se_w1.as<float>(); se.b1 = b.se_b1.as<float>();
+            se.w2t = b.se_w2.as<float>(); se.b2 = b.se_b2.as<float>(); se.mid = h->semid.as<float>();
+            se.gate = h->gate.as<float>(); se.B = B; se.C = b.cexp; se.cse = b.cse;
+            ISB_TRY(launch_se_fcs(se, st));
             ISB_TRY(conv(h, st, b.project, h->bufD.p, B, b.out_hw, b.out_hw, 1, false, res, h->gate.as<float>(), Y, false));
         }
         std::swap(X, Y);
@@ -317,7 +299,12 @@ extern "C" int isb_hpe_load_weights(isb_hpe* h, const void* blob, size_t nbytes)
                 ISB_TRY(blob_get(m, (p + ".se.b2").c_str(), b->cexp, 1, &b2));
                 ISB_TRY(upload(b->se_w1, w1->data, w1->numel() * 4));
                 ISB_TRY(upload(b->se_b1, b1->data, b1->numel() * 4));
-                ISB_TRY(upload(b->se_w2, w2->data, w2->numel() * 4));
+                {   // stored transposed [cse][C]: the gate kernel reads it with the channel on the lane
+                    std::vector<float> w2t((size_t)b->cse * b->cexp);
+                    for (int c = 0; c < b->cexp; ++c)
+                        for (int j = 0; j < b->cse; ++j) w2t[(size_t)j * b->cexp + c] = w2->data[(size_t)c * b->cse + j];
+                    ISB_TRY(upload(b->se_w2, w2t.data(), w2t.size() * 4));
+                }
                 ISB_TRY(upload(b->se_b2, b2->data, b2->numel() * 4));
             }
             h->blocks.push_back(std::move(b));

@@ -129,16 +129,22 @@ struct DwArgs {
     const float* w;         // f32 [9][C] tap-major, BN scale folded
     const float* bias;      // [C]
     uint16_t* out;          // bf16 [B,OH,OW,C]
+    float* pooled;          // f32 [B,C] spatial mean of `out` (squeeze-excite input) or null
     int B, H, W, C, OH, OW, stride, pad;
 };
 int launch_dwconv3x3(const DwArgs& a, hipStream_t st);
 
-struct PoolArgs {
-    const uint16_t* in;     // bf16 [B,HW,C]
-    float* out;             // f32 [B,C]
-    int B, HW, C;
+struct SeFcArgs {
+    const float* pooled;    // [B,C]
+    const float* w1;        // [cse,C]
+    const float* b1;        // [cse]
+    const float* w2t;       // [cse,C]  (se.w2 transposed)
+    const float* b2;        // [C]
+    float* mid;             // [B,cse]
+    float* gate;            // out [B,C]
+    int B, C, cse;
 };
-int launch_se_pool(const PoolArgs& a, hipStream_t st);
+int launch_se_fcs(const SeFcArgs& a, hipStream_t st);
 
 struct StemArgs {
     const float* in;        // f32 [B,H,W,3]
