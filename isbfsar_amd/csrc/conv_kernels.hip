@@ -18,6 +18,7 @@
 // SiLU and the residual are applied in registers, the bf16 tile is staged through LDS (row stride
 // BN*2+16 B: conflict-free 8-byte writes) and leaves as full 16-byte pieces.
 #include <algorithm>
+#include <type_traits>
 
 #include "isb_common.h"
 #include "kernels.h"
@@ -75,10 +76,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         a_off[i] = ok ? ((b * p.H + a_iy[i]) * p.W + a_ix[i]) * p.Cin + chunk * 8 : 0;
         a_gate[i] = b * p.Cin + chunk * 8;
     }
-    uint4 ra[A_PASS], rb[B_PASS];
+    uint4 rA[1][A_PASS], rB[1][B_PASS];
+    float4 gA[A_PASS][2];
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i) gA[i][0] = gA[i][1] = make_float4(0.f, 0.f, 0.f, 0.f);
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    using St0 = std::integral_constant<int, 0>;
 
-    auto gload = [&](int kt) {
+    auto gload = [&](int kt, auto stage) {
+        constexpr int SG = decltype(stage)::value;
         const int k0 = kt * CK;
         const int tap = k0 / p.Cin;
         const int c0 = k0 - tap * p.Cin;
@@ -90,21 +96,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
             uint4 v = zero4;
             if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
                 v = *reinterpret_cast<const uint4*>(p.in + (a_off[i] + tap_off));
-                if (p.gate) {      // squeeze-excite gate of the producing depthwise conv (1x1 convs only)
+                if (p.gate) {      // squeeze-excite gate (1x1 convs only): fetched now, applied when the tile is
+                                   // written to LDS, so neither load is waited for before the MFMAs of this step
                     const float* g = p.gate + (a_gate[i] + c0);
-                    const float4 g0 = *reinterpret_cast<const float4*>(g), g1 = *reinterpret_cast<const float4*>(g + 4);
-                    uint32_t w[4] = {v.x, v.y, v.z, v.w};
-                    const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float lo = bf2f_((uint16_t)(w[e] & 0xffff)) * gg[2 * e];
-                        const float hi = bf2f_((uint16_t)(w[e] >> 16)) * gg[2 * e + 1];
-                        w[e] = (uint32_t)f2bf_(lo) | ((uint32_t)f2bf_(hi) << 16);
-                    }
-                    v = make_uint4(w[0], w[1], w[2], w[3]);
+                    gA[i][0] = *reinterpret_cast<const float4*>(g);
+                    gA[i][1] = *reinterpret_cast<const float4*>(g + 4);
                 }
             }
-            ra[i] = v;
+            rA[SG][i] = v;
         }
 #pragma unroll
         for (int i = 0; i < B_PASS; ++i) {
@@ -114,18 +113,33 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
                 const int n = n0 + (cidx >> 2);
                 if (n < p.Cout) v = *reinterpret_cast<const uint4*>(p.w + (size_t)n * p.K + k0 + (cidx & 3) * 8);
             }
-            rb[i] = v;
+            rB[SG][i] = v;
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, auto stage) {
+        constexpr int SG = decltype(stage)::value;
         unsigned char* As = lds + buf * BUF;
         unsigned char* Bs = As + BM * ROWB;
 #pragma unroll
-        for (int i = 0; i < A_PASS; ++i) *reinterpret_cast<uint4*>(As + swz((tid >> 2) + 64 * i, chunk)) = ra[i];
+        for (int i = 0; i < A_PASS; ++i) {
+            uint4 v = rA[SG][i];
+            if (p.gate) {
+                uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                const float gg[8] = {gA[i][0].x, gA[i][0].y, gA[i][0].z, gA[i][0].w, gA[i][1].x, gA[i][1].y, gA[i][1].z, gA[i][1].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float lo = bf2f_((uint16_t)(w[e] & 0xffff)) * gg[2 * e];
+                    const float hi = bf2f_((uint16_t)(w[e] >> 16)) * gg[2 * e + 1];
+                    w[e] = (uint32_t)f2bf_(lo) | ((uint32_t)f2bf_(hi) << 16);
+                }
+                v = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            *reinterpret_cast<uint4*>(As + swz((tid >> 2) + 64 * i, chunk)) = v;
+        }
 #pragma unroll
         for (int i = 0; i < B_PASS; ++i) {
             const int cidx = tid + 256 * i;
-            if (cidx < B_CHUNKS) *reinterpret_cast<uint4*>(Bs + swz(cidx >> 2, cidx & 3)) = rb[i];
+            if (cidx < B_CHUNKS) *reinterpret_cast<uint4*>(Bs + swz(cidx >> 2, cidx & 3)) = rB[SG][i];
         }
     };
 
@@ -140,12 +154,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int nkt = p.K / CK;
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nkt) gload(kt + 1);
+    auto compute = [&](int cur) {
         const unsigned char* As = lds + cur * BUF;
         const unsigned char* Bs = As + BM * ROWB;
 #pragma unroll
@@ -163,7 +172,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nkt) lstore(cur ^ 1);
+    };
+    gload(0, St0{});
+    lstore(0, St0{});
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) gload(kt + 1, St0{});            // in flight during this tile's MFMAs
+        compute(cur);
+        if (kt + 1 < nkt) lstore(cur ^ 1, St0{});
         __syncthreads();
     }
 
@@ -302,18 +319,23 @@ __global__ __launch_bounds__(256) void dwconv3x3_pool_kernel(DwArgs p) {
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const int iy = oy * S - p.pad + ky;
-                if ((unsigned)iy >= (unsigned)p.H) continue;
-                const uint16_t* rowp = p.in + ((size_t)(b * p.H + iy) * p.W) * p.C + c;
+                const bool yok = (unsigned)iy < (unsigned)p.H;
+                const uint16_t* rowp = p.in + ((size_t)(b * p.H + (yok ? iy : 0)) * p.W) * p.C + c;
+                uint4 v[NCOL];
+#pragma unroll
+                for (int col = 0; col < NCOL; ++col) {     // branch-free: every load of the row is in flight at once
+                    const int ix = ox0 * S - p.pad + col;
+                    const bool ok = yok && (unsigned)ix < (unsigned)p.W;
+                    const uint4 t = *reinterpret_cast<const uint4*>(rowp + (size_t)(ok ? ix : 0) * p.C);
+                    v[col] = ok ? t : make_uint4(0, 0, 0, 0);
+                }
 #pragma unroll
                 for (int col = 0; col < NCOL; ++col) {
-                    const int ix = ox0 * S - p.pad + col;
-                    if ((unsigned)ix >= (unsigned)p.W) continue;
-                    const uint4 v = *reinterpret_cast<const uint4*>(rowp + (size_t)ix * p.C);
                     float x[8];
-                    x[0] = bf2f_((uint16_t)(v.x & 0xffff)); x[1] = bf2f_((uint16_t)(v.x >> 16));
-                    x[2] = bf2f_((uint16_t)(v.y & 0xffff)); x[3] = bf2f_((uint16_t)(v.y >> 16));
-                    x[4] = bf2f_((uint16_t)(v.z & 0xffff)); x[5] = bf2f_((uint16_t)(v.z >> 16));
-                    x[6] = bf2f_((uint16_t)(v.w & 0xffff)); x[7] = bf2f_((uint16_t)(v.w >> 16));
+                    x[0] = bf2f_((uint16_t)(v[col].x & 0xffff)); x[1] = bf2f_((uint16_t)(v[col].x >> 16));
+                    x[2] = bf2f_((uint16_t)(v[col].y & 0xffff)); x[3] = bf2f_((uint16_t)(v[col].y >> 16));
+                    x[4] = bf2f_((uint16_t)(v[col].z & 0xffff)); x[5] = bf2f_((uint16_t)(v[col].z >> 16));
+                    x[6] = bf2f_((uint16_t)(v[col].w & 0xffff)); x[7] = bf2f_((uint16_t)(v[col].w >> 16));
 #pragma unroll
                     for (int o = 0; o < 4; ++o) {
                         const int kx = col - o * S;       // tap of output o that reads this column
