@@ -42,148 +42,14 @@ __device__ __forceinline__ float silu_fast(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
 
+// epilogue shared by the register-staged and the LDS-DMA kernels
 template <int TM, int TN, int WGM, int WGN>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[TM][TN], unsigned char* lds, int m0, int n0,
+                                              int wm, int wn, int r, int h, int tid) {
+    constexpr int NT = 64 * WGM * WGN;
     constexpr int BM = 32 * TM * WGM;
     constexpr int BN = 32 * TN * WGN;
-    constexpr int A_PASS = BM / 64;                       // 16-B chunks per thread for the A tile
-    constexpr int B_CHUNKS = BN * 4;
-    constexpr int B_PASS = (B_CHUNKS + 255) / 256;
-    constexpr int BUF = (BM + BN) * ROWB;
-    constexpr int CROW = BN * 2 + 16;                     // staged C tile row (bf16) + pad: conflict-free b64 writes
-    constexpr int LDS_BYTES = (2 * BUF > BM * CROW) ? 2 * BUF : BM * CROW;
-    static_assert(WGM * WGN == 4, "4 waves");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WGN, wn = wave % WGN;
-    const int r = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int chunk = tid & 3;
-
-    // ---- per-thread A rows (fixed over the k loop): pixel coordinates, 32-bit element offsets
-    int a_off[A_PASS], a_iy[A_PASS], a_ix[A_PASS], a_gate[A_PASS];
-    const int ohw = p.OH * p.OW;
-#pragma unroll
-    for (int i = 0; i < A_PASS; ++i) {
-        const int m = m0 + (tid >> 2) + 64 * i;
-        const bool ok = m < p.M;
-        const int mm = ok ? m : 0;
-        const int b = mm / ohw, rem = mm - b * ohw;
-        const int oy = rem / p.OW, ox = rem - oy * p.OW;
-        a_iy[i] = ok ? oy * p.stride - p.pad : -100000;   // rows past M never pass the bounds test
-        a_ix[i] = ox * p.stride - p.pad;
-        a_off[i] = ok ? ((b * p.H + a_iy[i]) * p.W + a_ix[i]) * p.Cin + chunk * 8 : 0;
-        a_gate[i] = b * p.Cin + chunk * 8;
-    }
-    uint4 rA[1][A_PASS], rB[1][B_PASS];
-    float4 gA[A_PASS][2];
-#pragma unroll
-    for (int i = 0; i < A_PASS; ++i) gA[i][0] = gA[i][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
-    using St0 = std::integral_constant<int, 0>;
-
-    auto gload = [&](int kt, auto stage) {
-        constexpr int SG = decltype(stage)::value;
-        const int k0 = kt * CK;
-        const int tap = k0 / p.Cin;
-        const int c0 = k0 - tap * p.Cin;
-        const int ky = tap / p.KW, kx = tap - ky * p.KW;
-        const int tap_off = (ky * p.W + kx) * p.Cin + c0;
-#pragma unroll
-        for (int i = 0; i < A_PASS; ++i) {
-            const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
-            uint4 v = zero4;
-            if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
-                v = *reinterpret_cast<const uint4*>(p.in + (a_off[i] + tap_off));
-                if (p.gate) {      // squeeze-excite gate (1x1 convs only): fetched now, applied when the tile is
-                                   // written to LDS, so neither load is waited for before the MFMAs of this step
-                    const float* g = p.gate + (a_gate[i] + c0);
-                    gA[i][0] = *reinterpret_cast<const float4*>(g);
-                    gA[i][1] = *reinterpret_cast<const float4*>(g + 4);
-                }
-            }
-            rA[SG][i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < B_PASS; ++i) {
-            const int cidx = tid + 256 * i;
-            uint4 v = zero4;
-            if (cidx < B_CHUNKS) {
-                const int n = n0 + (cidx >> 2);
-                if (n < p.Cout) v = *reinterpret_cast<const uint4*>(p.w + (size_t)n * p.K + k0 + (cidx & 3) * 8);
-            }
-            rB[SG][i] = v;
-        }
-    };
-    auto lstore = [&](int buf, auto stage) {
-        constexpr int SG = decltype(stage)::value;
-        unsigned char* As = lds + buf * BUF;
-        unsigned char* Bs = As + BM * ROWB;
-#pragma unroll
-        for (int i = 0; i < A_PASS; ++i) {
-            uint4 v = rA[SG][i];
-            if (p.gate) {
-                uint32_t w[4] = {v.x, v.y, v.z, v.w};
-                const float gg[8] = {gA[i][0].x, gA[i][0].y, gA[i][0].z, gA[i][0].w, gA[i][1].x, gA[i][1].y, gA[i][1].z, gA[i][1].w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float lo = bf2f_((uint16_t)(w[e] & 0xffff)) * gg[2 * e];
-                    const float hi = bf2f_((uint16_t)(w[e] >> 16)) * gg[2 * e + 1];
-                    w[e] = (uint32_t)f2bf_(lo) | ((uint32_t)f2bf_(hi) << 16);
-                }
-                v = make_uint4(w[0], w[1], w[2], w[3]);
-            }
-            *reinterpret_cast<uint4*>(As + swz((tid >> 2) + 64 * i, chunk)) = v;
-        }
-#pragma unroll
-        for (int i = 0; i < B_PASS; ++i) {
-            const int cidx = tid + 256 * i;
-            if (cidx < B_CHUNKS) *reinterpret_cast<uint4*>(Bs + swz(cidx >> 2, cidx & 3)) = rB[SG][i];
-        }
-    };
-
-    // accumulators hold the TRANSPOSED tile: D = W_tile (rows n) x X_tile^T (cols m), so a lane owns one
-    // pixel (m = lane&31) and 4 consecutive channels per register quad -> 8-byte packed bf16 pieces
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    const int nkt = p.K / CK;
-    auto compute = [&](int cur) {
-        const unsigned char* As = lds + cur * BUF;
-        const unsigned char* Bs = As + BM * ROWB;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[TM], bfr[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(As + swz((wm * TM + i) * 32 + r, 2 * ks + h)));
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Bs + swz((wn * TN + j) * 32 + r, 2 * ks + h)));
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-        }
-    };
-    gload(0, St0{});
-    lstore(0, St0{});
-    __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nkt) gload(kt + 1, St0{});            // in flight during this tile's MFMAs
-        compute(cur);
-        if (kt + 1 < nkt) lstore(cur ^ 1, St0{});
-        __syncthreads();
-    }
-
+    constexpr int CROW = BN * 2 + 16;
     // ---- epilogue. acc[i][j][e]: channel n = n0 + (wn*TN+j)*32 + 8*(e>>2) + 4*h + (e&3), pixel m = m0 + (wm*TM+i)*32 + r
     if (p.out_f32) {          // f32 output (last 1x1 conv feeding the f32 pose head): direct stores
         float* out32 = reinterpret_cast<float*>(p.out);
@@ -241,12 +107,303 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     uint16_t* out16 = reinterpret_cast<uint16_t*>(p.out);
     constexpr int CPR = BN / 8;                            // 16-byte pieces per tile row
 #pragma unroll 4
-    for (int id = tid; id < BM * CPR; id += 256) {
+    for (int id = tid; id < BM * CPR; id += NT) {
         const int row = id / CPR, cc = id - row * CPR;
         const int m = m0 + row, n = n0 + cc * 8;
         if (m < p.M && n < p.Cout)
             *reinterpret_cast<uint4*>(out16 + (size_t)m * p.Cout + n) = *reinterpret_cast<const uint4*>(Cs + row * CROW + cc * 16);
     }
+}
+
+template <int TM, int TN, int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(ConvArgs p) {
+    constexpr int NT = 64 * WGM * WGN;                    // threads: 4 or 8 waves
+    constexpr int BM = 32 * TM * WGM;
+    constexpr int BN = 32 * TN * WGN;
+    constexpr int A_ROWS = NT / 4;                        // tile rows staged per pass (4 x 16-B chunks per row)
+    constexpr int A_PASS = BM / A_ROWS;
+    constexpr int B_CHUNKS = BN * 4;
+    constexpr int B_PASS = (B_CHUNKS + NT - 1) / NT;
+    constexpr int BUF = (BM + BN) * ROWB;
+    constexpr int CROW = BN * 2 + 16;                     // staged C tile row (bf16) + pad: conflict-free b64 writes
+    constexpr int LDS_BYTES = (2 * BUF > BM * CROW) ? 2 * BUF : BM * CROW;
+    static_assert(BM % A_ROWS == 0, "A tile rows must divide evenly over the threads");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int r = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int chunk = tid & 3;
+
+    // ---- per-thread A rows (fixed over the k loop): pixel coordinates, 32-bit element offsets
+    int a_off[A_PASS], a_iy[A_PASS], a_ix[A_PASS], a_gate[A_PASS];
+    const int ohw = p.OH * p.OW;
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i) {
+        const int m = m0 + (tid >> 2) + A_ROWS * i;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int b = mm / ohw, rem = mm - b * ohw;
+        const int oy = rem / p.OW, ox = rem - oy * p.OW;
+        a_iy[i] = ok ? oy * p.stride - p.pad : -100000;   // rows past M never pass the bounds test
+        a_ix[i] = ox * p.stride - p.pad;
+        a_off[i] = ok ? ((b * p.H + a_iy[i]) * p.W + a_ix[i]) * p.Cin + chunk * 8 : 0;
+        a_gate[i] = b * p.Cin + chunk * 8;
+    }
+    uint4 rA[1][A_PASS], rB[1][B_PASS];
+    float4 gA[A_PASS][2];
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i) gA[i][0] = gA[i][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    using St0 = std::integral_constant<int, 0>;
+
+    auto gload = [&](int kt, auto stage) {
+        constexpr int SG = decltype(stage)::value;
+        const int k0 = kt * CK;
+        const int tap = k0 / p.Cin;
+        const int c0 = k0 - tap * p.Cin;
+        const int ky = tap / p.KW, kx = tap - ky * p.KW;
+        const int tap_off = (ky * p.W + kx) * p.Cin + c0;
+#pragma unroll
+        for (int i = 0; i < A_PASS; ++i) {
+            const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
+            uint4 v = zero4;
+            if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
+                v = *reinterpret_cast<const uint4*>(p.in + (a_off[i] + tap_off));
+                if (p.gate) {      // squeeze-excite gate (1x1 convs only): fetched now, applied when the tile is
+                                   // written to LDS, so neither load is waited for before the MFMAs of this step
+                    const float* g = p.gate + (a_gate[i] + c0);
+                    gA[i][0] = *reinterpret_cast<const float4*>(g);
+                    gA[i][1] = *reinterpret_cast<const float4*>(g + 4);
+                }
+            }
+            rA[SG][i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_PASS; ++i) {
+            const int cidx = tid + NT * i;
+            uint4 v = zero4;
+            if (cidx < B_CHUNKS) {
+                const int n = n0 + (cidx >> 2);
+                if (n < p.Cout) v = *reinterpret_cast<const uint4*>(p.w + (size_t)n * p.K + k0 + (cidx & 3) * 8);
+            }
+            rB[SG][i] = v;
+        }
+    };
+    auto lstore = [&](int buf, auto stage) {
+        constexpr int SG = decltype(stage)::value;
+        unsigned char* As = lds + buf * BUF;
+        unsigned char* Bs = As + BM * ROWB;
+#pragma unroll
+        for (int i = 0; i < A_PASS; ++i) {
+            uint4 v = rA[SG][i];
+            if (p.gate) {
+                uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                const float gg[8] = {gA[i][0].x, gA[i][0].y, gA[i][0].z, gA[i][0].w, gA[i][1].x, gA[i][1].y, gA[i][1].z, gA[i][1].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float lo = bf2f_((uint16_t)(w[e] & 0xffff)) * gg[2 * e];
+                    const float hi = bf2f_((uint16_t)(w[e] >> 16)) * gg[2 * e + 1];
+                    w[e] = (uint32_t)f2bf_(lo) | ((uint32_t)f2bf_(hi) << 16);
+                }
+                v = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            *reinterpret_cast<uint4*>(As + swz((tid >> 2) + A_ROWS * i, chunk)) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_PASS; ++i) {
+            const int cidx = tid + NT * i;
+            if (cidx < B_CHUNKS) *reinterpret_cast<uint4*>(Bs + swz(cidx >> 2, cidx & 3)) = rB[SG][i];
+        }
+    };
+
+    // accumulators hold the TRANSPOSED tile: D = W_tile (rows n) x X_tile^T (cols m), so a lane owns one
+    // pixel (m = lane&31) and 4 consecutive channels per register quad -> 8-byte packed bf16 pieces
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nkt = p.K / CK;
+    auto compute = [&](int cur) {
+        const unsigned char* As = lds + cur * BUF;
+        const unsigned char* Bs = As + BM * ROWB;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[TM], bfr[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(As + swz((wm * TM + i) * 32 + r, 2 * ks + h)));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Bs + swz((wn * TN + j) * 32 + r, 2 * ks + h)));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    };
+    gload(0, St0{});
+    lstore(0, St0{});
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) gload(kt + 1, St0{});            // in flight during this tile's MFMAs
+        compute(cur);
+        if (kt + 1 < nkt) lstore(cur ^ 1, St0{});
+        __syncthreads();
+    }
+
+    conv_epilogue<TM, TN, WGM, WGN>(p, acc, lds, m0, n0, wm, wn, r, h, tid);
+}
+
+// -------------------------------------------------------------------------------------------
+// LDS-DMA variant (convolutions without an SE gate): tiles go global -> LDS directly
+// (global_load_lds_dwordx4: 1 KiB per wave-instruction, destination = wave-uniform base + lane*16,
+// so the XOR swizzle is applied to the per-lane SOURCE address). No staging registers, no
+// ds_write instructions; padding taps and rows past M read a 16-byte zero line. The DMA of tile
+// k+1 is in flight while tile k feeds the MFMAs; __syncthreads() waits for it (vmcnt) before the swap.
+// -------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+template <int TM, int TN, int WGM, int WGN, int NB>
+__global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_kernel(ConvArgs p) {
+    constexpr int NW = WGM * WGN;
+    constexpr int BM = 32 * TM * WGM;
+    constexpr int BN = 32 * TN * WGN;
+    constexpr int A_INST = BM / 16, B_INST = BN / 16;    // 1-KiB pieces (16 tile rows) per tile
+    constexpr int A_PW = (A_INST + NW - 1) / NW, B_PW = (B_INST + NW - 1) / NW;
+    constexpr int BUF = (BM + BN) * ROWB;
+    constexpr int CROW = BN * 2 + 16;
+    constexpr int LDS_BYTES = (NB * BUF > BM * CROW) ? NB * BUF : BM * CROW;
+    static_assert(NB == 2 || (A_INST % NW == 0 && B_INST % NW == 0), "ring mode needs the same DMA count in every wave");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int r = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+    // lane -> (tile row, logical chunk) of the 1-KiB piece it fills: LDS position lane*16 holds
+    // physical chunk lane&3 of row lane>>2; the source chunk is the inverse swizzle of that
+    int a_off[A_PW], a_iy[A_PW], a_ix[A_PW], b_off[B_PW];
+    const int ohw = p.OH * p.OW;
+#pragma unroll
+    for (int s = 0; s < A_PW; ++s) {
+        const int row = 16 * (wave + NW * s) + (lane >> 2);
+        const int logical = (lane & 3) ^ ((row >> 2) & 3);
+        const int m = m0 + row;
+        const bool ok = m < p.M && row < BM;
+        const int mm = ok ? m : 0;
+        const int b = mm / ohw, rem = mm - b * ohw;
+        const int oy = rem / p.OW, ox = rem - oy * p.OW;
+        a_iy[s] = ok ? oy * p.stride - p.pad : -100000;
+        a_ix[s] = ox * p.stride - p.pad;
+        a_off[s] = ok ? ((b * p.H + a_iy[s]) * p.W + a_ix[s]) * p.Cin + logical * 8 : 0;
+    }
+#pragma unroll
+    for (int s = 0; s < B_PW; ++s) {
+        const int row = 16 * (wave + NW * s) + (lane >> 2);
+        const int logical = (lane & 3) ^ ((row >> 2) & 3);
+        const int n = n0 + row;
+        b_off[s] = (n < p.Cout && row < BN) ? n * p.K + logical * 8 : -1;
+    }
+
+    auto dma = [&](int kt, int buf) {
+        const int k0 = kt * CK;
+        const int tap = k0 / p.Cin;
+        const int c0 = k0 - tap * p.Cin;
+        const int ky = tap / p.KW, kx = tap - ky * p.KW;
+        const int tap_off = (ky * p.W + kx) * p.Cin + c0;
+        unsigned char* base = lds + buf * BUF;
+#pragma unroll
+        for (int s = 0; s < A_PW; ++s) {
+            const int q = wave + NW * s;
+            if (q < A_INST) {
+                const int iy = a_iy[s] + ky, ix = a_ix[s] + kx;
+                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                const uint16_t* src = ok ? p.in + (a_off[s] + tap_off) : p.zeros;
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(base + q * 1024), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < B_PW; ++s) {
+            const int q = wave + NW * s;
+            if (q < B_INST) {
+                const uint16_t* src = b_off[s] >= 0 ? p.w + (b_off[s] + k0) : p.zeros;
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(base + BM * ROWB + q * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    auto compute = [&](int cur) {
+        const unsigned char* As = lds + cur * BUF;
+        const unsigned char* Bs = As + BM * ROWB;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[TM], bfr[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(As + swz((wm * TM + i) * 32 + r, 2 * ks + h)));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Bs + swz((wn * TN + j) * 32 + r, 2 * ks + h)));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    const int nkt = p.K / CK;
+    if constexpr (NB == 2) {
+        dma(0, 0);
+        __syncthreads();
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nkt) dma(kt + 1, cur ^ 1);
+            compute(cur);
+            __syncthreads();
+        }
+    } else {
+        // ring of NB buffers, D = NB-2 tiles in flight beyond the one being consumed. One barrier per
+        // tile, placed BEFORE the MFMAs; the DMA issued in iteration kt overwrites the buffer of tile
+        // kt-2, which every wave finished before it arrived at barrier kt-1 (hence NB = D + 2).
+        // Waits are counted (never vmcnt(0) in steady state) and the barrier is the raw s_barrier:
+        // __syncthreads() would drain the DMA queue.
+        constexpr int D = NB - 2;
+        constexpr int PER = A_PW + B_PW;                    // DMA instructions per wave per tile
+#pragma unroll
+        for (int t = 0; t < D; ++t)
+            if (t < nkt) dma(t, t);
+        for (int kt = 0; kt < nkt; ++kt) {
+            if (kt + D < nkt) dma(kt + D, (kt + D) % NB);
+            const int ahead = min(D, nkt - 1 - kt);         // tiles issued after tile kt
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            compute(kt % NB);
+        }
+        __syncthreads();                                    // all MFMA reads done before the tile staging reuses LDS
+    }
+    conv_epilogue<TM, TN, WGM, WGN>(p, acc, lds, m0, n0, wm, wn, r, h, tid);
 }
 
 int launch_conv_igemm(const ConvArgs& a, hipStream_t st) {
@@ -258,22 +415,75 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t st) {
         set_error("conv_igemm: SE gate only on 1x1 convolutions");
         return ISB_ERR_INVALID;
     }
-    if (a.Cout % 128 == 0) {
-        dim3 g(cdiv(a.M, 128), a.Cout / 128);
-        hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2>), g, dim3(256), 0, st, a);
-    } else if (a.Cout % 96 == 0) {
-        dim3 g(cdiv(a.M, 128), a.Cout / 96);
-        hipLaunchKernelGGL((conv_igemm_kernel<1, 3, 4, 1>), g, dim3(256), 0, st, a);
-    } else if (a.Cout % 64 == 0) {
-        dim3 g(cdiv(a.M, 128), a.Cout / 64);
-        hipLaunchKernelGGL((conv_igemm_kernel<2, 1, 2, 2>), g, dim3(256), 0, st, a);
-    } else if (a.Cout == 224) {
-        dim3 g(cdiv(a.M, 128), 1);
-        hipLaunchKernelGGL((conv_igemm_kernel<1, 7, 4, 1>), g, dim3(256), 0, st, a);
-    } else {
-        dim3 g(cdiv(a.M, 256), a.Cout / 32);
-        hipLaunchKernelGGL((conv_igemm_kernel<2, 1, 4, 1>), g, dim3(256), 0, st, a);
+    // tile variants: 0 = pick by Cout
+    int v = a.variant;
+    if (v == 0) {
+        // measured on MI355X (tools/conv_sweep.py, profiles/): without an SE gate the LDS-DMA kernels win,
+        // 8-wave 256-row tiles for wide outputs; gated projections stay on the register-staged kernel
+        if (!a.gate && a.zeros) {
+            if (a.Cout % 128 == 0) v = 16;            // 256 x 128, 8 waves
+            else if (a.Cout % 64 == 0) v = 19;        // 256 x  64, 8 waves
+            else if (a.Cout % 96 == 0) v = 12;        // 128 x  96
+            else if (a.Cout == 224) v = 14;
+            else v = 15;                              // 256 x  32
+        } else {
+            if (a.Cout % 128 == 0) v = 1;
+            else if (a.Cout % 96 == 0) v = 2;
+            else if (a.Cout % 64 == 0) v = 3;
+            else if (a.Cout == 224) v = 1;            // two 128-wide column blocks beat the 224-wide tile
+            else v = 5;
+        }
     }
+    if (v > 10 && (a.gate || !a.zeros)) {
+        set_error("conv_igemm: the LDS-DMA variants take no SE gate and need the zero line");
+        return ISB_ERR_INVALID;
+    }
+#define ISB_CONV_LAUNCH(TM, TN, WGM, WGN)                                                              \
+    do {                                                                                               \
+        dim3 g(cdiv(a.M, 32 * TM * WGM), cdiv(a.Cout, 32 * TN * WGN));                                 \
+        hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, WGM, WGN>), g, dim3(64 * WGM * WGN), 0, st, a); \
+    } while (0)
+    switch (v) {
+        case 1: ISB_CONV_LAUNCH(2, 2, 2, 2); break;      // 128 x 128, 4 waves
+        case 2: ISB_CONV_LAUNCH(1, 3, 4, 1); break;      // 128 x  96
+        case 3: ISB_CONV_LAUNCH(2, 1, 2, 2); break;      // 128 x  64
+        case 4: ISB_CONV_LAUNCH(1, 7, 4, 1); break;      // 128 x 224
+        case 5: ISB_CONV_LAUNCH(2, 1, 4, 1); break;      // 256 x  32
+        case 6: ISB_CONV_LAUNCH(2, 2, 4, 2); break;      // 256 x 128, 8 waves
+        case 7: ISB_CONV_LAUNCH(4, 2, 2, 4); break;      // 256 x 256, 8 waves
+        case 8: ISB_CONV_LAUNCH(2, 3, 4, 2); break;      // 256 x 192, 8 waves
+        case 9: ISB_CONV_LAUNCH(2, 1, 4, 2); break;      // 256 x  64, 8 waves
+#define ISB_CONV_LAUNCH_DMA(TM, TN, WGM, WGN)                                                              \
+    do {                                                                                                   \
+        dim3 g(cdiv(a.M, 32 * TM * WGM), cdiv(a.Cout, 32 * TN * WGN));                                     \
+        hipLaunchKernelGGL((conv_igemm_dma_kernel<TM, TN, WGM, WGN, 2>), g, dim3(64 * WGM * WGN), 0, st, a); \
+    } while (0)
+        case 11: ISB_CONV_LAUNCH_DMA(2, 2, 2, 2); break;
+        case 12: ISB_CONV_LAUNCH_DMA(1, 3, 4, 1); break;
+        case 13: ISB_CONV_LAUNCH_DMA(2, 1, 2, 2); break;
+        case 14: ISB_CONV_LAUNCH_DMA(1, 7, 4, 1); break;
+        case 15: ISB_CONV_LAUNCH_DMA(2, 1, 4, 1); break;
+        case 16: ISB_CONV_LAUNCH_DMA(2, 2, 4, 2); break;
+        case 17: ISB_CONV_LAUNCH_DMA(4, 2, 2, 4); break;
+        case 18: ISB_CONV_LAUNCH_DMA(2, 3, 4, 2); break;
+        case 19: ISB_CONV_LAUNCH_DMA(2, 1, 4, 2); break;
+#undef ISB_CONV_LAUNCH_DMA
+#define ISB_CONV_LAUNCH_RING(TM, TN, WGM, WGN)                                                                \
+    do {                                                                                                      \
+        dim3 g(cdiv(a.M, 32 * TM * WGM), cdiv(a.Cout, 32 * TN * WGN));                                        \
+        hipLaunchKernelGGL((conv_igemm_dma_kernel<TM, TN, WGM, WGN, 4>), g, dim3(64 * WGM * WGN), 0, st, a); \
+    } while (0)
+        case 21: ISB_CONV_LAUNCH_RING(2, 2, 2, 2); break;   // 128 x 128, 4 waves, 4-buffer ring
+        case 23: ISB_CONV_LAUNCH_RING(2, 1, 2, 2); break;   // 128 x  64
+        case 26: ISB_CONV_LAUNCH_RING(2, 2, 4, 2); break;   // 256 x 128, 8 waves
+        case 27: ISB_CONV_LAUNCH_RING(4, 2, 2, 4); break;   // 256 x 256, 8 waves
+        case 28: ISB_CONV_LAUNCH_RING(4, 1, 2, 4); break;   // 256 x 128 as 2x4 waves of 128x32
+#undef ISB_CONV_LAUNCH_RING
+        default:
+            set_error("conv_igemm: unknown tile variant %d", v);
+            return ISB_ERR_INVALID;
+    }
+#undef ISB_CONV_LAUNCH
     ISB_LAUNCHED("conv_igemm", st);
     return ISB_OK;
 }

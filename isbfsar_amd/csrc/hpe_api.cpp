@@ -50,6 +50,7 @@ struct isb_hpe {
     bool has_indices = false;
     // workspace (per micro-batch)
     int ws_B = 0;
+    DevBuf zeros;
     DevBuf H, newK, R, crops, bufX, bufY, bufE, bufD, pooled, semid, gate, feat, logits;
     DevBuf frames_tmp, bbox_tmp, joints_tmp, valid_tmp;
     // profiling of conv_igemm launches
@@ -115,6 +116,7 @@ int conv(isb_hpe* h, hipStream_t st, const ConvW& cw, const void* in, int B, int
     a.pad = (cw.k == 3 && stride == 1) ? 1 : 0;          // TF SAME: stride 2 on an even input pads bottom/right only
     a.M = B * a.OH * a.OW; a.K = cw.k * cw.k * cw.cin;
     a.act = act ? 1 : 0; a.out_f32 = out_f32 ? 1 : 0;
+    a.zeros = h->zeros.as<uint16_t>();
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->prof) {
         ISB_HIP(hipEventCreate(&e0));
@@ -220,6 +222,8 @@ extern "C" int isb_hpe_create(const isb_hpe_cfg* cfg, isb_hpe** out) {
     // K as float32 values (hpe.py:28-33)
     h->K[0] = (double)cfg->fx; h->K[2] = (double)cfg->ppx; h->K[4] = (double)cfg->fy; h->K[5] = (double)cfg->ppy; h->K[8] = 1.0;
     ISB_HIP(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    ISB_TRY(h->zeros.alloc(256));
+    ISB_HIP(hipMemset(h->zeros.p, 0, 256));
     *out = h.release();
     return ISB_OK;
 }
@@ -482,4 +486,49 @@ extern "C" int isb_pose_windows(const float* d_joints, int32_t n_cam, int32_t n_
     ISB_REQUIRE(n_cam >= 1 && J >= 1 && L >= 1 && n_frames >= L, ISB_ERR_INVALID,
                 "bad shape n_cam=%d n_frames=%d J=%d L=%d", n_cam, n_frames, J, L);
     return launch_pose_windows(d_joints, n_cam, n_frames, J, L, d_windows, (hipStream_t)stream);
+}
+
+// test / tuning hook: one conv_igemm layer on host tensors, timed with HIP events
+extern "C" int isb_debug_conv(int32_t device, const uint16_t* x, const float* w, const float* scale, const float* shift,
+                              const uint16_t* res, const float* gate, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                              int32_t Cout, int32_t k, int32_t stride, int32_t act, int32_t variant, int32_t iters,
+                              uint16_t* out, float* ms_per_iter) {
+    ISB_REQUIRE(x && w && scale && shift && out && ms_per_iter, ISB_ERR_INVALID, "null argument");
+    ISB_REQUIRE((k == 1 || k == 3) && (stride == 1 || stride == 2) && iters >= 1, ISB_ERR_INVALID, "bad conv parameters");
+    ISB_HIP(hipSetDevice(device));
+    const int OH = H / stride, OW = W / stride;
+    const size_t nin = (size_t)B * H * W * Cin, nout = (size_t)B * OH * OW * Cout, nw = (size_t)Cout * k * k * Cin;
+    DevBuf dx, dwf, dsc, dsh, dw16, dres, dgate, dout, dzero;
+    ISB_TRY(dzero.alloc(256));
+    ISB_HIP(hipMemset(dzero.p, 0, 256));
+    ISB_TRY(upload(dx, x, nin * 2));
+    ISB_TRY(upload(dwf, w, nw * 4));
+    ISB_TRY(upload(dsc, scale, (size_t)Cout * 4));
+    ISB_TRY(upload(dsh, shift, (size_t)Cout * 4));
+    ISB_TRY(dw16.alloc(nw * 2));
+    ISB_TRY(dout.alloc(nout * 2));
+    if (res) ISB_TRY(upload(dres, res, nout * 2));
+    if (gate) ISB_TRY(upload(dgate, gate, (size_t)B * Cin * 4));
+    ISB_TRY(launch_f32_to_bf16_rows(dwf.as<float>(), dsc.as<float>(), dw16.as<uint16_t>(), Cout, (size_t)k * k * Cin, nullptr));
+    ConvArgs a{};
+    a.in = dx.as<uint16_t>(); a.w = dw16.as<uint16_t>(); a.bias = dsh.as<float>();
+    a.res = res ? dres.as<uint16_t>() : nullptr; a.gate = gate ? dgate.as<float>() : nullptr; a.out = dout.p;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = k; a.KW = k; a.stride = stride; a.OH = OH; a.OW = OW;
+    a.pad = (k == 3 && stride == 1) ? 1 : 0; a.M = B * OH * OW; a.K = k * k * Cin; a.act = act; a.out_f32 = 0; a.variant = variant; a.zeros = dzero.as<uint16_t>();
+    ISB_TRY(launch_conv_igemm(a, nullptr));       // warm-up + result
+    ISB_HIP(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    ISB_HIP(hipEventCreate(&e0));
+    ISB_HIP(hipEventCreate(&e1));
+    ISB_HIP(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters; ++i) ISB_TRY(launch_conv_igemm(a, nullptr));
+    ISB_HIP(hipEventRecord(e1, nullptr));
+    ISB_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    ISB_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_per_iter = ms / iters;
+    ISB_HIP(hipMemcpy(out, dout.p, nout * 2, hipMemcpyDeviceToHost));
+    return ISB_OK;
 }

@@ -121,6 +121,8 @@ struct ConvArgs {
     int M, K;
     int act;                // 1 = SiLU
     int out_f32;
+    int variant;            // tile variant, 0 = choose by Cout (conv_kernels.hip)
+    const uint16_t* zeros;  // >= 16 bytes of zeros (source of padding taps for the LDS-DMA kernels)
 };
 int launch_conv_igemm(const ConvArgs& a, hipStream_t st);
 

@@ -136,6 +136,34 @@ class HpeEngine:
         return ms.value, n.value
 
 
+def f32_to_bf16(a: np.ndarray) -> np.ndarray:
+    """round-to-nearest-even f32 -> bf16 bit patterns (uint16)"""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+def bf16_to_f32(a: np.ndarray) -> np.ndarray:
+    return (np.ascontiguousarray(a, dtype=np.uint16).astype(np.uint32) << 16).view(np.float32)
+
+
+def conv_debug(x_bf16, w, scale, shift, k, stride, act, res_bf16=None, gate=None, variant=0, iters=1, device=0):
+    """One backbone convolution through isb_debug_conv. x_bf16 uint16 [B,H,W,Cin] (bf16 bits),
+    w f32 [Cout,k,k,Cin]. Returns (out uint16 [B,OH,OW,Cout], ms_per_launch)."""
+    x = np.ascontiguousarray(x_bf16, dtype=np.uint16)
+    B, H, W, Cin = x.shape
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    Cout = w.shape[0]
+    out = np.empty((B, H // stride, W // stride, Cout), np.uint16)
+    ms = C.c_float()
+    r = None if res_bf16 is None else np.ascontiguousarray(res_bf16, dtype=np.uint16)
+    g = None if gate is None else np.ascontiguousarray(gate, dtype=np.float32)
+    _lib.check(_lib.lib().isb_debug_conv(device, _ptr(x), _ptr(w), _ptr(np.ascontiguousarray(scale, dtype=np.float32)),
+                                         _ptr(np.ascontiguousarray(shift, dtype=np.float32)), _ptr(r), _ptr(g),
+                                         B, H, W, Cin, Cout, k, stride, int(act), variant, iters, _ptr(out), C.byref(ms)),
+               "isb_debug_conv")
+    return out, ms.value
+
+
 def pose_windows(joints, seq_len: int):
     """joints torch CUDA f32 [n_cam, n_frames, J, 3] -> windows [n_cam*(n_frames-L+1), L, 3J]
     (root-centred on joint 0, main.py:103; window assembly, ar.py:42-50)."""

@@ -1,0 +1,68 @@
+"""GPU unit tests of the conv_igemm kernel family (every tile variant) against a torch-CPU conv on
+the same bf16-rounded operands: 3x3 / 1x1, stride 1 / 2 (TF SAME), SiLU, residual, SE gate."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from isbfsar_amd.hpe_engine import bf16_to_f32, conv_debug, f32_to_bf16
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(x, w, scale, shift, k, stride, act, res, gate):
+    xb = torch.from_numpy(bf16_to_f32(f32_to_bf16(x)))                       # [B,H,W,Cin]
+    if gate is not None:
+        xb = (xb * torch.from_numpy(gate)[:, None, None, :]).bfloat16().float()
+    wf = (torch.from_numpy(w) * torch.from_numpy(scale).view(-1, 1, 1, 1)).bfloat16().float()
+    xi = xb.permute(0, 3, 1, 2)
+    wi = wf.permute(0, 3, 1, 2)
+    if k == 3 and stride == 2:
+        y = F.conv2d(F.pad(xi, (0, 1, 0, 1)), wi, stride=2)
+    elif k == 3:
+        y = F.conv2d(xi, wi, padding=1)
+    else:
+        y = F.conv2d(xi, wi, stride=stride)
+    y = y + torch.from_numpy(shift).view(1, -1, 1, 1)
+    if act:
+        y = y * torch.sigmoid(y)
+    y = y.permute(0, 2, 3, 1)
+    if res is not None:
+        y = y + torch.from_numpy(bf16_to_f32(f32_to_bf16(res)))
+    return y.bfloat16().float().numpy()
+
+
+CASES = [
+    # B, H, Cin, Cout, k, stride, act, res, gate
+    (2, 16, 64, 128, 3, 1, 1, False, False),
+    (2, 16, 32, 128, 3, 2, 1, False, False),
+    (3, 8, 96, 96, 1, 1, 0, True, True),
+    (2, 16, 64, 224, 1, 1, 0, True, True),
+    (2, 16, 32, 32, 3, 1, 1, True, False),
+    (1, 16, 128, 64, 1, 1, 0, False, False),
+    (2, 8, 192, 256, 1, 1, 1, False, False),
+]
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 13, 14, 15, 16, 17, 18, 19, 21, 23, 26, 27, 28])
+@pytest.mark.parametrize("case", CASES)
+def test_conv_variants(case, variant):
+    B, H, Cin, Cout, k, stride, act, use_res, use_gate = case
+    if variant > 10 and use_gate:
+        pytest.skip("the LDS-DMA kernels take no SE gate")
+    rng = np.random.default_rng(hash((case, 7)) % (2 ** 31))
+    x = rng.normal(0, 1, (B, H, H, Cin)).astype(np.float32)
+    w = (rng.normal(0, 1, (Cout, k, k, Cin)) / np.sqrt(k * k * Cin)).astype(np.float32)
+    scale = rng.uniform(0.8, 1.2, Cout).astype(np.float32)
+    shift = rng.uniform(-0.1, 0.1, Cout).astype(np.float32)
+    OH = H // stride
+    res = rng.normal(0, 1, (B, OH, OH, Cout)).astype(np.float32) if use_res else None
+    gate = rng.uniform(0.1, 0.9, (B, Cin)).astype(np.float32) if use_gate else None
+    out, ms = conv_debug(f32_to_bf16(x), w, scale, shift, k, stride, act,
+                         None if res is None else f32_to_bf16(res), gate, variant=variant)
+    got = bf16_to_f32(out)
+    ref = _ref(x, w, scale, shift, k, stride, act, res, gate)
+    # both sides round to bf16 once; accumulation order differs -> at most 1 bf16 ulp apart
+    tol = 2.0 ** -7 * np.maximum(1.0, np.abs(ref))
+    assert np.all(np.abs(got - ref) <= tol), float(np.abs(got - ref).max())
+    assert ms >= 0
