@@ -145,6 +145,17 @@ int isb_hpe_forward(isb_hpe* h, const uint8_t* d_frames, const int32_t* d_bbox, 
 int isb_hpe_forward_host(isb_hpe* h, const uint8_t* h_frames, const int32_t* h_bbox, int32_t B, float* h_joints,
                          uint8_t* h_valid);
 
+/* detector post-processing, hpe.py:59-79 + misc.py:64-107: YOLOv4 export tensors
+ *   d_boxes [B,4032,1,4] f32 (x1,y1,x2,y2 normalised), d_confs [B,4032,80] f32
+ * -> d_bbox [B,4] i32 (x1,x2,y1,y2) of the most confident anchor whose arg-max class is 0 (person)
+ * and whose confidence exceeds conf_thresh (MetrabsTRTConfig.yolo_thresh, utils/params.py:34), or
+ * (-1,-1,-1,-1); d_found [B] u8 (may be NULL). The NMS of the reference cannot change this winner.
+ * A (-1,...) box makes isb_hpe_forward report valid = 0 for that frame (estimate() -> None). */
+int isb_hpe_select_person(isb_hpe* h, const float* d_boxes, const float* d_confs, int32_t B, float conf_thresh,
+                          int32_t* d_bbox, uint8_t* d_found, void* stream);
+int isb_hpe_select_person_host(isb_hpe* h, const float* h_boxes, const float* h_confs, int32_t B, float conf_thresh,
+                               int32_t* h_bbox, uint8_t* h_found);
+
 /* stage-level entry points (host buffers, synchronous, B <= max_batch): each stage can be pinned
  * against the oracle on its own.
  *   crop_params : misc.homography + hpe.py:96       -> H f32 [B,9], new_K f64 [B,9], R f64 [B,9]

@@ -88,6 +88,7 @@ int project(isb_ar* h, hipStream_t st, const float* d_feat, int items, float* d_
 }  // namespace
 
 extern "C" int isb_ar_create(const isb_ar_cfg* cfg, isb_ar** out) {
+    return isb::guard([&]() -> int {
     ISB_REQUIRE(cfg && out, ISB_ERR_INVALID, "isb_ar_create: null argument");
     ISB_REQUIRE(cfg->seq_len >= 2 && cfg->seq_len <= 64, ISB_ERR_INVALID, "seq_len %d outside [2,64]", cfg->seq_len);
     ISB_REQUIRE(cfg->n_joints >= 1 && cfg->n_joints <= 1024, ISB_ERR_INVALID, "n_joints %d outside [1,1024]", cfg->n_joints);
@@ -113,6 +114,7 @@ extern "C" int isb_ar_create(const isb_ar_cfg* cfg, isb_ar** out) {
     ISB_HIP(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     *out = h.release();
     return ISB_OK;
+    });
 }
 
 extern "C" void isb_ar_destroy(isb_ar* h) {
@@ -128,6 +130,7 @@ extern "C" void isb_ar_destroy(isb_ar* h) {
 }
 
 extern "C" int isb_ar_load_weights(isb_ar* h, const void* blob, size_t nbytes) {
+    return isb::guard([&]() -> int {
     ISB_REQUIRE(h, ISB_ERR_INVALID, "null handle");
     ISB_HIP(hipSetDevice(h->cfg.device));
     std::map<std::string, BlobTensor> m;
@@ -217,9 +220,11 @@ extern "C" int isb_ar_load_weights(isb_ar* h, const void* blob, size_t nbytes) {
     h->weights = true;
     h->support = false;
     return ISB_OK;
+    });
 }
 
 extern "C" int isb_ar_set_support(isb_ar* h, const float* poses, const float* features, int32_t n) {
+    return isb::guard([&]() -> int {
     ISB_REQUIRE(h, ISB_ERR_INVALID, "null handle");
     ISB_REQUIRE(h->weights, ISB_ERR_STATE, "isb_ar_set_support before isb_ar_load_weights");
     ISB_REQUIRE((poses != nullptr) != (features != nullptr), ISB_ERR_INVALID,
@@ -265,18 +270,22 @@ extern "C" int isb_ar_set_support(isb_ar* h, const float* poses, const float* fe
     h->n = n;
     h->support = true;
     return ISB_OK;
+    });
 }
 
 extern "C" int isb_ar_get_support_features(isb_ar* h, float* out) {
+    return isb::guard([&]() -> int {
     ISB_REQUIRE(h && out, ISB_ERR_INVALID, "null argument");
     ISB_REQUIRE(h->support, ISB_ERR_STATE, "no support set installed");
     ISB_HIP(hipSetDevice(h->cfg.device));
     ISB_HIP(hipMemcpy(out, h->s_feat.p, (size_t)h->n * h->L * 256 * 4, hipMemcpyDeviceToHost));
     return ISB_OK;
+    });
 }
 
 extern "C" int isb_ar_infer(isb_ar* h, const float* d_windows, int32_t B, float* d_logits, float* d_is_true,
                             float* d_embed, void* stream) {
+    return isb::guard([&]() -> int {
     ISB_REQUIRE(h && d_windows && d_logits && d_is_true, ISB_ERR_INVALID, "null argument");
     ISB_REQUIRE(B >= 1, ISB_ERR_INVALID, "batch %d < 1", B);
     ISB_REQUIRE(h->weights && h->support, ISB_ERR_STATE, "isb_ar_infer needs weights and a support set");
@@ -360,10 +369,12 @@ extern "C" int isb_ar_infer(isb_ar* h, const float* d_windows, int32_t B, float*
         ISB_TRY(launch_ar_disc_tail(da, st));
     }
     return ISB_OK;
+    });
 }
 
 extern "C" int isb_ar_infer_host(isb_ar* h, const float* windows, int32_t B, float* logits, float* is_true,
                                  float* embed) {
+    return isb::guard([&]() -> int {
     ISB_REQUIRE(h && windows && logits && is_true, ISB_ERR_INVALID, "null argument");
     ISB_REQUIRE(B >= 1, ISB_ERR_INVALID, "batch %d < 1", B);
     ISB_REQUIRE(h->weights && h->support, ISB_ERR_STATE, "isb_ar_infer_host needs weights and a support set");
@@ -382,24 +393,30 @@ extern "C" int isb_ar_infer_host(isb_ar* h, const float* windows, int32_t B, flo
     if (embed) ISB_HIP(hipMemcpyAsync(embed, de.p, (size_t)B * h->L * 256 * 4, hipMemcpyDeviceToHost, st));
     ISB_HIP(hipStreamSynchronize(st));
     return ISB_OK;
+    });
 }
 
 extern "C" int isb_ar_last_chosen(isb_ar* h, int32_t* out, int32_t B) {
+    return isb::guard([&]() -> int {
     ISB_REQUIRE(h && out, ISB_ERR_INVALID, "null argument");
     ISB_REQUIRE(B >= 1 && B <= h->chosen_cap, ISB_ERR_INVALID, "B %d exceeds last batch %d", B, h->chosen_cap);
     ISB_HIP(hipSetDevice(h->cfg.device));
     ISB_HIP(hipDeviceSynchronize());
     ISB_HIP(hipMemcpy(out, h->chosen.p, (size_t)B * 4, hipMemcpyDeviceToHost));
     return ISB_OK;
+    });
 }
 
 extern "C" int isb_ar_profile(isb_ar* h, int32_t enable) {
+    return isb::guard([&]() -> int {
     ISB_REQUIRE(h, ISB_ERR_INVALID, "null handle");
     h->prof = enable != 0;
     return ISB_OK;
+    });
 }
 
 extern "C" int isb_ar_profile_read(isb_ar* h, double* ms_total, int64_t* launches) {
+    return isb::guard([&]() -> int {
     ISB_REQUIRE(h && ms_total && launches, ISB_ERR_INVALID, "null argument");
     ISB_HIP(hipSetDevice(h->cfg.device));
     for (auto& e : h->prof_ev) {
@@ -416,4 +433,5 @@ extern "C" int isb_ar_profile_read(isb_ar* h, double* ms_total, int64_t* launche
     h->prof_ms = 0.0;
     h->prof_launches = 0;
     return ISB_OK;
+    });
 }

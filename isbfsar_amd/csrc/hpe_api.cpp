@@ -181,8 +181,10 @@ int run_backbone(isb_hpe* h, hipStream_t st, const float* crops, int B) {
     return ISB_OK;
 }
 
-int run_post(isb_hpe* h, hipStream_t st, const float* logits, int B, float* joints, uint8_t* valid, double* dbg) {
+int run_post(isb_hpe* h, hipStream_t st, const float* logits, int B, float* joints, uint8_t* valid, double* dbg,
+             const int32_t* bbox = nullptr) {
     PostArgs a{};
+    a.bbox = bbox;
     a.logits = logits; a.newK = h->newK.as<double>(); a.R = h->R.as<double>(); a.expand = h->expand.as<float>();
     a.indices = h->has_indices ? h->indices.as<int32_t>() : nullptr;
     a.joints = joints; a.valid = valid; a.dbg = dbg; a.B = B; a.n_out = h->n_out;
@@ -207,6 +209,7 @@ int run_warp(isb_hpe* h, hipStream_t st, const uint8_t* d_frames, int B) {
 }  // namespace
 
 extern "C" int isb_hpe_create(const isb_hpe_cfg* cfg, isb_hpe** out) {
+    return isb::guard([&]() -> int {
     ISB_REQUIRE(cfg && out, ISB_ERR_INVALID, "isb_hpe_create: null argument");
     ISB_REQUIRE(cfg->width >= 16 && cfg->height >= 16 && cfg->width <= 8192 && cfg->height <= 8192, ISB_ERR_INVALID,
                 "frame size %dx%d unsupported", cfg->width, cfg->height);
@@ -226,6 +229,7 @@ extern "C" int isb_hpe_create(const isb_hpe_cfg* cfg, isb_hpe** out) {
     ISB_HIP(hipMemset(h->zeros.p, 0, 256));
     *out = h.release();
     return ISB_OK;
+    });
 }
 
 extern "C" void isb_hpe_destroy(isb_hpe* h) {
@@ -241,6 +245,7 @@ extern "C" void isb_hpe_destroy(isb_hpe* h) {
 }
 
 extern "C" int isb_hpe_load_weights(isb_hpe* h, const void* blob, size_t nbytes) {
+    return isb::guard([&]() -> int {
     ISB_REQUIRE(h, ISB_ERR_INVALID, "null handle");
     ISB_HIP(hipSetDevice(h->cfg.device));
     hipStream_t st = h->own_stream;
@@ -323,9 +328,11 @@ extern "C" int isb_hpe_load_weights(isb_hpe* h, const void* blob, size_t nbytes)
     ISB_TRY(upload(h->head_b, hb->data, 288 * 4));
     h->weights = true;
     return ISB_OK;
+    });
 }
 
 extern "C" int isb_hpe_set_joint_map(isb_hpe* h, const float* expand, const int32_t* indices, int32_t n_out) {
+    return isb::guard([&]() -> int {
     ISB_REQUIRE(h && expand, ISB_ERR_INVALID, "null argument");
     ISB_REQUIRE(n_out >= 1 && n_out <= 122, ISB_ERR_INVALID, "n_out %d outside [1,122]", n_out);
     ISB_REQUIRE(indices || n_out == 122, ISB_ERR_INVALID, "without indices n_out must be 122");
@@ -339,10 +346,12 @@ extern "C" int isb_hpe_set_joint_map(isb_hpe* h, const float* expand, const int3
     h->n_out = n_out;
     h->jointmap = true;
     return ISB_OK;
+    });
 }
 
 extern "C" int isb_hpe_forward(isb_hpe* h, const uint8_t* d_frames, const int32_t* d_bbox, int32_t B, float* d_joints,
                                uint8_t* d_valid, void* stream) {
+    return isb::guard([&]() -> int {
     ISB_REQUIRE(h && d_frames && d_bbox && d_joints && d_valid, ISB_ERR_INVALID, "null argument");
     ISB_REQUIRE(B >= 1, ISB_ERR_INVALID, "batch %d < 1", B);
     ISB_REQUIRE(h->weights && h->jointmap, ISB_ERR_STATE, "isb_hpe_forward needs weights and a joint map");
@@ -356,13 +365,16 @@ extern "C" int isb_hpe_forward(isb_hpe* h, const uint8_t* d_frames, const int32_
         ISB_TRY(run_crop_params(h, st, d_bbox + (size_t)b0 * 4, Bm));
         ISB_TRY(run_warp(h, st, d_frames + (size_t)b0 * fsz, Bm));
         ISB_TRY(run_backbone(h, st, h->crops.as<float>(), Bm));
-        ISB_TRY(run_post(h, st, h->logits.as<float>(), Bm, d_joints + (size_t)b0 * h->n_out * 3, d_valid + b0, nullptr));
+        ISB_TRY(run_post(h, st, h->logits.as<float>(), Bm, d_joints + (size_t)b0 * h->n_out * 3, d_valid + b0, nullptr,
+                         d_bbox + (size_t)b0 * 4));
     }
     return ISB_OK;
+    });
 }
 
 extern "C" int isb_hpe_forward_host(isb_hpe* h, const uint8_t* frames, const int32_t* bbox, int32_t B, float* joints,
                                     uint8_t* valid) {
+    return isb::guard([&]() -> int {
     ISB_REQUIRE(h && frames && bbox && joints && valid, ISB_ERR_INVALID, "null argument");
     ISB_REQUIRE(B >= 1, ISB_ERR_INVALID, "batch %d < 1", B);
     ISB_REQUIRE(h->weights && h->jointmap, ISB_ERR_STATE, "isb_hpe_forward_host needs weights and a joint map");
@@ -381,10 +393,12 @@ extern "C" int isb_hpe_forward_host(isb_hpe* h, const uint8_t* frames, const int
     ISB_HIP(hipMemcpyAsync(valid, dv.p, (size_t)B, hipMemcpyDeviceToHost, st));
     ISB_HIP(hipStreamSynchronize(st));
     return ISB_OK;
+    });
 }
 
 // ---------------------------------------------------------------- stage-level hooks (tests)
 extern "C" int isb_hpe_crop_params_host(isb_hpe* h, const int32_t* bbox, int32_t B, float* H, double* newK, double* R) {
+    return isb::guard([&]() -> int {
     ISB_REQUIRE(h && bbox && H && newK && R && B >= 1, ISB_ERR_INVALID, "bad argument");
     ISB_HIP(hipSetDevice(h->cfg.device));
     hipStream_t st = h->own_stream;
@@ -398,9 +412,11 @@ extern "C" int isb_hpe_crop_params_host(isb_hpe* h, const int32_t* bbox, int32_t
     ISB_HIP(hipMemcpy(newK, h->newK.p, (size_t)B * 72, hipMemcpyDeviceToHost));
     ISB_HIP(hipMemcpy(R, h->R.p, (size_t)B * 72, hipMemcpyDeviceToHost));
     return ISB_OK;
+    });
 }
 
 extern "C" int isb_hpe_warp_host(isb_hpe* h, const uint8_t* frames, const int32_t* bbox, int32_t B, float* crops) {
+    return isb::guard([&]() -> int {
     ISB_REQUIRE(h && frames && bbox && crops && B >= 1, ISB_ERR_INVALID, "bad argument");
     ISB_HIP(hipSetDevice(h->cfg.device));
     hipStream_t st = h->own_stream;
@@ -415,9 +431,11 @@ extern "C" int isb_hpe_warp_host(isb_hpe* h, const uint8_t* frames, const int32_
     ISB_HIP(hipStreamSynchronize(st));
     ISB_HIP(hipMemcpy(crops, h->crops.p, (size_t)B * 256 * 256 * 3 * 4, hipMemcpyDeviceToHost));
     return ISB_OK;
+    });
 }
 
 extern "C" int isb_hpe_backbone_host(isb_hpe* h, const float* crops, int32_t B, float* features, float* logits) {
+    return isb::guard([&]() -> int {
     ISB_REQUIRE(h && crops && B >= 1, ISB_ERR_INVALID, "bad argument");
     ISB_REQUIRE(h->weights, ISB_ERR_STATE, "isb_hpe_backbone_host before isb_hpe_load_weights");
     ISB_HIP(hipSetDevice(h->cfg.device));
@@ -430,10 +448,12 @@ extern "C" int isb_hpe_backbone_host(isb_hpe* h, const float* crops, int32_t B, 
     if (features) ISB_HIP(hipMemcpy(features, h->feat.p, (size_t)B * 64 * 1280 * 4, hipMemcpyDeviceToHost));
     if (logits) ISB_HIP(hipMemcpy(logits, h->logits.p, (size_t)B * 64 * 288 * 4, hipMemcpyDeviceToHost));
     return ISB_OK;
+    });
 }
 
 extern "C" int isb_hpe_post_host(isb_hpe* h, const float* logits, const int32_t* bbox, int32_t B, float* joints,
                                  uint8_t* valid, double* pred) {
+    return isb::guard([&]() -> int {
     ISB_REQUIRE(h && logits && bbox && joints && valid && B >= 1, ISB_ERR_INVALID, "bad argument");
     ISB_REQUIRE(h->jointmap, ISB_ERR_STATE, "isb_hpe_post_host before isb_hpe_set_joint_map");
     ISB_HIP(hipSetDevice(h->cfg.device));
@@ -453,15 +473,19 @@ extern "C" int isb_hpe_post_host(isb_hpe* h, const float* logits, const int32_t*
     ISB_HIP(hipMemcpy(valid, dv.p, (size_t)B, hipMemcpyDeviceToHost));
     if (pred) ISB_HIP(hipMemcpy(pred, dd.p, (size_t)B * 32 * 5 * 8, hipMemcpyDeviceToHost));
     return ISB_OK;
+    });
 }
 
 extern "C" int isb_hpe_profile(isb_hpe* h, int32_t enable) {
+    return isb::guard([&]() -> int {
     ISB_REQUIRE(h, ISB_ERR_INVALID, "null handle");
     h->prof = enable != 0;
     return ISB_OK;
+    });
 }
 
 extern "C" int isb_hpe_profile_read(isb_hpe* h, double* ms_total, int64_t* launches) {
+    return isb::guard([&]() -> int {
     ISB_REQUIRE(h && ms_total && launches, ISB_ERR_INVALID, "null argument");
     ISB_HIP(hipSetDevice(h->cfg.device));
     for (auto& e : h->prof_ev) {
@@ -478,14 +502,17 @@ extern "C" int isb_hpe_profile_read(isb_hpe* h, double* ms_total, int64_t* launc
     h->prof_ms = 0.0;
     h->prof_launches = 0;
     return ISB_OK;
+    });
 }
 
 extern "C" int isb_pose_windows(const float* d_joints, int32_t n_cam, int32_t n_frames, int32_t J, int32_t L,
                                 float* d_windows, void* stream) {
+    return isb::guard([&]() -> int {
     ISB_REQUIRE(d_joints && d_windows, ISB_ERR_INVALID, "null argument");
     ISB_REQUIRE(n_cam >= 1 && J >= 1 && L >= 1 && n_frames >= L, ISB_ERR_INVALID,
                 "bad shape n_cam=%d n_frames=%d J=%d L=%d", n_cam, n_frames, J, L);
     return launch_pose_windows(d_joints, n_cam, n_frames, J, L, d_windows, (hipStream_t)stream);
+    });
 }
 
 // test / tuning hook: one conv_igemm layer on host tensors, timed with HIP events
@@ -493,6 +520,7 @@ extern "C" int isb_debug_conv(int32_t device, const uint16_t* x, const float* w,
                               const uint16_t* res, const float* gate, int32_t B, int32_t H, int32_t W, int32_t Cin,
                               int32_t Cout, int32_t k, int32_t stride, int32_t act, int32_t variant, int32_t iters,
                               uint16_t* out, float* ms_per_iter) {
+    return isb::guard([&]() -> int {
     ISB_REQUIRE(x && w && scale && shift && out && ms_per_iter, ISB_ERR_INVALID, "null argument");
     ISB_REQUIRE((k == 1 || k == 3) && (stride == 1 || stride == 2) && iters >= 1, ISB_ERR_INVALID, "bad conv parameters");
     ISB_HIP(hipSetDevice(device));
@@ -531,4 +559,34 @@ extern "C" int isb_debug_conv(int32_t device, const uint16_t* x, const float* w,
     *ms_per_iter = ms / iters;
     ISB_HIP(hipMemcpy(out, dout.p, nout * 2, hipMemcpyDeviceToHost));
     return ISB_OK;
+    });
+}
+
+extern "C" int isb_hpe_select_person(isb_hpe* h, const float* d_boxes, const float* d_confs, int32_t B, float conf_thresh,
+                                     int32_t* d_bbox, uint8_t* d_found, void* stream) {
+    return isb::guard([&]() -> int {
+        ISB_REQUIRE(h && d_boxes && d_confs && d_bbox && B >= 1, ISB_ERR_INVALID, "bad argument");
+        ISB_HIP(hipSetDevice(h->cfg.device));
+        return launch_select_person(d_boxes, d_confs, B, 4032, 80, conf_thresh, h->cfg.width, h->cfg.height, d_bbox, d_found,
+                                    (hipStream_t)stream);
+    });
+}
+
+extern "C" int isb_hpe_select_person_host(isb_hpe* h, const float* boxes, const float* confs, int32_t B, float conf_thresh,
+                                          int32_t* bbox, uint8_t* found) {
+    return isb::guard([&]() -> int {
+        ISB_REQUIRE(h && boxes && confs && bbox && found && B >= 1, ISB_ERR_INVALID, "bad argument");
+        ISB_HIP(hipSetDevice(h->cfg.device));
+        DevBuf db, dc, dbb, df;
+        ISB_TRY(upload(db, boxes, (size_t)B * 4032 * 4 * 4));
+        ISB_TRY(upload(dc, confs, (size_t)B * 4032 * 80 * 4));
+        ISB_TRY(dbb.alloc((size_t)B * 16));
+        ISB_TRY(df.alloc((size_t)B));
+        ISB_TRY(launch_select_person(db.as<float>(), dc.as<float>(), B, 4032, 80, conf_thresh, h->cfg.width, h->cfg.height,
+                                     dbb.as<int32_t>(), df.as<uint8_t>(), h->own_stream));
+        ISB_HIP(hipStreamSynchronize(h->own_stream));
+        ISB_HIP(hipMemcpy(bbox, dbb.p, (size_t)B * 16, hipMemcpyDeviceToHost));
+        ISB_HIP(hipMemcpy(found, df.p, (size_t)B, hipMemcpyDeviceToHost));
+        return ISB_OK;
+    });
 }

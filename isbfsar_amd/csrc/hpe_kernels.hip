@@ -33,7 +33,9 @@ __device__ __forceinline__ void mat3_inv(const double* m, double* o) {
 __global__ void crop_params_kernel(CropParamArgs p) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= p.B) return;
-    const double x1 = p.bbox[4 * b + 0], x2 = p.bbox[4 * b + 1], y1 = p.bbox[4 * b + 2], y2 = p.bbox[4 * b + 3];
+    const bool nobox = p.bbox[4 * b] < 0;               // select_person found nobody: keep the math finite
+    const double x1 = nobox ? 0 : p.bbox[4 * b + 0], x2 = nobox ? 1 : p.bbox[4 * b + 1];
+    const double y1 = nobox ? 0 : p.bbox[4 * b + 2], y2 = nobox ? 1 : p.bbox[4 * b + 3];
     const double* K = p.K;
     // numpy inverts the float32 K in float32 (one correctly rounded division per entry)
     const float fx = (float)K[0], fy = (float)K[4], cx = (float)K[2], cy = (float)K[5];
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(64) void hpe_post_kernel(PostArgs p) {
     const bool infov = x2 >= 18.0 && x2 <= 238.0 && y2 >= 18.0 && y2 <= 238.0;
     const unsigned long long bal = __ballot(infov && half == 0);
     const int nvis = __popcll(bal);
-    const bool ok = nvis >= 8;
+    const bool ok = nvis >= 8 && !(p.bbox && p.bbox[4 * b] < 0);
     if (lane == 0) p.valid[b] = ok ? 1 : 0;
 
     // reconstruct_absolute (misc.py:183-204): inverse of new_K.astype(float32) in float32
@@ -265,6 +267,62 @@ __global__ __launch_bounds__(64) void hpe_post_kernel(PostArgs p) {
 int launch_hpe_post(const PostArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(hpe_post_kernel, dim3(a.B), dim3(64), 0, st, a);
     ISB_LAUNCHED("hpe_post", st);
+    return ISB_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// select_person: detector post-processing reduced to what estimate() consumes (hpe.py:59-79).
+// The reference thresholds the per-anchor max class confidence, keeps class 0 (person), runs NMS
+// (misc.py:27-107) and then takes the most confident survivor -- which NMS can never remove (it is
+// the first box NMS keeps), so the result is the arg-max-confidence person anchor. One WG per frame.
+// bbox out = (x1, x2, y1, y2) = int(coord * size) clamped at 0, float32 product like numpy 2;
+// (-1,-1,-1,-1) when no person is found (estimate() returns None, hpe.py:72-73).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void select_person_kernel(const float* boxes, const float* confs, int n_anchor, int n_cls, float thresh,
+                                                            int width, int height, int32_t* bbox, uint8_t* found) {
+    __shared__ float sc[256];
+    __shared__ int si[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float best = -1.f;
+    int besti = -1;
+    for (int a = tid; a < n_anchor; a += 256) {
+        const float* c = confs + ((size_t)b * n_anchor + a) * n_cls;
+        float mx = c[0];
+        int id = 0;
+        for (int k = 1; k < n_cls; ++k)
+            if (c[k] > mx) { mx = c[k]; id = k; }          // np.argmax: first maximum
+        if (id == 0 && mx > thresh && mx > best) { best = mx; besti = a; }
+    }
+    sc[tid] = best; si[tid] = besti;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if (tid < s) {
+            const float o = sc[tid + s];
+            const int oi = si[tid + s];
+            if (oi >= 0 && (si[tid] < 0 || o > sc[tid] || (o == sc[tid] && oi < si[tid]))) { sc[tid] = o; si[tid] = oi; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const int a = si[0];
+        int32_t* o = bbox + 4 * b;
+        if (a < 0) {
+            o[0] = o[1] = o[2] = o[3] = -1;
+            if (found) found[b] = 0;
+        } else {
+            const float* bx = boxes + ((size_t)b * n_anchor + a) * 4;
+            const int x1 = (int)__fmul_rn(bx[0], (float)width), y1 = (int)__fmul_rn(bx[1], (float)height);
+            const int x2 = (int)__fmul_rn(bx[2], (float)width), y2 = (int)__fmul_rn(bx[3], (float)height);
+            o[0] = x1 > 0 ? x1 : 0; o[1] = x2 > 0 ? x2 : 0; o[2] = y1 > 0 ? y1 : 0; o[3] = y2 > 0 ? y2 : 0;
+            if (found) found[b] = 1;
+        }
+    }
+}
+
+int launch_select_person(const float* boxes, const float* confs, int B, int n_anchor, int n_cls, float thresh, int width, int height,
+                         int32_t* bbox, uint8_t* found, hipStream_t st) {
+    hipLaunchKernelGGL(select_person_kernel, dim3(B), dim3(256), 0, st, boxes, confs, n_anchor, n_cls, thresh, width, height, bbox, found);
+    ISB_LAUNCHED("select_person", st);
     return ISB_OK;
 }
 

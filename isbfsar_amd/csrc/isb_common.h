@@ -7,7 +7,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <map>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -93,6 +95,23 @@ inline int upload(DevBuf& b, const void* src, size_t n) {
 // and report it by name (debugging aid: pins an asynchronous fault to the launch that caused it).
 int post_launch(const char* what, hipStream_t st);
 #define ISB_LAUNCHED(what, st) ISB_TRY(isb::post_launch(what, st))
+
+// No C++ exception may cross the C ABI: every extern "C" entry point runs its body through guard().
+template <class F>
+int guard(F&& f) noexcept {
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        set_error("out of host memory");
+        return ISB_ERR_NOMEM;
+    } catch (const std::exception& e) {
+        set_error("internal error: %s", e.what());
+        return ISB_ERR_INVALID;
+    } catch (...) {
+        set_error("internal error (unknown exception)");
+        return ISB_ERR_INVALID;
+    }
+}
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t cdivz(size_t a, size_t b) { return (a + b - 1) / b; }

@@ -186,9 +186,12 @@ struct PostArgs {
     float* joints;          // out [B,n_out,3]
     uint8_t* valid;         // out [B]
     double* dbg;            // optional [B,32,5] pred2d(2) pred3d(3) or null
+    const int32_t* bbox;    // optional [B,4]: x1 < 0 marks 'no person' -> valid = 0
     int B, n_out;
 };
 int launch_hpe_post(const PostArgs& a, hipStream_t st);
+int launch_select_person(const float* boxes, const float* confs, int B, int n_anchor, int n_cls, float thresh, int width, int height,
+                         int32_t* bbox, uint8_t* found, hipStream_t st);
 int launch_pose_windows(const float* joints, int n_cam, int n_frames, int J, int L, float* windows, hipStream_t st);
 
 }  // namespace isb

@@ -126,6 +126,17 @@ class HpeEngine:
                    "isb_hpe_post_host")
         return joints, valid, pred
 
+    def select_person(self, boxes, confs, conf_thresh: float = 0.3):
+        """YOLOv4 export tensors (numpy) -> (bbox int32 [B,4] as x1,x2,y1,y2 or -1s, found u8 [B])."""
+        bx = np.ascontiguousarray(boxes, dtype=np.float32).reshape(-1, 4032, 4)
+        cf = np.ascontiguousarray(confs, dtype=np.float32).reshape(-1, 4032, 80)
+        B = bx.shape[0]
+        bbox = np.empty((B, 4), np.int32)
+        found = np.empty((B,), np.uint8)
+        _lib.check(_lib.lib().isb_hpe_select_person_host(self._h, _ptr(bx), _ptr(cf), B, conf_thresh, _ptr(bbox), _ptr(found)),
+                   "isb_hpe_select_person_host")
+        return bbox, found
+
     def profile(self, enable: bool):
         _lib.check(_lib.lib().isb_hpe_profile(self._h, int(enable)), "isb_hpe_profile")
 

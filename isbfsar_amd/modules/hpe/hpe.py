@@ -6,9 +6,10 @@ and the per-frame consumer (``main.py:77-105``) run unmodified:
     estimate(frame uint8[480,640,3] BGR) -> None | {"pose": float64[n,3], "edges": [...], "bbox": (x1,x2,y1,y2)}
     just_box mode                         -> {"bbox": (x1,y1,x2,y2)}            (hpe.py:82-83)
 
-The YOLOv4 detector (hpe.py:51-73) is out of scope for this round: the person box
-comes from ``bbox_provider(frame) -> (x1,x2,y1,y2) | None`` (default: ``model_config.fixed_bbox``
-or the whole frame). Everything after the box runs on the GPU; there is no CPU path.
+The YOLOv4 network itself (hpe.py:51-59, an un-vendored engine) is not part of this build: pass
+``detector(frame) -> (boxes, confs)`` (the YOLO export tensors; their post-processing, hpe.py:60-79,
+runs on the GPU) or ``bbox_provider(frame) -> (x1,x2,y1,y2) | None`` (default:
+``model_config.fixed_bbox`` or the whole frame). Everything after that runs on the GPU; no CPU path.
 """
 from __future__ import annotations
 
@@ -20,7 +21,7 @@ from ...weights import unpack_blob
 
 
 class HumanPoseEstimator:
-    def __init__(self, model_config, cam_config, just_box=None, bbox_provider=None):
+    def __init__(self, model_config, cam_config, just_box=None, bbox_provider=None, detector=None):
         if just_box is None:
             self.just_box = model_config.just_box
         else:
@@ -44,10 +45,11 @@ class HumanPoseEstimator:
         self.expand_joints, indices, self.edges = load_joint_assets(
             model_config.expand_joints_path, model_config.skeleton_types_path, self.skeleton)
         self.bbox_provider = bbox_provider
+        self.detector = detector          # callable(frame) -> (boxes [1,4032,1,4], confs [1,4032,80]) like Runner(yolo)
         self.fixed_bbox = getattr(model_config, "fixed_bbox", None)
 
         self.engine = None
-        if not self.just_box:
+        if not self.just_box or self.detector is not None:
             self.engine = HpeEngine(cam_config.fx, cam_config.fy, cam_config.ppx, cam_config.ppy,
                                     cam_config.width, cam_config.height,
                                     device=getattr(model_config, "device", 0),
@@ -62,6 +64,10 @@ class HumanPoseEstimator:
             self.engine.set_joint_map(self.expand_joints, indices)
 
     def _bbox(self, frame):
+        if self.detector is not None:                     # hpe.py:59-73, post-processing on the GPU
+            boxes, confs = self.detector(frame)
+            bbox, found = self.engine.select_person(boxes, confs, self.yolo_thresh)
+            return tuple(int(v) for v in bbox[0]) if found[0] else None
         if self.bbox_provider is not None:
             return self.bbox_provider(frame)
         if self.fixed_bbox is not None:

@@ -38,3 +38,26 @@ def skeleton_windows(n: int, seq_len: int, n_joints: int, seed: int = 0, step: f
     x = x0 + np.cumsum(steps, axis=1)
     x = x - x[:, :, :1, :]                       # root-centre every frame (main.py:103)
     return x.reshape(n, seq_len, n_joints * 3).astype(np.float32)
+
+
+def yolo_outputs(n: int = 6, seed: int = 99):
+    """Seeded detector outputs in the reference's YOLOv4 export layout (modules/hpe/hpe.py:60):
+    boxes float32[n,4032,1,4] (x1,y1,x2,y2 normalised), confidences float32[n,4032,80].
+    Frame 3 has no detection above the 0.3 threshold, frame 4 only non-person classes, frame 5
+    negative x1 coordinates (clamped to 0, hpe.py:76)."""
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(0.0, 1.0, (n, 4032, 2, 2)).astype(np.float32)
+    lo, hi = c.min(axis=2), c.max(axis=2)
+    boxes = np.concatenate([lo, hi], axis=-1)[:, :, None, :].astype(np.float32)
+    confs = (rng.uniform(0.0, 0.25, (n, 4032, 80))).astype(np.float32)
+    for i in range(n):
+        for _ in range(12):
+            a, cls = int(rng.integers(0, 4032)), int(rng.integers(0, 3))
+            confs[i, a, cls] = np.float32(rng.uniform(0.31, 0.99))
+    if n > 3:
+        confs[3] = np.minimum(confs[3], np.float32(0.25))
+    if n > 4:
+        confs[4, :, 0] = np.minimum(confs[4, :, 0], np.float32(0.2))
+    if n > 5:
+        boxes[5, :, 0, 0] = -0.01
+    return boxes, confs

@@ -218,6 +218,28 @@ def gen_all(out_dir: str):
         flat[f"hom{i}_R"] = R
         flat[f"hom{i}_H"] = (est30.K @ np.linalg.inv(new_K @ R)).astype(np.float32)
     flat["bboxes"] = np.array(BBOXES, np.int32)
+    # G8: detector post-processing (misc.postprocess_yolo_output + hpe.py:63-79) on seeded YOLO tensors
+    from modules.hpe.utils.misc import postprocess_yolo_output as ref_post
+    from isbfsar_amd import synth
+    yb, yc = synth.yolo_outputs()
+    sel = []
+    for i in range(yb.shape[0]):
+        box = ref_post(yb[i:i + 1], yc[i:i + 1], est30.yolo_thresh, est30.nms_thresh)[0]
+        humans = [e for e in box if e[5] == 0]
+        if not humans:
+            sel.append([-1, -1, -1, -1])
+            continue
+        humans.sort(key=lambda x: x[4], reverse=True)
+        hm = humans[0]
+        x1 = int(hm[0] * 640) if int(hm[0] * 640) > 0 else 0
+        y1 = int(hm[1] * 480) if int(hm[1] * 480) > 0 else 0
+        x2 = int(hm[2] * 640) if int(hm[2] * 640) > 0 else 0
+        y2 = int(hm[3] * 480) if int(hm[3] * 480) > 0 else 0
+        sel.append([x1, x2, y1, y2])
+    flat["yolo_sel"] = np.array(sel, np.int32)
+    flat["yolo_boxes_digest"] = digest(yb)
+    flat["yolo_confs_digest"] = digest(yc)
+    print("yolo selections:", sel)
     np.savez_compressed(os.path.join(out_dir, "hpe_post.npz"), **flat)
     print("hpe goldens written")
 

@@ -205,6 +205,29 @@ def test_forward_end_to_end_vs_oracle(eng_w, bbone_state, assets):
     assert np.array_equal(j2.cpu().numpy(), joints) and np.array_equal(v2.cpu().numpy(), valid)
 
 
+def test_select_person_matches_reference(eng, g):
+    """detector post-processing on the GPU vs the reference's postprocess_yolo_output + hpe.py:63-79"""
+    from oracle import hpe_oracle as ho
+    boxes, confs = synth.yolo_outputs()
+    bbox, found = eng.select_person(boxes, confs, 0.3)
+    np.testing.assert_array_equal(bbox, g["yolo_sel"])
+    np.testing.assert_array_equal(found, (g["yolo_sel"][:, 0] >= 0).astype(np.uint8))
+    b2, c2 = synth.yolo_outputs(n=9, seed=123)           # more frames against the oracle
+    bb2, f2 = eng.select_person(b2, c2, 0.3)
+    for i in range(9):
+        sel = ho.select_person(b2[i:i + 1], c2[i:i + 1], 640, 480)
+        assert (sel is None and not f2[i]) or tuple(bb2[i]) == sel
+
+
+def test_no_person_gives_invalid_pose(eng_w):
+    """estimate() returns None when the detector finds nobody (hpe.py:72-73): a (-1,..) box -> valid 0"""
+    fr = synth.frames(2, seed=90)
+    bb = synth.bboxes(2, seed=90)
+    bb[1] = -1
+    joints, valid = eng_w.forward(fr, bb)
+    assert valid[0] == 1 and valid[1] == 0 and np.all(joints[1] == 0) and np.isfinite(joints).all()
+
+
 def test_shard_invariance(eng_w):
     """Frames are independent units: any split of a batch (what DP sharding across GPUs does)
     gives bit-identical poses (SURVEY.md 8e correctness check)."""
@@ -249,3 +272,11 @@ def test_human_pose_estimator_dropin(bbone_state, assets):
     assert jb.estimate(frame) == {"bbox": (192, 48, 448, 432)}
     nob = HumanPoseEstimator(cfg, RealSenseIntrinsics(), just_box=True, bbox_provider=lambda f: None)
     assert nob.estimate(frame) is None
+    # with a detector callable (anything that returns the YOLOv4 export tensors, hpe.py:59-60) the
+    # reference flow detector -> post-processing -> crop runs end to end on the GPU
+    boxes, confs = synth.yolo_outputs()
+    det = HumanPoseEstimator(cfg, RealSenseIntrinsics(), detector=lambda f: (boxes[0:1], confs[0:1]))
+    r2 = det.estimate(frame)
+    assert r2 is not None and r2["bbox"] == (269, 459, 280, 455)
+    nodet = HumanPoseEstimator(cfg, RealSenseIntrinsics(), detector=lambda f: (boxes[3:4], confs[3:4]))
+    assert nodet.estimate(frame) is None

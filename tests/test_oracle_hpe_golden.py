@@ -85,3 +85,15 @@ def test_root_centre():
     d, flat = ho.root_centre(pose)
     assert flat.shape == (90,) and np.all(flat[:3] == 0)
     assert abs(d - np.linalg.norm(pose[0]) * 2.5) < 1e-12
+
+
+def test_detector_postprocess_matches_reference(g):
+    """G8: top-person selection (hpe.py:59-79 + misc.postprocess_yolo_output/nms_cpu) on seeded YOLO tensors."""
+    from isbfsar_amd import synth
+    boxes, confs = synth.yolo_outputs()
+    assert _digest(boxes) == str(g["yolo_boxes_digest"]) and _digest(confs) == str(g["yolo_confs_digest"])
+    for i in range(boxes.shape[0]):
+        sel = ho.select_person(boxes[i:i + 1], confs[i:i + 1], 640, 480)
+        want = tuple(int(v) for v in g["yolo_sel"][i])
+        assert (sel is None and want[0] < 0) or sel == want
+    assert (g["yolo_sel"][:, 0] < 0).sum() == 2
