@@ -204,5 +204,97 @@ class PipelineWorkload(_HpeBase):
                 "parallelism": f"dp{world} (frames sharded; one all-gather of per-window records)"}
 
 
+class StreamWorkload(_HpeBase):
+    """BASELINE configs[4]: one camera feed per GPU, per-frame step = HPE on 1 frame + AR on the current
+    30-frame sliding window against a 120-class support set, the whole step captured in ONE hipGraph
+    (torch.cuda.CUDAGraph drives hipStreamBeginCapture on the stream the library launches on)."""
+    name = "stream"
+    metric = "sustained per-feed steps/sec (1 frame -> pose -> sliding 30-frame window -> 120-class match + open-set), hipGraph replay"
+    unit = "steps/s"
+
+    def __init__(self, args, rank, world, dev):
+        import torch
+        args.batch = 1
+        self._setup_hpe(args, rank, dev)
+        self.world = world
+        self.way = 120 if args.way == 60 else args.way
+        self.ar_precision = args.precision
+        self.ar_state = weights.make_ar_state(self.L, self.J, seed=1)
+        self.ss = synth.skeleton_windows(self.way, self.L, self.J, seed=101)
+        self.ar = ArEngine(self.L, self.J, self.way, device=dev, precision=self.ar_precision, max_batch=1)
+        self.ar.load_weights(self.ar_state)
+        self.ar.set_support(poses=self.ss)
+        hist = synth.skeleton_windows(1, self.L, self.J, seed=777 + rank).reshape(1, self.L, self.J, 3)
+        self.ring = torch.from_numpy(hist).cuda(dev).contiguous()
+        self.graph = None
+        self.out = None
+        # warm-up outside capture (workspaces are allocated on first use), then capture one step
+        for _ in range(2):
+            self._step_eager()
+        torch.cuda.synchronize()
+        try:
+            g = torch.cuda.CUDAGraph()
+            s = torch.cuda.Stream(device=dev)
+            s.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(s):
+                self._step_eager()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g, stream=s):
+                    self._step_eager()
+            torch.cuda.synchronize()
+            self.graph = g
+        except Exception as e:          # report, do not hide: the JSON line says graph=false
+            self.graph_error = repr(e)
+            torch.cuda.synchronize()
+
+    def _step_eager(self):
+        joints, valid = self.hpe.forward(self.frames, self.bbox)                 # [1,122,3]
+        self.ring.copy_(self.torch.cat([self.ring[:, 1:], joints.view(1, 1, self.J, 3)], dim=1))
+        windows = pose_windows(self.ring, self.L)                                 # [1,L,3J]
+        logits, is_true, _ = self.ar.infer(windows)
+        self.out = (logits, is_true, valid)
+
+    def units_per_step(self):
+        return 1
+
+    def step(self):
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._step_eager()
+
+    def roofline(self, steps):
+        r = self._hpe_roofline(steps) if self.graph is None else None
+        lat = []
+        torch = self.torch
+        for _ in range(200):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.step()
+            e1.record()
+            e1.synchronize()
+            lat.append(e0.elapsed_time(e1))
+        lat = np.sort(np.array(lat))
+        extra = {"step_latency_ms": {"p50": round(float(lat[len(lat) // 2]), 4), "p99": round(float(lat[int(len(lat) * 0.99)]), 4)},
+                 "hipgraph": self.graph is not None}
+        if r is None:
+            # under graph replay the per-launch events of the profile hook are not available; the roofline of
+            # this latency-bound B=1 step is quoted from the un-captured run
+            self.graph, g = None, self.graph
+            r = self._hpe_roofline(steps)
+            self.graph = g
+        r.update(extra)
+        return r
+
+    def cpu_baseline(self, sample):
+        return PipelineWorkload.cpu_baseline(self, sample or 3)
+
+    def config(self, world):
+        return {"workload": "BASELINE configs[4]: 1 camera feed per GPU, per-frame step = HPE (1 frame, 122 joints) + AR on the "
+                            f"sliding 30-frame window, way={self.way}, hipGraph-captured={self.graph is not None}",
+                "per_gpu_batch": 1, "seq_len": self.L, "n_joints": self.J, "way": self.way,
+                "parallelism": f"dp{world} (one feed per GPU, no collective)"}
+
+
 def get(name: str):
-    return HpeWorkload if name == "hpe" else PipelineWorkload
+    return {"hpe": HpeWorkload, "stream": StreamWorkload}.get(name, PipelineWorkload)

@@ -191,6 +191,35 @@ def test_action_recognizer_dropin_stream(golden_dir):
     assert list(res.keys()) == ["c0", "c1", "c2", "c3"] and abs(sum(res.values()) - 1.0) < 1e-5
 
 
+def test_support_set_persistence_like_main_py():
+    """main.py:321-333 pickles `ar.support_set` / `ar.requires_focus` and assigns them back later; the
+    on-disk shape is name -> {"poses": tensor[L,3J], "features": tensor[L,256]} (assets/saved/support_set.pkl)."""
+    import pickle
+    from isbfsar_amd.modules.ar.ar import ActionRecognizer
+    from isbfsar_amd.params import TRXConfig
+    L, J, way = 16, 30, 5
+    args = TRXConfig()
+    args.weights = weights.make_ar_state(L, J, seed=0)
+    ar = ActionRecognizer(args)
+    ss = synth.skeleton_windows(3, L, J, seed=41)
+    stream = synth.skeleton_windows(1, L + 2, J, seed=42)[0]
+    for c in range(3):
+        ar.train({"flag": f"act{c}", "data": {"poses": ss[c]}, "requires_focus": False})
+    outs = [ar.inference({"sk": f}) for f in stream]
+    blob_ss, blob_rf = pickle.dumps(ar.support_set), pickle.dumps(ar.requires_focus)      # save()
+    assert all(set(v.keys()) == {"poses", "features"} for v in ar.support_set.values())
+    assert tuple(ar.support_set["act0"]["features"].shape) == (L, 256)
+    ar2 = ActionRecognizer(args)
+    ar2.support_set = pickle.loads(blob_ss)                                                # load()
+    ar2.requires_focus = pickle.loads(blob_rf)
+    outs2 = [ar2.inference({"sk": f}) for f in stream]
+    for (r1, t1, _), (r2, t2, _) in zip(outs, outs2):
+        assert r1.keys() == r2.keys()
+        if r1:
+            assert all(r1[k] == r2[k] for k in r1) and np.array_equal(t1, t2)
+    assert outs2[-1][0] and list(outs2[-1][0].keys()) == ["act0", "act1", "act2"]
+
+
 def test_full_size_properties():
     """BASELINE configs[2]: B=1024 windows of 30x122 joints, 60 classes. Size-independent
     properties: (i) windows are independent -> a permuted batch gives permuted outputs bit for
