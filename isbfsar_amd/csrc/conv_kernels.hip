@@ -381,6 +381,27 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_kernel(ConvArgs
             compute(cur);
             __syncthreads();
         }
+    } else if constexpr (NB == 3) {
+        // three buffers, two tiles in flight: tile kt+2 is requested before tile kt is consumed and is
+        // waited for one iteration later with a COUNTED vmcnt (the newest tile stays in flight across
+        // the barrier). The barrier after the MFMAs also orders the next DMA (into the buffer just
+        // consumed) behind every wave's reads.
+        constexpr int PER = A_PW + B_PW;
+        dma(0, 0);
+        if (nkt > 1) {
+            dma(1, 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        for (int kt = 0; kt < nkt; ++kt) {
+            if (kt + 2 < nkt) dma(kt + 2, (kt + 2) % 3);
+            compute(kt % 3);
+            if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
     } else {
         // ring of NB buffers, D = NB-2 tiles in flight beyond the one being consumed. One barrier per
         // tile, placed BEFORE the MFMAs; the DMA issued in iteration kt overwrites the buffer of tile
@@ -473,6 +494,16 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t st) {
         dim3 g(cdiv(a.M, 32 * TM * WGM), cdiv(a.Cout, 32 * TN * WGN));                                        \
         hipLaunchKernelGGL((conv_igemm_dma_kernel<TM, TN, WGM, WGN, 4>), g, dim3(64 * WGM * WGN), 0, st, a); \
     } while (0)
+#define ISB_CONV_LAUNCH_3B(TM, TN, WGM, WGN)                                                                  \
+    do {                                                                                                      \
+        dim3 g(cdiv(a.M, 32 * TM * WGM), cdiv(a.Cout, 32 * TN * WGN));                                        \
+        hipLaunchKernelGGL((conv_igemm_dma_kernel<TM, TN, WGM, WGN, 3>), g, dim3(64 * WGM * WGN), 0, st, a); \
+    } while (0)
+        case 31: ISB_CONV_LAUNCH_3B(2, 2, 2, 2); break;     // 128 x 128, 4 waves, 3 buffers / 2 tiles in flight
+        case 33: ISB_CONV_LAUNCH_3B(2, 1, 2, 2); break;     // 128 x  64
+        case 36: ISB_CONV_LAUNCH_3B(2, 2, 4, 2); break;     // 256 x 128, 8 waves
+        case 37: ISB_CONV_LAUNCH_3B(4, 2, 2, 4); break;     // 256 x 256, 8 waves
+#undef ISB_CONV_LAUNCH_3B
         case 21: ISB_CONV_LAUNCH_RING(2, 2, 2, 2); break;   // 128 x 128, 4 waves, 4-buffer ring
         case 23: ISB_CONV_LAUNCH_RING(2, 1, 2, 2); break;   // 128 x  64
         case 26: ISB_CONV_LAUNCH_RING(2, 2, 4, 2); break;   // 256 x 128, 8 waves
@@ -601,60 +632,71 @@ int launch_dwconv3x3(const DwArgs& a, hipStream_t st) {
 
 // =====================================================================================
 // squeeze-excite FCs in f32 on the vector ALU (tiny GEMMs: latency, not FLOPs, is what matters)
-//   se_fc1: mid[b][j]  = silu(b1[j] + sum_c pooled[b][c] * W1[j][c])    wave = (j, 8 samples)
-//   se_fc2: gate[b][c] = sigmoid(b2[c] + sum_j mid[b][j] * W2T[j][c])   thread = (c, 8 samples)
+//   se_fc1: mid[b][j]  = silu(b1[j] + sum_c pooled[b][c] * W1[j][c])    wave = (4 j, 8 samples)
+//   se_fc2: gate[b][c] = sigmoid(b2[c] + sum_j mid[b][j] * W2T[j][c])   thread = (c, 4 samples)
 // fixed summation order -> independent of scheduling and of how the batch is sharded
 // =====================================================================================
 __global__ __launch_bounds__(256) void se_fc1_kernel(SeFcArgs p) {
+    // wave = 4 outputs j x 8 samples: every weight / activation vector fetched from L2 feeds 8 / 4 FMAs
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = blockIdx.x * 4 + wave;
+    const int j0 = (blockIdx.x * 4 + wave) * 4;
     const int b0 = blockIdx.y * 8;
-    if (j >= p.cse) return;
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const float* wrow = p.w1 + (size_t)j * p.C;
+    if (j0 >= p.cse) return;
+    float acc[4][8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc[q][s] = 0.f;
     for (int c = lane * 4; c < p.C; c += 256) {
-        const float4 wv = *reinterpret_cast<const float4*>(wrow + c);
+        float4 wv[4], xv[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            wv[q] = *reinterpret_cast<const float4*>(p.w1 + (size_t)min(j0 + q, p.cse - 1) * p.C + c);
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+            xv[s] = *reinterpret_cast<const float4*>(p.pooled + (size_t)min(b0 + s, p.B - 1) * p.C + c);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                acc[q][s] = fmaf(xv[s].x, wv[q].x, fmaf(xv[s].y, wv[q].y, fmaf(xv[s].z, wv[q].z, fmaf(xv[s].w, wv[q].w, acc[q][s]))));
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            if (b0 + s < p.B) {
-                const float4 x = *reinterpret_cast<const float4*>(p.pooled + (size_t)(b0 + s) * p.C + c);
-                acc[s] = fmaf(x.x, wv.x, fmaf(x.y, wv.y, fmaf(x.z, wv.z, fmaf(x.w, wv.w, acc[s]))));
+            float v = acc[q][s];
+#pragma unroll
+            for (int sh = 32; sh >= 1; sh >>= 1) v += __shfl_xor(v, sh, 64);
+            if (lane == 0 && j0 + q < p.cse && b0 + s < p.B) {
+                v += p.b1[j0 + q];
+                p.mid[(size_t)(b0 + s) * p.cse + j0 + q] = v / (1.0f + expf(-v));
             }
         }
-    }
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        float v = acc[s];
-#pragma unroll
-        for (int sh = 32; sh >= 1; sh >>= 1) v += __shfl_xor(v, sh, 64);
-        if (lane == 0 && b0 + s < p.B) {
-            v += p.b1[j];
-            p.mid[(size_t)(b0 + s) * p.cse + j] = v / (1.0f + expf(-v));
-        }
-    }
 }
 
 __global__ __launch_bounds__(256) void se_fc2_kernel(SeFcArgs p) {
-    __shared__ float mids[8][160];
-    const int b0 = blockIdx.y * 8;
-    for (int i = threadIdx.x; i < 8 * p.cse; i += 256) {
+    __shared__ float mids[4][160];
+    const int b0 = blockIdx.y * 4;
+    for (int i = threadIdx.x; i < 4 * p.cse; i += 256) {
         const int s = i / p.cse, j = i - s * p.cse;
         mids[s][j] = (b0 + s < p.B) ? p.mid[(size_t)(b0 + s) * p.cse + j] : 0.f;
     }
     __syncthreads();
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= p.C) return;
-    float acc[8];
+    float acc[4];
     const float bias = p.b2[c];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) acc[s] = bias;
+    for (int s = 0; s < 4; ++s) acc[s] = bias;
+#pragma unroll 8
     for (int j = 0; j < p.cse; ++j) {
         const float wv = p.w2t[(size_t)j * p.C + c];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) acc[s] = fmaf(mids[s][j], wv, acc[s]);
+        for (int s = 0; s < 4; ++s) acc[s] = fmaf(mids[s][j], wv, acc[s]);
     }
 #pragma unroll
-    for (int s = 0; s < 8; ++s)
+    for (int s = 0; s < 4; ++s)
         if (b0 + s < p.B) p.gate[(size_t)(b0 + s) * p.C + c] = 1.0f / (1.0f + expf(-acc[s]));
 }
 
@@ -663,8 +705,8 @@ int launch_se_fcs(const SeFcArgs& a, hipStream_t st) {
         set_error("se_fcs: unsupported shape cse=%d C=%d", a.cse, a.C);
         return ISB_ERR_INVALID;
     }
-    hipLaunchKernelGGL(se_fc1_kernel, dim3(cdiv(a.cse, 4), cdiv(a.B, 8)), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(se_fc2_kernel, dim3(cdiv(a.C, 256), cdiv(a.B, 8)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(se_fc1_kernel, dim3(cdiv(a.cse, 16), cdiv(a.B, 8)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(se_fc2_kernel, dim3(cdiv(a.C, 256), cdiv(a.B, 4)), dim3(256), 0, st, a);
     ISB_LAUNCHED("se_fcs", st);
     return ISB_OK;
 }

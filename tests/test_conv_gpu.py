@@ -44,7 +44,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 13, 14, 15, 16, 17, 18, 19, 21, 23, 26, 27, 28])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 13, 14, 15, 16, 17, 18, 19, 21, 23, 26, 27, 28, 31, 33, 36, 37])
 @pytest.mark.parametrize("case", CASES)
 def test_conv_variants(case, variant):
     B, H, Cin, Cout, k, stride, act, use_res, use_gate = case
