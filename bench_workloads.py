@@ -60,7 +60,7 @@ class _HpeBase:
         self.B = args.batch or 256
         self.dev = dev
         self.bb_state = effnetv2.make_state(0)
-        self.hpe = HpeEngine(device=dev, max_batch=min(self.B, 256))
+        self.hpe = HpeEngine(device=dev, max_batch=min(self.B, int(os.environ.get("ISB_HPE_MICROBATCH", "256"))))
         self.hpe.load_weights(self.bb_state)
         self.hpe.set_joint_map(np.load(os.path.join(_ASSETS, "32_to_122.npy")), None)   # skeleton=None -> 122 joints
         self.frames_host = synth.frames(self.B, seed=10_000 * rank)
@@ -77,9 +77,16 @@ class _HpeBase:
         self.hpe.profile(False)
         flops = 2.0 * igemm_macs_per_crop() * self.B * steps
         achieved = flops / (ms / 1e3) / 1e12
+        traffic = None
+        tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
+        if os.path.exists(tj):      # HBM bytes of the conv_igemm launches of one forward pass, from the PMC passes
+            with open(tj) as f:     # (FETCH_SIZE / WRITE_SIZE, collected separately; see profiles/README.md)
+                t = json.load(f)["hpe_b256"]["conv_igemm"]["hbm_bytes_per_forward"]
+            traffic = t * self.B / 256.0
         return {"bound": "mfma", "kernel": "conv_igemm_kernel (all launches of a forward pass)",
                 "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS_BF16, "unit": "TFLOP/s",
-                "frac": round(achieved / MFMA_PEAK_TFLOPS_BF16, 4), "traffic": None,
+                "frac": round(achieved / MFMA_PEAK_TFLOPS_BF16, 4), "traffic": traffic,
+                "traffic_unit": "HBM bytes per forward pass over all conv_igemm launches (PMC, measured at B=256)",
                 "avg_launch_ms": round(ms / max(launches, 1), 5), "launches": int(launches),
                 "flops_per_step": flops / steps}
 

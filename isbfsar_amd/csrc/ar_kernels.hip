@@ -36,6 +36,8 @@ namespace isb {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
 __device__ __forceinline__ uint16_t f2bf(float x) { return __builtin_bit_cast(uint16_t, (__bf16)x); }
 __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
@@ -210,21 +212,23 @@ __global__ __launch_bounds__(512, 2) void ar_stats_kernel(ArStatsArgs p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) { lsum[i] = 0.f; mrun[i] = -3.0e38f; }
 
+    // the window's Kq fragment tiles go global -> LDS by LDS-DMA (lane-linear images: wave w fills
+    // KiB w of the 8-KiB tile); tile it+1 is in flight while tile it feeds the MFMAs
     const uint16_t* gq = p.KqF + (size_t)b * p.NT * TILE_U16 + tid * 8;
     const uint16_t* gq_lo = X3 ? p.KqF_lo + (size_t)b * p.NT * TILE_U16 + tid * 8 : nullptr;
-    uint4 st_hi = *reinterpret_cast<const uint4*>(gq), st_lo;
-    if (X3) st_lo = *reinterpret_cast<const uint4*>(gq_lo);
-    *reinterpret_cast<uint4*>(lds + tid * 8) = st_hi;
-    if (X3) *reinterpret_cast<uint4*>(lds + TILE_U16 + tid * 8) = st_lo;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto dma_tile = [&](int it2, int buf) {
+        uint16_t* base = lds + buf * NBUF_U16 + wave_u * 512;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(gq + (size_t)it2 * TILE_U16), (lds_ptr_t)base, 16, 0, 0);
+        if (X3) __builtin_amdgcn_global_load_lds((glb_ptr_t)(gq_lo + (size_t)it2 * TILE_U16), (lds_ptr_t)(base + TILE_U16), 16, 0, 0);
+    };
+    dma_tile(0, 0);
     __syncthreads();
 
     for (int it = 0; it < p.NT; ++it) {
         const int cur = it & 1;
         const bool more = it + 1 < p.NT;
-        if (more) {
-            st_hi = *reinterpret_cast<const uint4*>(gq + (size_t)(it + 1) * TILE_U16);
-            if (X3) st_lo = *reinterpret_cast<const uint4*>(gq_lo + (size_t)(it + 1) * TILE_U16);
-        }
+        if (more) dma_tile(it + 1, cur ^ 1);
         if (active) {
             const uint16_t* bt = lds + cur * NBUF_U16 + lane * 8;
             f32x16 acc;
@@ -257,11 +261,6 @@ __global__ __launch_bounds__(512, 2) void ar_stats_kernel(ArStatsArgs p) {
                     mrun[i] = mn;
                 }
             }
-        }
-        if (more) {
-            uint16_t* nb = lds + (cur ^ 1) * NBUF_U16;
-            *reinterpret_cast<uint4*>(nb + tid * 8) = st_hi;
-            if (X3) *reinterpret_cast<uint4*>(nb + TILE_U16 + tid * 8) = st_lo;
         }
         __syncthreads();
     }
@@ -341,37 +340,45 @@ __global__ __launch_bounds__(512, 2) void ar_proto_kernel(ArProtoArgs p) {
 
     const float* lse_row = p.lse2 + ((size_t)b * p.n + c) * Tp + 4 * h;
 
-    // staging (ALL mode): thread tid moves 16 B of the Kc tile and 16 B of the V^T tile
+    // staging (ALL mode): the class's Kc / V^T fragment tiles go global -> LDS by LDS-DMA (the fragment
+    // images are lane-linear, so wave w simply fills bytes [w KiB, (w+1) KiB) of each 8-KiB tile);
+    // tile jt+1 is in flight while tile jt feeds the MFMAs, __syncthreads() waits for it (vmcnt).
     const uint16_t* gk = p.KcF + (size_t)c * p.NT * KT_U16 + tid * 8;
     const uint16_t* gv = p.VtF + (size_t)c * p.NT * VT_U16 + tid * 8;
     const uint16_t* gk_lo = X3 ? p.KcF_lo + (size_t)c * p.NT * KT_U16 + tid * 8 : nullptr;
     const uint16_t* gv_lo = X3 ? p.VtF_lo + (size_t)c * p.NT * VT_U16 + tid * 8 : nullptr;
-    uint4 sk, sv, skl, svl;
-    if (!CHOSEN) {
-        sk = *reinterpret_cast<const uint4*>(gk);
-        sv = *reinterpret_cast<const uint4*>(gv);
-        *reinterpret_cast<uint4*>(lds + tid * 8) = sk;
-        *reinterpret_cast<uint4*>(lds + KT_U16 + tid * 8) = sv;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto dma_tile = [&](int jt2, int buf) {
+        uint16_t* base = lds + buf * NBUF_U16 + wave_u * 512;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(gk + (size_t)jt2 * KT_U16), (lds_ptr_t)base, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(gv + (size_t)jt2 * VT_U16), (lds_ptr_t)(base + KT_U16), 16, 0, 0);
         if (X3) {
-            skl = *reinterpret_cast<const uint4*>(gk_lo);
-            svl = *reinterpret_cast<const uint4*>(gv_lo);
-            *reinterpret_cast<uint4*>(lds + PART_U16 + tid * 8) = skl;
-            *reinterpret_cast<uint4*>(lds + PART_U16 + KT_U16 + tid * 8) = svl;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(gk_lo + (size_t)jt2 * KT_U16), (lds_ptr_t)(base + PART_U16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(gv_lo + (size_t)jt2 * VT_U16), (lds_ptr_t)(base + PART_U16 + KT_U16), 16, 0, 0);
         }
+    };
+    float lse_nx[16];
+    auto load_lse = [&](int jt2) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 u = *reinterpret_cast<const float4*>(lse_row + jt2 * 32 + 8 * q);
+            lse_nx[4 * q + 0] = u.x; lse_nx[4 * q + 1] = u.y; lse_nx[4 * q + 2] = u.z; lse_nx[4 * q + 3] = u.w;
+        }
+    };
+    load_lse(0);
+    if (!CHOSEN) {
+        dma_tile(0, 0);
         __syncthreads();
     }
 
     for (int jt = 0; jt < p.NT; ++jt) {
         const int cur = jt & 1;
         const bool more = jt + 1 < p.NT;
-        if (!CHOSEN && more) {
-            sk = *reinterpret_cast<const uint4*>(gk + (size_t)(jt + 1) * KT_U16);
-            sv = *reinterpret_cast<const uint4*>(gv + (size_t)(jt + 1) * VT_U16);
-            if (X3) {
-                skl = *reinterpret_cast<const uint4*>(gk_lo + (size_t)(jt + 1) * KT_U16);
-                svl = *reinterpret_cast<const uint4*>(gv_lo + (size_t)(jt + 1) * VT_U16);
-            }
-        }
+        if (!CHOSEN && more) dma_tile(jt + 1, cur ^ 1);
+        float lse[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) lse[e] = lse_nx[e];
+        if (more) load_lse(jt + 1);                        // next tile's lse2 arrives under this tile's MFMAs
         if (active) {
             const uint16_t* kt;
             const uint16_t* vt;
@@ -388,13 +395,6 @@ __global__ __launch_bounds__(512, 2) void ar_proto_kernel(ArProtoArgs p) {
                 kt = lds + cur * NBUF_U16 + lane * 8;
                 vt = kt + KT_U16;
                 if (X3) { kt_lo = kt + PART_U16; vt_lo = vt + PART_U16; }
-            }
-            // lse2 of the 16 support tuples this lane's accumulator rows belong to
-            float lse[16];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 u = *reinterpret_cast<const float4*>(lse_row + jt * 32 + 8 * q);
-                lse[4 * q + 0] = u.x; lse[4 * q + 1] = u.y; lse[4 * q + 2] = u.z; lse[4 * q + 3] = u.w;
             }
             // S^T tile = Kc[jt] * Kq[it]^T
             f32x16 acc;
@@ -435,18 +435,7 @@ __global__ __launch_bounds__(512, 2) void ar_proto_kernel(ArProtoArgs p) {
                     }
                 }
         }
-        if (!CHOSEN) {
-            if (more) {
-                uint16_t* nb = lds + (cur ^ 1) * NBUF_U16;
-                *reinterpret_cast<uint4*>(nb + tid * 8) = sk;
-                *reinterpret_cast<uint4*>(nb + KT_U16 + tid * 8) = sv;
-                if (X3) {
-                    *reinterpret_cast<uint4*>(nb + PART_U16 + tid * 8) = skl;
-                    *reinterpret_cast<uint4*>(nb + PART_U16 + KT_U16 + tid * 8) = svl;
-                }
-            }
-            __syncthreads();
-        }
+        if (!CHOSEN) __syncthreads();
     }
     if (!active) return;
 
