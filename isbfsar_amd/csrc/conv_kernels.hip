@@ -73,7 +73,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
         return;
     }
     // bf16 output: bias + SiLU + residual in registers (one rounding), stage the tile in LDS, then
-    // write full 16-byte pieces, 256 B contiguous per pixel row
+    // write full 16-byte pieces, 256 B contiguous per pixel row. Tiles too wide to stage (> 64 KiB)
+    // store their 8-byte packed pieces straight from registers (the L2 merges the partial lines).
+    constexpr bool STAGE = BM * CROW <= 65536;
+    uint16_t* out16 = reinterpret_cast<uint16_t*>(p.out);
     unsigned char* Cs = lds;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -100,11 +103,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
                 uint2 pk;
                 pk.x = (uint32_t)f2bf_(v0) | ((uint32_t)f2bf_(v1) << 16);
                 pk.y = (uint32_t)f2bf_(v2) | ((uint32_t)f2bf_(v3) << 16);
-                *reinterpret_cast<uint2*>(Cs + ml * CROW + nl * 2) = pk;
+                if constexpr (STAGE) *reinterpret_cast<uint2*>(Cs + ml * CROW + nl * 2) = pk;
+                else if (mok && n < p.Cout) *reinterpret_cast<uint2*>(out16 + (size_t)m * p.Cout + n) = pk;
             }
     }
+    if constexpr (!STAGE) return;
     __syncthreads();
-    uint16_t* out16 = reinterpret_cast<uint16_t*>(p.out);
     constexpr int CPR = BN / 8;                            // 16-byte pieces per tile row
 #pragma unroll 4
     for (int id = tid; id < BM * CPR; id += NT) {
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(ConvArgs p) 
     constexpr int B_PASS = (B_CHUNKS + NT - 1) / NT;
     constexpr int BUF = (BM + BN) * ROWB;
     constexpr int CROW = BN * 2 + 16;                     // staged C tile row (bf16) + pad: conflict-free b64 writes
-    constexpr int LDS_BYTES = (2 * BUF > BM * CROW) ? 2 * BUF : BM * CROW;
+    constexpr int LDS_BYTES = (2 * BUF > BM * CROW || BM * CROW > 65536) ? 2 * BUF : BM * CROW;
     static_assert(BM % A_ROWS == 0, "A tile rows must divide evenly over the threads");
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
 
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_kernel(ConvArgs
     constexpr int A_PW = (A_INST + NW - 1) / NW, B_PW = (B_INST + NW - 1) / NW;
     constexpr int BUF = (BM + BN) * ROWB;
     constexpr int CROW = BN * 2 + 16;
-    constexpr int LDS_BYTES = (NB * BUF > BM * CROW) ? NB * BUF : BM * CROW;
+    constexpr int LDS_BYTES = (NB * BUF > BM * CROW || BM * CROW > 65536) ? NB * BUF : BM * CROW;
     static_assert(NB == 2 || (A_INST % NW == 0 && B_INST % NW == 0), "ring mode needs the same DMA count in every wave");
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
 
@@ -441,21 +445,28 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t st) {
     if (v == 0) {
         // measured on MI355X (tools/conv_sweep.py, profiles/): without an SE gate the LDS-DMA kernels win,
         // 8-wave 256-row tiles for wide outputs; gated projections stay on the register-staged kernel
+        // High occupancy wins on this chip (many waves of 32-row x 64..96-column sub-tiles); projections
+        // that carry an SE gate stay on the register-staged kernel and prefer full-width tiles (the big
+        // A operand is then read once).
         if (!a.gate && a.zeros) {
-            if (a.Cout % 128 == 0) v = 16;            // 256 x 128, 8 waves
-            else if (a.Cout % 64 == 0) v = 19;        // 256 x  64, 8 waves
-            else if (a.Cout % 96 == 0) v = 12;        // 128 x  96
+            if (a.Cout == 32) v = 59;                 // 256 x  32, 8 waves
+            else if (a.Cout % 192 == 0) v = 54;       // 128 x 192, 8 waves of 32 x 96
+            else if (a.Cout % 128 == 0) v = 55;       // 128 x 128, 8 waves of 32 x 64
+            else if (a.Cout == 64) v = 57;            // 256 x  64
             else if (a.Cout == 224) v = 14;
-            else v = 15;                              // 256 x  32
+            else v = 55;
         } else {
-            if (a.Cout % 128 == 0) v = 1;
+            if (a.Cout % 320 == 0) v = 43;            // 128 x 320, 8 waves
+            else if (a.Cout % 192 == 0) v = 44;       // 128 x 192, 8 waves
+            else if (a.Cout == 224) v = 4;            // 128 x 224
+            else if (a.Cout % 128 == 0) v = 1;
             else if (a.Cout % 96 == 0) v = 2;
             else if (a.Cout % 64 == 0) v = 3;
-            else if (a.Cout == 224) v = 1;            // two 128-wide column blocks beat the 224-wide tile
             else v = 5;
         }
     }
-    if (v > 10 && (a.gate || !a.zeros)) {
+    const bool is_dma = (v >= 11 && v <= 39) || (v >= 51 && v <= 59);
+    if (is_dma && (a.gate || !a.zeros)) {
         set_error("conv_igemm: the LDS-DMA variants take no SE gate and need the zero line");
         return ISB_ERR_INVALID;
     }
@@ -474,6 +485,13 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t st) {
         case 7: ISB_CONV_LAUNCH(4, 2, 2, 4); break;      // 256 x 256, 8 waves
         case 8: ISB_CONV_LAUNCH(2, 3, 4, 2); break;      // 256 x 192, 8 waves
         case 9: ISB_CONV_LAUNCH(2, 1, 4, 2); break;      // 256 x  64, 8 waves
+        case 41: ISB_CONV_LAUNCH(1, 6, 4, 1); break;     // 128 x 192: full-width tiles read the A operand once
+        case 42: ISB_CONV_LAUNCH(1, 6, 4, 2); break;     // 128 x 384, 8 waves
+        case 43: ISB_CONV_LAUNCH(1, 5, 4, 2); break;     // 128 x 320, 8 waves
+        case 44: ISB_CONV_LAUNCH(1, 3, 4, 2); break;     // 128 x 192, 8 waves
+        case 45: ISB_CONV_LAUNCH(1, 2, 4, 2); break;     // 128 x 128, 8 waves of 32 x 64
+        case 47: ISB_CONV_LAUNCH(1, 4, 4, 2); break;     // 128 x 256, 8 waves
+        case 48: ISB_CONV_LAUNCH(1, 7, 4, 2); break;     // 128 x 448, 8 waves
 #define ISB_CONV_LAUNCH_DMA(TM, TN, WGM, WGN)                                                              \
     do {                                                                                                   \
         dim3 g(cdiv(a.M, 32 * TM * WGM), cdiv(a.Cout, 32 * TN * WGN));                                     \
@@ -488,6 +506,15 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t st) {
         case 17: ISB_CONV_LAUNCH_DMA(4, 2, 2, 4); break;
         case 18: ISB_CONV_LAUNCH_DMA(2, 3, 4, 2); break;
         case 19: ISB_CONV_LAUNCH_DMA(2, 1, 4, 2); break;
+        case 51: ISB_CONV_LAUNCH_DMA(1, 6, 4, 1); break;
+        case 52: ISB_CONV_LAUNCH_DMA(1, 6, 4, 2); break;
+        case 53: ISB_CONV_LAUNCH_DMA(1, 5, 4, 2); break;
+        case 54: ISB_CONV_LAUNCH_DMA(1, 3, 4, 2); break;
+        case 55: ISB_CONV_LAUNCH_DMA(1, 2, 4, 2); break;
+        case 56: ISB_CONV_LAUNCH_DMA(1, 4, 4, 2); break;
+        case 57: ISB_CONV_LAUNCH_DMA(1, 2, 8, 1); break;    // 256 x 64
+        case 58: ISB_CONV_LAUNCH_DMA(1, 3, 8, 1); break;    // 256 x 96
+        case 59: ISB_CONV_LAUNCH_DMA(1, 1, 8, 1); break;    // 256 x 32
 #undef ISB_CONV_LAUNCH_DMA
 #define ISB_CONV_LAUNCH_RING(TM, TN, WGM, WGN)                                                                \
     do {                                                                                                      \
