@@ -184,6 +184,13 @@ int isb_debug_conv(int32_t device, const uint16_t* h_x, const float* h_w, const 
                    int32_t k, int32_t stride, int32_t act, int32_t variant, int32_t iters, uint16_t* h_out,
                    float* ms_per_iter);
 
+/* test / tuning hook: the fused MBConv front half (1x1 expand + BN + SiLU -> depthwise 3x3 + BN + SiLU,
+ * plus the squeeze-excite mean) on host tensors; HW = 8 or 16 (one sample per workgroup tile).
+ *   h_x bf16 [B,HW,HW,Cin], h_w1 f32 [Cexp,Cin], h_dww f32 [Cexp,3,3]; out bf16 [B,HW,HW,Cexp], pooled f32 [B,Cexp] */
+int isb_debug_expand_dw(int32_t device, const uint16_t* h_x, const float* h_w1, const float* h_scale1, const float* h_shift1,
+                        const float* h_dww, const float* h_dwscale, const float* h_dwshift, int32_t B, int32_t HW, int32_t Cin,
+                        int32_t Cexp, int32_t iters, uint16_t* h_out, float* h_pooled, float* ms_per_iter);
+
 /* ------------------------------------------------------------------------------------------
  * Glue between the two stages (main.py:102-105 + ar.py:42-50): root-centre every pose on joint 0,
  * flatten to 3J and cut sliding windows of L consecutive frames per camera.

@@ -267,6 +267,112 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(ConvArgs p) 
 }
 
 // -------------------------------------------------------------------------------------------
+// Fused MBConv front half: 1x1 expand (this GEMM) -> folded BN + SiLU -> depthwise 3x3 (stride 1)
+// -> folded BN + SiLU -> D, plus the squeeze-excite average pool -- without the expanded tensor E ever
+// leaving the chip. The M tile is exactly ONE sample (BM == H*W pixels in raster order), so after the
+// bias/SiLU'd bf16 E tile has been staged in LDS as [pixel][channel] the 3x3 neighbourhood of every
+// output is in LDS. thread = (8-channel chunk, pixel quad) as in dwconv3x3_pool_kernel.
+// -------------------------------------------------------------------------------------------
+template <int TM, int TN, int WGM, int WGN>
+__device__ __forceinline__ void conv_epilogue_dw(const ConvArgs& p, f32x16 (&acc)[TM][TN], unsigned char* lds, int m0, int n0,
+                                                 int wm, int wn, int r, int h, int tid) {
+    constexpr int NT = 64 * WGM * WGN;
+    constexpr int BM = 32 * TM * WGM;
+    constexpr int BN = 32 * TN * WGN;
+    constexpr int CROW = BN * 2 + 16;
+    constexpr int CH = BN / 8;                             // 8-channel chunks in the slab
+    constexpr int NQ = BM / 4;                             // pixel quads of the sample
+    static_assert(CH * NQ == NT, "one (chunk, quad) item per thread");
+    unsigned char* Cs = lds;
+    float* red = reinterpret_cast<float*>(lds + BM * CROW);   // [NQ][BN] partial pool sums
+    // stage E = silu(acc + bias) as bf16 [pixel][channel]
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int ml = (wm * TM + i) * 32 + r;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nl = (wn * TN + j) * 32 + 8 * q + 4 * h;
+                const float4 bs = *reinterpret_cast<const float4*>(p.bias + n0 + nl);
+                const float v0 = silu_fast(acc[i][j][4 * q] + bs.x), v1 = silu_fast(acc[i][j][4 * q + 1] + bs.y);
+                const float v2 = silu_fast(acc[i][j][4 * q + 2] + bs.z), v3 = silu_fast(acc[i][j][4 * q + 3] + bs.w);
+                uint2 pk;
+                pk.x = (uint32_t)f2bf_(v0) | ((uint32_t)f2bf_(v1) << 16);
+                pk.y = (uint32_t)f2bf_(v2) | ((uint32_t)f2bf_(v3) << 16);
+                *reinterpret_cast<uint2*>(Cs + ml * CROW + nl * 2) = pk;
+            }
+    }
+    __syncthreads();
+    // depthwise 3x3, stride 1, pad 1 over the staged sample
+    const int W = p.OW, Hh = p.OH;
+    const int cl = tid % CH, pq = tid / CH;
+    const int c = n0 + cl * 8;                             // global expanded channel
+    const int qpr = W >> 2;
+    const int oy = pq / qpr, ox0 = (pq - oy * qpr) * 4;
+    const int b = m0 / BM;
+    float w[9][8], a4[4][8], psum[8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const float4 w0 = *reinterpret_cast<const float4*>(p.dw_w + (size_t)t * p.Cout + c), w1 = *reinterpret_cast<const float4*>(p.dw_w + (size_t)t * p.Cout + c + 4);
+        w[t][0] = w0.x; w[t][1] = w0.y; w[t][2] = w0.z; w[t][3] = w0.w; w[t][4] = w1.x; w[t][5] = w1.y; w[t][6] = w1.z; w[t][7] = w1.w;
+    }
+    {
+        const float4 s0 = *reinterpret_cast<const float4*>(p.dw_bias + c), s1 = *reinterpret_cast<const float4*>(p.dw_bias + c + 4);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            a4[o][0] = s0.x; a4[o][1] = s0.y; a4[o][2] = s0.z; a4[o][3] = s0.w; a4[o][4] = s1.x; a4[o][5] = s1.y; a4[o][6] = s1.z; a4[o][7] = s1.w;
+        }
+    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy - 1 + ky;
+        if ((unsigned)iy >= (unsigned)Hh) continue;
+#pragma unroll
+        for (int col = 0; col < 6; ++col) {
+            const int ix = ox0 - 1 + col;
+            if ((unsigned)ix >= (unsigned)W) continue;
+            const uint4 v = *reinterpret_cast<const uint4*>(Cs + (iy * W + ix) * CROW + cl * 16);
+            float x[8];
+            x[0] = bf2f_((uint16_t)(v.x & 0xffff)); x[1] = bf2f_((uint16_t)(v.x >> 16));
+            x[2] = bf2f_((uint16_t)(v.y & 0xffff)); x[3] = bf2f_((uint16_t)(v.y >> 16));
+            x[4] = bf2f_((uint16_t)(v.z & 0xffff)); x[5] = bf2f_((uint16_t)(v.z >> 16));
+            x[6] = bf2f_((uint16_t)(v.w & 0xffff)); x[7] = bf2f_((uint16_t)(v.w >> 16));
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const int kx = col - o;
+                if (kx >= 0 && kx < 3) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a4[o][e] = fmaf(x[e], w[ky * 3 + kx][e], a4[o][e]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) psum[e] = 0.f;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        uint32_t pk[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint16_t lo = f2bf_(silu_fast(a4[o][2 * e])), hi = f2bf_(silu_fast(a4[o][2 * e + 1]));
+            pk[e] = (uint32_t)lo | ((uint32_t)hi << 16);
+            psum[2 * e] += bf2f_(lo);
+            psum[2 * e + 1] += bf2f_(hi);
+        }
+        *reinterpret_cast<uint4*>(p.dw_out + (((size_t)(b * Hh + oy) * W + ox0 + o) * p.Cout + c)) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[pq * BN + cl * 8 + e] = psum[e];
+    __syncthreads();
+    if (tid < BN) {
+        float t = 0.f;
+        for (int s2 = 0; s2 < NQ; ++s2) t += red[s2 * BN + tid];
+        p.pooled[(size_t)b * p.Cout + n0 + tid] = t / (float)BM;
+    }
+}
+
+// -------------------------------------------------------------------------------------------
 // LDS-DMA variant (convolutions without an SE gate): tiles go global -> LDS directly
 // (global_load_lds_dwordx4: 1 KiB per wave-instruction, destination = wave-uniform base + lane*16,
 // so the XOR swizzle is applied to the per-lane SOURCE address). No staging registers, no
@@ -276,7 +382,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(ConvArgs p) 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
-template <int TM, int TN, int WGM, int WGN, int NB>
+template <int TM, int TN, int WGM, int WGN, int NB, bool DW = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_kernel(ConvArgs p) {
     constexpr int NW = WGM * WGN;
     constexpr int BM = 32 * TM * WGM;
@@ -285,7 +391,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_kernel(ConvArgs
     constexpr int A_PW = (A_INST + NW - 1) / NW, B_PW = (B_INST + NW - 1) / NW;
     constexpr int BUF = (BM + BN) * ROWB;
     constexpr int CROW = BN * 2 + 16;
-    constexpr int LDS_BYTES = (NB * BUF > BM * CROW || BM * CROW > 65536) ? NB * BUF : BM * CROW;
+    constexpr int LDS_PLAIN = (NB * BUF > BM * CROW || BM * CROW > 65536) ? NB * BUF : BM * CROW;
+    constexpr int LDS_DW = BM * CROW + (BM / 4) * BN * 4;   // staged E tile + partial pool sums
+    constexpr int LDS_BYTES = DW ? (LDS_DW > NB * BUF ? LDS_DW : NB * BUF) : LDS_PLAIN;
     static_assert(NB == 2 || (A_INST % NW == 0 && B_INST % NW == 0), "ring mode needs the same DMA count in every wave");
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
 
@@ -428,7 +536,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_kernel(ConvArgs
         }
         __syncthreads();                                    // all MFMA reads done before the tile staging reuses LDS
     }
-    conv_epilogue<TM, TN, WGM, WGN>(p, acc, lds, m0, n0, wm, wn, r, h, tid);
+    if constexpr (DW) conv_epilogue_dw<TM, TN, WGM, WGN>(p, acc, lds, m0, n0, wm, wn, r, h, tid);
+    else conv_epilogue<TM, TN, WGM, WGN>(p, acc, lds, m0, n0, wm, wn, r, h, tid);
 }
 
 int launch_conv_igemm(const ConvArgs& a, hipStream_t st) {
@@ -543,6 +652,27 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t st) {
     }
 #undef ISB_CONV_LAUNCH
     ISB_LAUNCHED("conv_igemm", st);
+    return ISB_OK;
+}
+
+int launch_conv_expand_dw(const ConvArgs& a, hipStream_t st) {
+    const int hw = a.OH * a.OW;
+    if (a.KH != 1 || a.stride != 1 || a.gate || a.res || !a.zeros || !a.dw_w || !a.dw_bias || !a.dw_out || !a.pooled || a.OH != a.OW ||
+        a.Cin % 32 != 0) {
+        set_error("conv_expand_dw: needs an un-gated stride-1 1x1 expand conv with depthwise weights");
+        return ISB_ERR_INVALID;
+    }
+    if (hw == 256 && a.Cout % 64 == 0) {           // one 16x16 sample per tile: 256 x 64, 8 waves
+        dim3 g(a.B, a.Cout / 64);
+        hipLaunchKernelGGL((conv_igemm_dma_kernel<1, 2, 8, 1, 2, true>), g, dim3(512), 0, st, a);
+    } else if (hw == 64 && a.Cout % 128 == 0) {    // one 8x8 sample per tile: 64 x 128, 4 waves
+        dim3 g(a.B, a.Cout / 128);
+        hipLaunchKernelGGL((conv_igemm_dma_kernel<1, 2, 2, 2, 2, true>), g, dim3(256), 0, st, a);
+    } else {
+        set_error("conv_expand_dw: unsupported shape hw=%d Cout=%d", hw, a.Cout);
+        return ISB_ERR_INVALID;
+    }
+    ISB_LAUNCHED("conv_expand_dw", st);
     return ISB_OK;
 }
 

@@ -39,6 +39,8 @@ struct isb_hpe {
     isb_hpe_cfg cfg{};
     hipStream_t own_stream = nullptr;
     bool weights = false, jointmap = false;
+    bool fuse_front = false;      // MBConv expand + depthwise + pool in one kernel (ISB_FUSE_FRONT=1): measured equal to
+                                  // the two-launch form on MI355X (E stays in the 256 MiB Infinity Cache), so off by default
     int n_out = 0;
     double K[9] = {0};
     // weights
@@ -159,13 +161,36 @@ int run_backbone(isb_hpe* h, hipStream_t st, const float* crops, int B) {
                 ISB_TRY(conv(h, st, b.project, h->bufE.p, B, b.out_hw, b.out_hw, 1, false, res, nullptr, Y, false));
             }
         } else {
-            ISB_TRY(conv(h, st, b.expand, X, B, b.in_hw, b.in_hw, 1, true, nullptr, nullptr, h->bufE.p, false));
-            DwArgs d{};
-            d.in = h->bufE.as<uint16_t>(); d.w = b.dw_w.as<float>(); d.bias = b.dw_b.as<float>(); d.out = h->bufD.as<uint16_t>();
-            d.B = B; d.H = b.in_hw; d.W = b.in_hw; d.C = b.cexp; d.OH = b.out_hw; d.OW = b.out_hw; d.stride = b.stride;
-            d.pad = b.stride == 1 ? 1 : 0;
-            d.pooled = h->pooled.as<float>();
-            ISB_TRY(launch_dwconv3x3(d, st));
+            if (b.stride == 1 && h->fuse_front) {
+                // expand 1x1 + dw 3x3 + SE pool in one launch: the expanded tensor never leaves the chip
+                ConvArgs a{};
+                a.in = (const uint16_t*)X; a.w = b.expand.w16.as<uint16_t>(); a.bias = b.expand.bias.as<float>();
+                a.B = B; a.H = b.in_hw; a.W = b.in_hw; a.Cin = b.cin; a.Cout = b.cexp; a.KH = 1; a.KW = 1; a.stride = 1;
+                a.OH = b.in_hw; a.OW = b.in_hw; a.pad = 0; a.M = B * b.in_hw * b.in_hw; a.K = b.cin; a.act = 1;
+                a.zeros = h->zeros.as<uint16_t>();
+                a.dw_w = b.dw_w.as<float>(); a.dw_bias = b.dw_b.as<float>(); a.dw_out = h->bufD.as<uint16_t>();
+                a.pooled = h->pooled.as<float>();
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (h->prof) {
+                    ISB_HIP(hipEventCreate(&e0));
+                    ISB_HIP(hipEventCreate(&e1));
+                    ISB_HIP(hipEventRecord(e0, st));
+                }
+                ISB_TRY(launch_conv_expand_dw(a, st));
+                if (h->prof) {
+                    ISB_HIP(hipEventRecord(e1, st));
+                    h->prof_ev.emplace_back(e0, e1);
+                    h->prof_launches += 1;
+                }
+            } else {
+                ISB_TRY(conv(h, st, b.expand, X, B, b.in_hw, b.in_hw, 1, true, nullptr, nullptr, h->bufE.p, false));
+                DwArgs d{};
+                d.in = h->bufE.as<uint16_t>(); d.w = b.dw_w.as<float>(); d.bias = b.dw_b.as<float>(); d.out = h->bufD.as<uint16_t>();
+                d.B = B; d.H = b.in_hw; d.W = b.in_hw; d.C = b.cexp; d.OH = b.out_hw; d.OW = b.out_hw; d.stride = b.stride;
+                d.pad = b.stride == 1 ? 1 : 0;
+                d.pooled = h->pooled.as<float>();
+                ISB_TRY(launch_dwconv3x3(d, st));
+            }
             SeFcArgs se{};
             se.pooled = h->pooled.as<float>(); se.w1 = b.se_w1.as<float>(); se.b1 = b.se_b1.as<float>();
             se.w2t = b.se_w2.as<float>(); se.b2 = b.se_b2.as<float>(); se.mid = h->semid.as<float>();
@@ -227,6 +252,7 @@ extern "C" int isb_hpe_create(const isb_hpe_cfg* cfg, isb_hpe** out) {
     ISB_HIP(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     ISB_TRY(h->zeros.alloc(256));
     ISB_HIP(hipMemset(h->zeros.p, 0, 256));
+    h->fuse_front = getenv("ISB_FUSE_FRONT") != nullptr;
     *out = h.release();
     return ISB_OK;
     });
@@ -587,6 +613,57 @@ extern "C" int isb_hpe_select_person_host(isb_hpe* h, const float* boxes, const 
         ISB_HIP(hipStreamSynchronize(h->own_stream));
         ISB_HIP(hipMemcpy(bbox, dbb.p, (size_t)B * 16, hipMemcpyDeviceToHost));
         ISB_HIP(hipMemcpy(found, df.p, (size_t)B, hipMemcpyDeviceToHost));
+        return ISB_OK;
+    });
+}
+
+// test / tuning hook: fused MBConv front half (1x1 expand + SiLU + depthwise 3x3 + SiLU + SE pool) on host tensors
+extern "C" int isb_debug_expand_dw(int32_t device, const uint16_t* x, const float* w1, const float* scale1, const float* shift1,
+                                   const float* dww, const float* dwscale, const float* dwshift, int32_t B, int32_t HW,
+                                   int32_t Cin, int32_t Cexp, int32_t iters, uint16_t* out, float* pooled, float* ms_per_iter) {
+    return isb::guard([&]() -> int {
+        ISB_REQUIRE(x && w1 && scale1 && shift1 && dww && dwscale && dwshift && out && pooled && ms_per_iter, ISB_ERR_INVALID,
+                    "null argument");
+        ISB_REQUIRE((HW == 8 || HW == 16) && iters >= 1, ISB_ERR_INVALID, "HW must be 8 or 16");
+        ISB_HIP(hipSetDevice(device));
+        const size_t nin = (size_t)B * HW * HW * Cin, nout = (size_t)B * HW * HW * Cexp, nw = (size_t)Cexp * Cin;
+        DevBuf dx, dwf, dsc, dsh, dw16, ddw, ddb, dout, dpool, dzero;
+        ISB_TRY(dzero.alloc(256));
+        ISB_HIP(hipMemset(dzero.p, 0, 256));
+        ISB_TRY(upload(dx, x, nin * 2));
+        ISB_TRY(upload(dwf, w1, nw * 4));
+        ISB_TRY(upload(dsc, scale1, (size_t)Cexp * 4));
+        ISB_TRY(upload(dsh, shift1, (size_t)Cexp * 4));
+        ISB_TRY(dw16.alloc(nw * 2));
+        ISB_TRY(launch_f32_to_bf16_rows(dwf.as<float>(), dsc.as<float>(), dw16.as<uint16_t>(), Cexp, (size_t)Cin, nullptr));
+        std::vector<float> wt((size_t)9 * Cexp);
+        for (int c = 0; c < Cexp; ++c)
+            for (int t = 0; t < 9; ++t) wt[(size_t)t * Cexp + c] = dww[(size_t)c * 9 + t] * dwscale[c];
+        ISB_TRY(upload(ddw, wt.data(), wt.size() * 4));
+        ISB_TRY(upload(ddb, dwshift, (size_t)Cexp * 4));
+        ISB_TRY(dout.alloc(nout * 2));
+        ISB_TRY(dpool.alloc((size_t)B * Cexp * 4));
+        ConvArgs a{};
+        a.in = dx.as<uint16_t>(); a.w = dw16.as<uint16_t>(); a.bias = dsh.as<float>();
+        a.B = B; a.H = HW; a.W = HW; a.Cin = Cin; a.Cout = Cexp; a.KH = 1; a.KW = 1; a.stride = 1; a.OH = HW; a.OW = HW;
+        a.pad = 0; a.M = B * HW * HW; a.K = Cin; a.act = 1; a.zeros = dzero.as<uint16_t>();
+        a.dw_w = ddw.as<float>(); a.dw_bias = ddb.as<float>(); a.dw_out = dout.as<uint16_t>(); a.pooled = dpool.as<float>();
+        ISB_TRY(launch_conv_expand_dw(a, nullptr));
+        ISB_HIP(hipDeviceSynchronize());
+        hipEvent_t e0, e1;
+        ISB_HIP(hipEventCreate(&e0));
+        ISB_HIP(hipEventCreate(&e1));
+        ISB_HIP(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < iters; ++i) ISB_TRY(launch_conv_expand_dw(a, nullptr));
+        ISB_HIP(hipEventRecord(e1, nullptr));
+        ISB_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        ISB_HIP(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        *ms_per_iter = ms / iters;
+        ISB_HIP(hipMemcpy(out, dout.p, nout * 2, hipMemcpyDeviceToHost));
+        ISB_HIP(hipMemcpy(pooled, dpool.p, (size_t)B * Cexp * 4, hipMemcpyDeviceToHost));
         return ISB_OK;
     });
 }

@@ -123,8 +123,14 @@ struct ConvArgs {
     int out_f32;
     int variant;            // tile variant, 0 = choose by Cout (conv_kernels.hip)
     const uint16_t* zeros;  // >= 16 bytes of zeros (source of padding taps for the LDS-DMA kernels)
+    // fused MBConv front half (launch_conv_expand_dw): depthwise 3x3 + SE pool applied to the staged tile
+    const float* dw_w;      // f32 [9][Cout] tap-major, BN scale folded
+    const float* dw_bias;   // f32 [Cout]
+    uint16_t* dw_out;       // bf16 [B,OH,OW,Cout] depthwise output D
+    float* pooled;          // f32 [B,Cout] spatial mean of D
 };
 int launch_conv_igemm(const ConvArgs& a, hipStream_t st);
+int launch_conv_expand_dw(const ConvArgs& a, hipStream_t st);
 
 struct DwArgs {
     const uint16_t* in;     // bf16 [B,H,W,C]

@@ -175,6 +175,23 @@ def conv_debug(x_bf16, w, scale, shift, k, stride, act, res_bf16=None, gate=None
     return out, ms.value
 
 
+def expand_dw_debug(x_bf16, w1, scale1, shift1, dww, dwscale, dwshift, iters=1, device=0):
+    """Fused MBConv front half through isb_debug_expand_dw. x_bf16 uint16 [B,HW,HW,Cin].
+    Returns (D uint16 [B,HW,HW,Cexp], pooled f32 [B,Cexp], ms_per_launch)."""
+    x = np.ascontiguousarray(x_bf16, dtype=np.uint16)
+    B, HW, _, Cin = x.shape
+    w1 = np.ascontiguousarray(w1, dtype=np.float32)
+    Cexp = w1.shape[0]
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    out = np.empty((B, HW, HW, Cexp), np.uint16)
+    pooled = np.empty((B, Cexp), np.float32)
+    ms = C.c_float()
+    _lib.check(_lib.lib().isb_debug_expand_dw(device, _ptr(x), _ptr(w1), _ptr(f(scale1)), _ptr(f(shift1)), _ptr(f(dww)),
+                                              _ptr(f(dwscale)), _ptr(f(dwshift)), B, HW, Cin, Cexp, iters, _ptr(out), _ptr(pooled),
+                                              C.byref(ms)), "isb_debug_expand_dw")
+    return out, pooled, ms.value
+
+
 def pose_windows(joints, seq_len: int):
     """joints torch CUDA f32 [n_cam, n_frames, J, 3] -> windows [n_cam*(n_frames-L+1), L, 3J]
     (root-centred on joint 0, main.py:103; window assembly, ar.py:42-50)."""

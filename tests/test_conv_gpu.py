@@ -66,3 +66,32 @@ def test_conv_variants(case, variant):
     tol = 2.0 ** -7 * np.maximum(1.0, np.abs(ref))
     assert np.all(np.abs(got - ref) <= tol), float(np.abs(got - ref).max())
     assert ms >= 0
+
+
+@pytest.mark.parametrize("B,HW,Cin,Cexp", [(2, 16, 192, 768), (3, 8, 384, 2304), (1, 16, 224, 1344), (2, 8, 640, 3840)])
+def test_fused_expand_dw_pool(B, HW, Cin, Cexp):
+    """Fused MBConv front half vs torch-CPU: expand 1x1 -> SiLU -> (bf16) -> depthwise 3x3 -> SiLU -> (bf16), SE mean."""
+    from isbfsar_amd.hpe_engine import expand_dw_debug
+    rng = np.random.default_rng(B * 1000 + Cexp)
+    x = rng.normal(0, 1, (B, HW, HW, Cin)).astype(np.float32)
+    w1 = (rng.normal(0, 1, (Cexp, Cin)) / np.sqrt(Cin)).astype(np.float32)
+    s1 = rng.uniform(0.8, 1.2, Cexp).astype(np.float32)
+    b1 = rng.uniform(-0.1, 0.1, Cexp).astype(np.float32)
+    dww = (rng.normal(0, 1, (Cexp, 3, 3)) / 3).astype(np.float32)
+    s2 = rng.uniform(0.8, 1.2, Cexp).astype(np.float32)
+    b2 = rng.uniform(-0.1, 0.1, Cexp).astype(np.float32)
+    out, pooled, ms = expand_dw_debug(f32_to_bf16(x), w1, s1, b1, dww, s2, b2)
+    xb = torch.from_numpy(bf16_to_f32(f32_to_bf16(x))).permute(0, 3, 1, 2)
+    wf = (torch.from_numpy(w1) * torch.from_numpy(s1)[:, None]).bfloat16().float()
+    e = F.conv2d(xb, wf[:, :, None, None]) + torch.from_numpy(b1).view(1, -1, 1, 1)
+    e = (e * torch.sigmoid(e)).bfloat16().float()
+    wd = (torch.from_numpy(dww) * torch.from_numpy(s2)[:, None, None]).unsqueeze(1)
+    d = F.conv2d(e, wd, padding=1, groups=Cexp) + torch.from_numpy(b2).view(1, -1, 1, 1)
+    d = (d * torch.sigmoid(d)).bfloat16().float()
+    ref = d.permute(0, 2, 3, 1).numpy()
+    got = bf16_to_f32(out)
+    # E differs by at most one bf16 ulp where the f32 sums straddle a rounding boundary; through the
+    # 9-tap depthwise sum that is a few 1e-3 absolute on O(1) values
+    assert np.abs(got - ref).max() < 3e-2 * max(1.0, np.abs(ref).max()), float(np.abs(got - ref).max())
+    assert np.mean(np.abs(got - ref) > 2.0 ** -7 * np.maximum(1.0, np.abs(ref))) < 0.02
+    np.testing.assert_allclose(pooled, got.reshape(B, HW * HW, Cexp).mean(1), rtol=0, atol=1e-5)
