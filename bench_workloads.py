@@ -100,8 +100,9 @@ class _HpeBase:
         W = np.load(os.path.join(_ASSETS, "32_to_122.npy"))
         t0 = time.perf_counter()
         for i in range(n):
-            nk, r, H = ho.crop_params(self.bbox_host[i], K)
-            crop = ho.warp(self.frames_host[i], H[0])
+            j = i % len(self.frames_host)
+            nk, r, H = ho.crop_params(self.bbox_host[j], K)
+            crop = ho.warp(self.frames_host[j], H[0])
             lg = net.head(net.backbone(crop[None]))
             ho.postprocess(lg, nk, r, W, None)
         return (time.perf_counter() - t0) / n

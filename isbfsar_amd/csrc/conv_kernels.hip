@@ -125,13 +125,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(ConvArgs p) 
     constexpr int BM = 32 * TM * WGM;
     constexpr int BN = 32 * TN * WGN;
     constexpr int A_ROWS = NT / 4;                        // tile rows staged per pass (4 x 16-B chunks per row)
-    constexpr int A_PASS = BM / A_ROWS;
+    constexpr int A_PASS = (BM + A_ROWS - 1) / A_ROWS;
     constexpr int B_CHUNKS = BN * 4;
     constexpr int B_PASS = (B_CHUNKS + NT - 1) / NT;
     constexpr int BUF = (BM + BN) * ROWB;
     constexpr int CROW = BN * 2 + 16;                     // staged C tile row (bf16) + pad: conflict-free b64 writes
     constexpr int LDS_BYTES = (2 * BUF > BM * CROW || BM * CROW > 65536) ? 2 * BUF : BM * CROW;
-    static_assert(BM % A_ROWS == 0, "A tile rows must divide evenly over the threads");
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -146,7 +145,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(ConvArgs p) 
 #pragma unroll
     for (int i = 0; i < A_PASS; ++i) {
         const int m = m0 + (tid >> 2) + A_ROWS * i;
-        const bool ok = m < p.M;
+        const bool ok = m < p.M && (tid >> 2) + A_ROWS * i < BM;
         const int mm = ok ? m : 0;
         const int b = mm / ohw, rem = mm - b * ohw;
         const int oy = rem / p.OW, ox = rem - oy * p.OW;
@@ -213,7 +212,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(ConvArgs p) 
                 }
                 v = make_uint4(w[0], w[1], w[2], w[3]);
             }
-            *reinterpret_cast<uint4*>(As + swz((tid >> 2) + A_ROWS * i, chunk)) = v;
+            if ((tid >> 2) + A_ROWS * i < BM) *reinterpret_cast<uint4*>(As + swz((tid >> 2) + A_ROWS * i, chunk)) = v;
         }
 #pragma unroll
         for (int i = 0; i < B_PASS; ++i) {
@@ -557,7 +556,11 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t st) {
         // High occupancy wins on this chip (many waves of 32-row x 64..96-column sub-tiles); projections
         // that carry an SE gate stay on the register-staged kernel and prefer full-width tiles (the big
         // A operand is then read once).
-        if (!a.gate && a.zeros) {
+        if (a.M <= 2048 && a.Cout >= 64) {
+            // latency regime (a single frame): a 128/256-row tile would leave most CUs idle; 64-row tiles
+            // and 64-wide columns give M/64 * Cout/64 workgroups
+            v = (!a.gate && a.zeros) ? 64 : 75;
+        } else if (!a.gate && a.zeros) {
             if (a.Cout == 32) v = 59;                 // 256 x  32, 8 waves
             else if (a.Cout % 192 == 0) v = 54;       // 128 x 192, 8 waves of 32 x 96
             else if (a.Cout % 128 == 0) v = 55;       // 128 x 128, 8 waves of 32 x 64
@@ -574,7 +577,7 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t st) {
             else v = 5;
         }
     }
-    const bool is_dma = (v >= 11 && v <= 39) || (v >= 51 && v <= 59);
+    const bool is_dma = (v >= 11 && v <= 39) || (v >= 51 && v <= 69);
     if (is_dma && (a.gate || !a.zeros)) {
         set_error("conv_igemm: the LDS-DMA variants take no SE gate and need the zero line");
         return ISB_ERR_INVALID;
@@ -601,6 +604,12 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t st) {
         case 45: ISB_CONV_LAUNCH(1, 2, 4, 2); break;     // 128 x 128, 8 waves of 32 x 64
         case 47: ISB_CONV_LAUNCH(1, 4, 4, 2); break;     // 128 x 256, 8 waves
         case 48: ISB_CONV_LAUNCH(1, 7, 4, 2); break;     // 128 x 448, 8 waves
+        case 71: ISB_CONV_LAUNCH(1, 3, 8, 2); break;     // 256 x 192, 16 waves
+        case 75: ISB_CONV_LAUNCH(1, 1, 2, 2); break;     //  64 x  64 (small M)
+        case 76: ISB_CONV_LAUNCH(1, 2, 2, 2); break;     //  64 x 128 (small M)
+        case 72: ISB_CONV_LAUNCH(1, 3, 4, 4); break;     // 128 x 384, 16 waves
+        case 73: ISB_CONV_LAUNCH(1, 5, 4, 4); break;     // 128 x 640, 16 waves
+        case 74: ISB_CONV_LAUNCH(1, 2, 8, 2); break;     // 256 x 128, 16 waves
 #define ISB_CONV_LAUNCH_DMA(TM, TN, WGM, WGN)                                                              \
     do {                                                                                                   \
         dim3 g(cdiv(a.M, 32 * TM * WGM), cdiv(a.Cout, 32 * TN * WGN));                                     \
@@ -624,6 +633,12 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t st) {
         case 57: ISB_CONV_LAUNCH_DMA(1, 2, 8, 1); break;    // 256 x 64
         case 58: ISB_CONV_LAUNCH_DMA(1, 3, 8, 1); break;    // 256 x 96
         case 59: ISB_CONV_LAUNCH_DMA(1, 1, 8, 1); break;    // 256 x 32
+        case 60: ISB_CONV_LAUNCH_DMA(1, 2, 8, 2); break;    // 256 x 128, 16 waves of 32 x 64
+        case 64: ISB_CONV_LAUNCH_DMA(1, 1, 2, 2); break;    //  64 x  64: small-M launches (single frames) need many workgroups
+        case 65: ISB_CONV_LAUNCH_DMA(1, 2, 2, 2); break;    //  64 x 128
+        case 61: ISB_CONV_LAUNCH_DMA(1, 3, 8, 2); break;    // 256 x 192, 16 waves of 32 x 96
+        case 62: ISB_CONV_LAUNCH_DMA(1, 2, 4, 4); break;    // 128 x 256, 16 waves
+        case 63: ISB_CONV_LAUNCH_DMA(1, 3, 4, 4); break;    // 128 x 384, 16 waves
 #undef ISB_CONV_LAUNCH_DMA
 #define ISB_CONV_LAUNCH_RING(TM, TN, WGM, WGN)                                                                \
     do {                                                                                                      \

@@ -44,11 +44,11 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 13, 14, 15, 16, 17, 18, 19, 21, 23, 26, 27, 28, 31, 33, 36, 37, 41, 42, 43, 44, 45, 47, 48, 51, 52, 53, 54, 55, 56, 57, 58, 59])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 13, 14, 15, 16, 17, 18, 19, 21, 23, 26, 27, 28, 31, 33, 36, 37, 41, 42, 43, 44, 45, 47, 48, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63, 64, 65, 71, 72, 73, 74, 75, 76])
 @pytest.mark.parametrize("case", CASES)
 def test_conv_variants(case, variant):
     B, H, Cin, Cout, k, stride, act, use_res, use_gate = case
-    if (11 <= variant <= 39 or 51 <= variant <= 59) and use_gate:
+    if (11 <= variant <= 39 or 51 <= variant <= 69) and use_gate:
         pytest.skip("the LDS-DMA kernels take no SE gate")
     rng = np.random.default_rng(hash((case, 7)) % (2 ** 31))
     x = rng.normal(0, 1, (B, H, H, Cin)).astype(np.float32)
