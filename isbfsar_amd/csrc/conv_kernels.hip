@@ -119,6 +119,24 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
     }
 }
 
+// workgroup -> output tile. Mode 0: 2-D grid. Modes 1/2: 1-D grid; hardware hands consecutive workgroup ids
+// to the 8 XCDs round-robin, so id % 8 names the XCD (and its private L2) a workgroup runs on. Within an XCD
+// the N tiles of one M tile are consecutive: the A rows are fetched into that L2 once and re-read from it.
+__device__ __forceinline__ bool conv_tile_origin(const ConvArgs& p, int BM, int BN, int& m0, int& n0) {
+    if (p.grid_mode == 0) {
+        m0 = blockIdx.x * BM;
+        n0 = blockIdx.y * BN;
+        return true;
+    }
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int nt = slot % p.grid_n, ml = slot / p.grid_n;
+    const int per = (p.grid_m + 7) >> 3;
+    const int mt = p.grid_mode == 1 ? ml * 8 + xcd : xcd * per + ml;
+    m0 = mt * BM;
+    n0 = nt * BN;
+    return mt < p.grid_m;
+}
+
 template <int TM, int TN, int WGM, int WGN>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(ConvArgs p) {
     constexpr int NT = 64 * WGM * WGN;                    // threads: 4 or 8 waves
@@ -136,7 +154,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(ConvArgs p) 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
     const int r = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    int m0, n0;
+    if (!conv_tile_origin(p, BM, BN, m0, n0)) return;
     const int chunk = tid & 3;
 
     // ---- per-thread A rows (fixed over the k loop): pixel coordinates, 32-bit element offsets
@@ -381,26 +400,45 @@ __device__ __forceinline__ void conv_epilogue_dw(const ConvArgs& p, f32x16 (&acc
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
-template <int TM, int TN, int WGM, int WGN, int NB, bool DW = false>
+extern __shared__ __attribute__((aligned(16))) unsigned char conv_lds_dyn[];
+
+// k-tile width KT: 32 (64-B LDS rows, 16 rows per 1-KiB DMA piece) or 64 (128-B rows = whole cache lines per
+// pixel row, 8 rows per piece, half as many barriers and line requests per byte; needs Cin % 64 == 0)
+template <int KT>
+__device__ __forceinline__ int swz_kt(int row, int chunk) {
+    if constexpr (KT == 32) return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);
+    else return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);     // conflict-free for ds_read_b128's 16-lane groups
+}
+
+template <int TM, int TN, int WGM, int WGN, int NB, bool DW = false, bool GATE = false, int KT = 32>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_kernel(ConvArgs p) {
     constexpr int NW = WGM * WGN;
     constexpr int BM = 32 * TM * WGM;
     constexpr int BN = 32 * TN * WGN;
-    constexpr int A_INST = BM / 16, B_INST = BN / 16;    // 1-KiB pieces (16 tile rows) per tile
+    constexpr int ROWB = KT * 2;                          // bytes per LDS row (shadows the 64-B global)
+    constexpr int CPRW = ROWB / 16;                       // 16-B chunks per row
+    constexpr int RPP = 1024 / ROWB;                      // tile rows per 1-KiB DMA piece
+    constexpr int A_INST = BM / RPP, B_INST = BN / RPP;   // pieces per tile
     constexpr int A_PW = (A_INST + NW - 1) / NW, B_PW = (B_INST + NW - 1) / NW;
     constexpr int BUF = (BM + BN) * ROWB;
     constexpr int CROW = BN * 2 + 16;
     constexpr int LDS_PLAIN = (NB * BUF > BM * CROW || BM * CROW > 65536) ? NB * BUF : BM * CROW;
     constexpr int LDS_DW = BM * CROW + (BM / 4) * BN * 4;   // staged E tile + partial pool sums
     constexpr int LDS_BYTES = DW ? (LDS_DW > NB * BUF ? LDS_DW : NB * BUF) : LDS_PLAIN;
-    static_assert(NB == 2 || (A_INST % NW == 0 && B_INST % NW == 0), "ring mode needs the same DMA count in every wave");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+    // counted vmcnt waits (NB > 2) need the same number of DMA instructions in every wave: waves with no
+    // piece left in a pass copy the zero line into a 1-KiB dump area behind the ring
+    constexpr bool PAD_DMA = NB > 2 && (A_INST % NW != 0 || B_INST % NW != 0);
+    constexpr int DUMP_OFF = NB * BUF;
+    constexpr int GATE_OFF = DUMP_OFF + 1024;               // GATE: f32 gate rows of the tile's samples (dynamic LDS)
+    __shared__ __attribute__((aligned(16))) unsigned char lds_static[GATE ? 16 : LDS_BYTES + (PAD_DMA ? 1024 : 0)];
+    unsigned char* const lds = GATE ? conv_lds_dyn : lds_static;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
     const int r = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    int m0, n0;
+    if (!conv_tile_origin(p, BM, BN, m0, n0)) return;
 
     // lane -> (tile row, logical chunk) of the 1-KiB piece it fills: LDS position lane*16 holds
     // physical chunk lane&3 of row lane>>2; the source chunk is the inverse swizzle of that
@@ -408,8 +446,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_kernel(ConvArgs
     const int ohw = p.OH * p.OW;
 #pragma unroll
     for (int s = 0; s < A_PW; ++s) {
-        const int row = 16 * (wave + NW * s) + (lane >> 2);
-        const int logical = (lane & 3) ^ ((row >> 2) & 3);
+        const int row = RPP * (wave + NW * s) + lane / CPRW;
+        const int logical = KT == 32 ? ((lane & 3) ^ ((row >> 2) & 3)) : ((lane & 7) ^ ((row >> 1) & 7));
         const int m = m0 + row;
         const bool ok = m < p.M && row < BM;
         const int mm = ok ? m : 0;
@@ -421,14 +459,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_kernel(ConvArgs
     }
 #pragma unroll
     for (int s = 0; s < B_PW; ++s) {
-        const int row = 16 * (wave + NW * s) + (lane >> 2);
-        const int logical = (lane & 3) ^ ((row >> 2) & 3);
+        const int row = RPP * (wave + NW * s) + lane / CPRW;
+        const int logical = KT == 32 ? ((lane & 3) ^ ((row >> 2) & 3)) : ((lane & 7) ^ ((row >> 1) & 7));
         const int n = n0 + row;
         b_off[s] = (n < p.Cout && row < BN) ? n * p.K + logical * 8 : -1;
     }
 
     auto dma = [&](int kt, int buf) {
-        const int k0 = kt * CK;
+        const int k0 = kt * KT;
         const int tap = k0 / p.Cin;
         const int c0 = k0 - tap * p.Cin;
         const int ky = tap / p.KW, kx = tap - ky * p.KW;
@@ -442,6 +480,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_kernel(ConvArgs
                 const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
                 const uint16_t* src = ok ? p.in + (a_off[s] + tap_off) : p.zeros;
                 __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(base + q * 1024), 16, 0, 0);
+            } else if constexpr (PAD_DMA) {
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)p.zeros, (lds_ptr_t)(lds + DUMP_OFF), 16, 0, 0);
             }
         }
 #pragma unroll
@@ -450,6 +490,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_kernel(ConvArgs
             if (q < B_INST) {
                 const uint16_t* src = b_off[s] >= 0 ? p.w + (b_off[s] + k0) : p.zeros;
                 __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(base + BM * ROWB + q * 1024), 16, 0, 0);
+            } else if constexpr (PAD_DMA) {
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)p.zeros, (lds_ptr_t)(lds + DUMP_OFF), 16, 0, 0);
             }
         }
     };
@@ -462,18 +504,44 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_kernel(ConvArgs
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    auto compute = [&](int cur) {
+    // SE gate (GATE): the f32 gate rows of the samples this tile covers sit in LDS; the A fragment is scaled
+    // as it leaves LDS, bf16(f32(x) * g) exactly as the register-staged kernel does at its LDS store
+    int g_row[TM];
+    if constexpr (GATE) {
+        const int s_first = m0 / ohw;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = min(m0 + (wm * TM + i) * 32 + r, p.M - 1);
+            g_row[i] = (m / ohw - s_first) * p.Cin + 8 * h;
+        }
+    }
+    auto compute = [&](int cur, int kt) {
         const unsigned char* As = lds + cur * BUF;
         const unsigned char* Bs = As + BM * ROWB;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < KT / 16; ++ks) {
             bf16x8 af[TM], bfr[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(As + swz((wm * TM + i) * 32 + r, 2 * ks + h)));
+            for (int i = 0; i < TM; ++i) {
+                uint4 v = *reinterpret_cast<const uint4*>(As + swz_kt<KT>((wm * TM + i) * 32 + r, 2 * ks + h));
+                if constexpr (GATE) {
+                    const float* gs = reinterpret_cast<const float*>(lds + GATE_OFF) + g_row[i] + kt * KT + ks * 16;
+                    const float4 g0 = *reinterpret_cast<const float4*>(gs), g1 = *reinterpret_cast<const float4*>(gs + 4);
+                    const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float lo = bf2f_((uint16_t)(w[e] & 0xffff)) * gg[2 * e];
+                        const float hi = bf2f_((uint16_t)(w[e] >> 16)) * gg[2 * e + 1];
+                        w[e] = (uint32_t)f2bf_(lo) | ((uint32_t)f2bf_(hi) << 16);
+                    }
+                    v = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+                af[i] = __builtin_bit_cast(bf16x8, v);
+            }
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Bs + swz((wn * TN + j) * 32 + r, 2 * ks + h)));
+                bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Bs + swz_kt<KT>((wn * TN + j) * 32 + r, 2 * ks + h)));
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -482,14 +550,26 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_kernel(ConvArgs
         }
     };
 
-    const int nkt = p.K / CK;
+    const int nkt = p.K / KT;
+    auto stage_gate = [&]() {      // after the first DMAs are in flight; the barrier that publishes tile 0 publishes this too
+        if constexpr (GATE) {
+            const int s_first = m0 / ohw;
+            const int ns = min(m0 + BM - 1, p.M - 1) / ohw - s_first + 1;
+            const float* src = p.gate + (size_t)s_first * p.Cin;
+            float* dst = reinterpret_cast<float*>(lds + GATE_OFF);
+            for (int idx = tid * 4; idx < ns * p.Cin; idx += 64 * NW * 4)
+                *reinterpret_cast<float4*>(dst + idx) = *reinterpret_cast<const float4*>(src + idx);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // written before the (raw) barrier that publishes tile 0
+        }
+    };
     if constexpr (NB == 2) {
         dma(0, 0);
+        stage_gate();
         __syncthreads();
         for (int kt = 0; kt < nkt; ++kt) {
             const int cur = kt & 1;
             if (kt + 1 < nkt) dma(kt + 1, cur ^ 1);
-            compute(cur);
+            compute(cur, kt);
             __syncthreads();
         }
     } else if constexpr (NB == 3) {
@@ -499,6 +579,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_kernel(ConvArgs
         // consumed) behind every wave's reads.
         constexpr int PER = A_PW + B_PW;
         dma(0, 0);
+        stage_gate();
         if (nkt > 1) {
             dma(1, 1);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
@@ -508,7 +589,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_kernel(ConvArgs
         __builtin_amdgcn_s_barrier();
         for (int kt = 0; kt < nkt; ++kt) {
             if (kt + 2 < nkt) dma(kt + 2, (kt + 2) % 3);
-            compute(kt % 3);
+            compute(kt % 3, kt);
             if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -521,6 +602,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_kernel(ConvArgs
         // __syncthreads() would drain the DMA queue.
         constexpr int D = NB - 2;
         constexpr int PER = A_PW + B_PW;                    // DMA instructions per wave per tile
+        if constexpr (GATE) {      // plain loads first: the counted waits below then cover them (loads return in order)
+            stage_gate();
+        }
 #pragma unroll
         for (int t = 0; t < D; ++t)
             if (t < nkt) dma(t, t);
@@ -531,7 +615,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_kernel(ConvArgs
             else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            compute(kt % NB);
+            compute(kt % NB, kt);
         }
         __syncthreads();                                    // all MFMA reads done before the tile staging reuses LDS
     }
@@ -539,7 +623,27 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_kernel(ConvArgs
     else conv_epilogue<TM, TN, WGM, WGN>(p, acc, lds, m0, n0, wm, wn, r, h, tid);
 }
 
+static int conv_grid_mode() {
+    static const int mode = [] {
+        const char* e = getenv("ISB_CONV_GRID");     // tuning override; 1 measured 4 % faster than the 2-D grid
+        return e ? atoi(e) : 1;
+    }();
+    return mode;
+}
+
+static dim3 conv_grid(ConvArgs& a, int BM, int BN) {
+    a.grid_m = cdiv(a.M, BM);
+    a.grid_n = cdiv(a.Cout, BN);
+    if (a.grid_mode == 0 || a.grid_n == 1) {
+        a.grid_mode = 0;
+        return dim3(a.grid_m, a.grid_n);
+    }
+    return dim3(8 * ((a.grid_m + 7) / 8) * a.grid_n);
+}
+
 int launch_conv_igemm(const ConvArgs& a, hipStream_t st) {
+    ConvArgs aa = a;
+    aa.grid_mode = conv_grid_mode();
     if (a.Cin % 32 != 0 || a.Cout % 32 != 0 || a.K != a.KH * a.KW * a.Cin || a.M <= 0) {
         set_error("conv_igemm: unsupported shape Cin=%d Cout=%d K=%d M=%d", a.Cin, a.Cout, a.K, a.M);
         return ISB_ERR_INVALID;
@@ -578,14 +682,50 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t st) {
         }
     }
     const bool is_dma = (v >= 11 && v <= 39) || (v >= 51 && v <= 69);
-    if (is_dma && (a.gate || !a.zeros)) {
-        set_error("conv_igemm: the LDS-DMA variants take no SE gate and need the zero line");
+    const bool is_gdma = (v >= 81 && v <= 99) || (v >= 111 && v <= 119);
+    const bool is_dma64 = v >= 101 && v <= 109;
+    if ((is_dma64 || v >= 111) && a.Cin % 64 != 0) {
+        set_error("conv_igemm: the 64-wide k-tile variants need Cin %% 64 == 0 (Cin=%d)", a.Cin);
         return ISB_ERR_INVALID;
     }
+    if (is_dma64 && (a.gate || !a.zeros)) {
+        set_error("conv_igemm: variants 101-109 take no SE gate and need the zero line");
+        return ISB_ERR_INVALID;
+    }
+    if (is_dma && (a.gate || !a.zeros)) {
+        set_error("conv_igemm: the plain LDS-DMA variants take no SE gate and need the zero line");
+        return ISB_ERR_INVALID;
+    }
+    if (is_gdma && (!a.gate || !a.zeros)) {
+        set_error("conv_igemm: variants 81-99 and 111-119 are the gated LDS-DMA kernels");
+        return ISB_ERR_INVALID;
+    }
+    // gated LDS-DMA kernels: ring of NB tile buffers + dump KiB + the f32 gate rows of the samples a tile covers
+#define ISB_CONV_LAUNCH_GATE(TM, TN, WGM, WGN, NB, KT)                                                                \
+    do {                                                                                                            \
+        constexpr int BM_ = 32 * TM * WGM, BN_ = 32 * TN * WGN;                                                     \
+        const int ohw = a.OH * a.OW;                                                                                \
+        if (ohw % BM_ != 0 && BM_ % ohw != 0) {                                                                     \
+            set_error("conv_igemm: gated tile of %d rows does not align with %d-pixel samples", BM_, ohw);          \
+            return ISB_ERR_INVALID;                                                                                 \
+        }                                                                                                           \
+        const int ns = BM_ > ohw ? BM_ / ohw : 1;                                                                   \
+        const int ring = NB * (BM_ + BN_) * (KT * 2) + 1024 + ns * a.Cin * 4;                                       \
+        const int stage = BM_ * (BN_ * 2 + 16);                                                                     \
+        const int bytes = ring > stage ? ring : stage;                                                              \
+        auto kern = conv_igemm_dma_kernel<TM, TN, WGM, WGN, NB, false, true, KT>;                                   \
+        static int attr_bytes = 0;                                                                                  \
+        if (bytes > attr_bytes) {                                                                                   \
+            ISB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));     \
+            attr_bytes = bytes;                                                                                     \
+        }                                                                                                           \
+        const dim3 g = conv_grid(aa, BM_, BN_);                                                                     \
+        hipLaunchKernelGGL(kern, g, dim3(64 * WGM * WGN), bytes, st, aa);                                           \
+    } while (0)
 #define ISB_CONV_LAUNCH(TM, TN, WGM, WGN)                                                              \
     do {                                                                                               \
-        dim3 g(cdiv(a.M, 32 * TM * WGM), cdiv(a.Cout, 32 * TN * WGN));                                 \
-        hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, WGM, WGN>), g, dim3(64 * WGM * WGN), 0, st, a); \
+        const dim3 g = conv_grid(aa, 32 * TM * WGM, 32 * TN * WGN);                                 \
+        hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, WGM, WGN>), g, dim3(64 * WGM * WGN), 0, st, aa); \
     } while (0)
     switch (v) {
         case 1: ISB_CONV_LAUNCH(2, 2, 2, 2); break;      // 128 x 128, 4 waves
@@ -612,8 +752,8 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t st) {
         case 74: ISB_CONV_LAUNCH(1, 2, 8, 2); break;     // 256 x 128, 16 waves
 #define ISB_CONV_LAUNCH_DMA(TM, TN, WGM, WGN)                                                              \
     do {                                                                                                   \
-        dim3 g(cdiv(a.M, 32 * TM * WGM), cdiv(a.Cout, 32 * TN * WGN));                                     \
-        hipLaunchKernelGGL((conv_igemm_dma_kernel<TM, TN, WGM, WGN, 2>), g, dim3(64 * WGM * WGN), 0, st, a); \
+        const dim3 g = conv_grid(aa, 32 * TM * WGM, 32 * TN * WGN);                                     \
+        hipLaunchKernelGGL((conv_igemm_dma_kernel<TM, TN, WGM, WGN, 2>), g, dim3(64 * WGM * WGN), 0, st, aa); \
     } while (0)
         case 11: ISB_CONV_LAUNCH_DMA(2, 2, 2, 2); break;
         case 12: ISB_CONV_LAUNCH_DMA(1, 3, 4, 1); break;
@@ -642,13 +782,13 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t st) {
 #undef ISB_CONV_LAUNCH_DMA
 #define ISB_CONV_LAUNCH_RING(TM, TN, WGM, WGN)                                                                \
     do {                                                                                                      \
-        dim3 g(cdiv(a.M, 32 * TM * WGM), cdiv(a.Cout, 32 * TN * WGN));                                        \
-        hipLaunchKernelGGL((conv_igemm_dma_kernel<TM, TN, WGM, WGN, 4>), g, dim3(64 * WGM * WGN), 0, st, a); \
+        const dim3 g = conv_grid(aa, 32 * TM * WGM, 32 * TN * WGN);                                        \
+        hipLaunchKernelGGL((conv_igemm_dma_kernel<TM, TN, WGM, WGN, 4>), g, dim3(64 * WGM * WGN), 0, st, aa); \
     } while (0)
 #define ISB_CONV_LAUNCH_3B(TM, TN, WGM, WGN)                                                                  \
     do {                                                                                                      \
-        dim3 g(cdiv(a.M, 32 * TM * WGM), cdiv(a.Cout, 32 * TN * WGN));                                        \
-        hipLaunchKernelGGL((conv_igemm_dma_kernel<TM, TN, WGM, WGN, 3>), g, dim3(64 * WGM * WGN), 0, st, a); \
+        const dim3 g = conv_grid(aa, 32 * TM * WGM, 32 * TN * WGN);                                        \
+        hipLaunchKernelGGL((conv_igemm_dma_kernel<TM, TN, WGM, WGN, 3>), g, dim3(64 * WGM * WGN), 0, st, aa); \
     } while (0)
         case 31: ISB_CONV_LAUNCH_3B(2, 2, 2, 2); break;     // 128 x 128, 4 waves, 3 buffers / 2 tiles in flight
         case 33: ISB_CONV_LAUNCH_3B(2, 1, 2, 2); break;     // 128 x  64
@@ -661,6 +801,39 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t st) {
         case 27: ISB_CONV_LAUNCH_RING(4, 2, 2, 4); break;   // 256 x 256, 8 waves
         case 28: ISB_CONV_LAUNCH_RING(4, 1, 2, 4); break;   // 256 x 128 as 2x4 waves of 128x32
 #undef ISB_CONV_LAUNCH_RING
+        case 81: ISB_CONV_LAUNCH_GATE(1, 2, 4, 2, 4, 32); break;   // 128 x 128, 8 waves, 4-buffer ring
+        case 82: ISB_CONV_LAUNCH_GATE(1, 3, 4, 2, 4, 32); break;   // 128 x 192
+        case 83: ISB_CONV_LAUNCH_GATE(1, 7, 4, 1, 4, 32); break;   // 128 x 224
+        case 84: ISB_CONV_LAUNCH_GATE(1, 5, 4, 2, 4, 32); break;   // 128 x 320
+        case 85: ISB_CONV_LAUNCH_GATE(1, 2, 2, 2, 4, 32); break;   //  64 x 128, 4 waves
+        case 86: ISB_CONV_LAUNCH_GATE(1, 3, 2, 2, 4, 32); break;   //  64 x 192
+        case 91: ISB_CONV_LAUNCH_GATE(1, 2, 4, 2, 2, 32); break;   // the same tiles with two buffers
+        case 92: ISB_CONV_LAUNCH_GATE(1, 3, 4, 2, 2, 32); break;
+        case 93: ISB_CONV_LAUNCH_GATE(1, 7, 4, 1, 2, 32); break;
+        case 94: ISB_CONV_LAUNCH_GATE(1, 5, 4, 2, 2, 32); break;
+        case 95: ISB_CONV_LAUNCH_GATE(1, 2, 2, 2, 2, 32); break;
+        case 96: ISB_CONV_LAUNCH_GATE(1, 3, 2, 2, 2, 32); break;
+        case 111: ISB_CONV_LAUNCH_GATE(1, 3, 4, 2, 2, 64); break;  // 64-wide k-tiles (128-B rows): 128 x 192
+        case 112: ISB_CONV_LAUNCH_GATE(1, 2, 4, 2, 2, 64); break;  // 128 x 128
+        case 113: ISB_CONV_LAUNCH_GATE(1, 7, 4, 1, 2, 64); break;  // 128 x 224
+        case 114: ISB_CONV_LAUNCH_GATE(1, 5, 4, 2, 2, 64); break;  // 128 x 320
+        case 115: ISB_CONV_LAUNCH_GATE(1, 3, 2, 2, 2, 64); break;  //  64 x 192
+        case 116: ISB_CONV_LAUNCH_GATE(1, 2, 2, 2, 2, 64); break;  //  64 x 128
+#undef ISB_CONV_LAUNCH_GATE
+#define ISB_CONV_LAUNCH_DMA64(TM, TN, WGM, WGN)                                                                        \
+    do {                                                                                                               \
+        const dim3 g = conv_grid(aa, 32 * TM * WGM, 32 * TN * WGN);                                                    \
+        hipLaunchKernelGGL((conv_igemm_dma_kernel<TM, TN, WGM, WGN, 2, false, false, 64>), g, dim3(64 * WGM * WGN), 0, st, aa); \
+    } while (0)
+        case 101: ISB_CONV_LAUNCH_DMA64(1, 3, 4, 2); break;   // 128 x 192, 64-wide k-tiles
+        case 102: ISB_CONV_LAUNCH_DMA64(1, 2, 4, 2); break;   // 128 x 128
+        case 103: ISB_CONV_LAUNCH_DMA64(2, 2, 4, 2); break;   // 256 x 128
+        case 104: ISB_CONV_LAUNCH_DMA64(1, 2, 8, 1); break;   // 256 x  64
+        case 105: ISB_CONV_LAUNCH_DMA64(1, 7, 4, 1); break;   // 128 x 224
+        case 106: ISB_CONV_LAUNCH_DMA64(1, 3, 2, 2); break;   //  64 x 192
+        case 107: ISB_CONV_LAUNCH_DMA64(1, 2, 2, 2); break;   //  64 x 128
+        case 108: ISB_CONV_LAUNCH_DMA64(2, 3, 4, 2); break;   // 256 x 192
+#undef ISB_CONV_LAUNCH_DMA64
         default:
             set_error("conv_igemm: unknown tile variant %d", v);
             return ISB_ERR_INVALID;
@@ -677,12 +850,14 @@ int launch_conv_expand_dw(const ConvArgs& a, hipStream_t st) {
         set_error("conv_expand_dw: needs an un-gated stride-1 1x1 expand conv with depthwise weights");
         return ISB_ERR_INVALID;
     }
+    ConvArgs aa = a;
+    aa.grid_mode = 0;
     if (hw == 256 && a.Cout % 64 == 0) {           // one 16x16 sample per tile: 256 x 64, 8 waves
         dim3 g(a.B, a.Cout / 64);
-        hipLaunchKernelGGL((conv_igemm_dma_kernel<1, 2, 8, 1, 2, true>), g, dim3(512), 0, st, a);
+        hipLaunchKernelGGL((conv_igemm_dma_kernel<1, 2, 8, 1, 2, true>), g, dim3(512), 0, st, aa);
     } else if (hw == 64 && a.Cout % 128 == 0) {    // one 8x8 sample per tile: 64 x 128, 4 waves
         dim3 g(a.B, a.Cout / 128);
-        hipLaunchKernelGGL((conv_igemm_dma_kernel<1, 2, 2, 2, 2, true>), g, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((conv_igemm_dma_kernel<1, 2, 2, 2, 2, true>), g, dim3(256), 0, st, aa);
     } else {
         set_error("conv_expand_dw: unsupported shape hw=%d Cout=%d", hw, a.Cout);
         return ISB_ERR_INVALID;
@@ -803,82 +978,130 @@ int launch_dwconv3x3(const DwArgs& a, hipStream_t st) {
 }
 
 // =====================================================================================
-// squeeze-excite FCs in f32 on the vector ALU (tiny GEMMs: latency, not FLOPs, is what matters)
-//   se_fc1: mid[b][j]  = silu(b1[j] + sum_c pooled[b][c] * W1[j][c])    wave = (4 j, 8 samples)
-//   se_fc2: gate[b][c] = sigmoid(b2[c] + sum_j mid[b][j] * W2T[j][c])   thread = (c, 4 samples)
-// fixed summation order -> independent of scheduling and of how the batch is sharded
+// squeeze-excite FCs in f32 on the vector ALU. Two tiny GEMMs (B x cse x C, 0.1 GFLOP) between a
+// global pool and the gated projection: what costs is latency and parallelism, not FLOPs.
+//   se_fc1_part: part[kc][b][j] = sum_{c in chunk kc} pooled[b][c] * W1[j][c]
+//                WG = 16 samples x 16 outputs x one 256-channel chunk, operands staged in LDS once
+//                (grid = cse/16 x B/16 x C/256 workgroups: every CU gets work, each makes ONE round trip)
+//   se_fc2:      mid[b][j]  = silu(b1[j] + sum_kc part[kc][b][j])           (prologue, fixed order)
+//                gate[b][c] = sigmoid(b2[c] + sum_j mid[b][j] * W2T[j][c])
+//                WG = 8 samples x 256 channels; lane = 4 channels (16-B weight loads), the 4 waves split j,
+//                partial sums meet in LDS and are added in wave order
+// every sum runs in a fixed order that depends on neither scheduling nor the batch size
 // =====================================================================================
-__global__ __launch_bounds__(256) void se_fc1_kernel(SeFcArgs p) {
-    // wave = 4 outputs j x 8 samples: every weight / activation vector fetched from L2 feeds 8 / 4 FMAs
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j0 = (blockIdx.x * 4 + wave) * 4;
-    const int b0 = blockIdx.y * 8;
-    if (j0 >= p.cse) return;
-    float acc[4][8];
+constexpr int SE_CHUNK = 256;      // channels per fc1 workgroup
+constexpr int SE_ROW = SE_CHUNK + 4;   // LDS row stride in floats (1040 B: consecutive rows land in consecutive 16-B slots)
+
+__global__ __launch_bounds__(256) void se_fc1_part_kernel(SeFcArgs p) {
+    __shared__ __attribute__((aligned(16))) float Ps[16][SE_ROW];
+    __shared__ __attribute__((aligned(16))) float Ws[16][SE_ROW];
+    const int t = threadIdx.x;
+    const int j0 = blockIdx.x * 16, b0 = blockIdx.y * 16, c0 = blockIdx.z * SE_CHUNK;
+    {
+        const int row = t >> 4, q = (t & 15) * 4;
+        const int b = b0 + row, j = j0 + row;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int s = 0; s < 8; ++s) acc[q][s] = 0.f;
-    for (int c = lane * 4; c < p.C; c += 256) {
-        float4 wv[4], xv[8];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            wv[q] = *reinterpret_cast<const float4*>(p.w1 + (size_t)min(j0 + q, p.cse - 1) * p.C + c);
-#pragma unroll
-        for (int s = 0; s < 8; ++s)
-            xv[s] = *reinterpret_cast<const float4*>(p.pooled + (size_t)min(b0 + s, p.B - 1) * p.C + c);
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int s = 0; s < 8; ++s)
-                acc[q][s] = fmaf(xv[s].x, wv[q].x, fmaf(xv[s].y, wv[q].y, fmaf(xv[s].z, wv[q].z, fmaf(xv[s].w, wv[q].w, acc[q][s]))));
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            float v = acc[q][s];
-#pragma unroll
-            for (int sh = 32; sh >= 1; sh >>= 1) v += __shfl_xor(v, sh, 64);
-            if (lane == 0 && j0 + q < p.cse && b0 + s < p.B) {
-                v += p.b1[j0 + q];
-                p.mid[(size_t)(b0 + s) * p.cse + j0 + q] = v / (1.0f + expf(-v));
+        for (int pass = 0; pass < 4; ++pass) {
+            const int cl = pass * 64 + q, c = c0 + cl;
+            float4 pv = make_float4(0.f, 0.f, 0.f, 0.f), wv = pv;
+            if (c < p.C) {
+                if (b < p.B) pv = *reinterpret_cast<const float4*>(p.pooled + (size_t)b * p.C + c);
+                if (j < p.cse) wv = *reinterpret_cast<const float4*>(p.w1 + (size_t)j * p.C + c);
             }
+            *reinterpret_cast<float4*>(&Ps[row][cl]) = pv;
+            *reinterpret_cast<float4*>(&Ws[row][cl]) = wv;
         }
+    }
+    __syncthreads();
+    const int s = t >> 4, jl = t & 15;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int c4 = 0; c4 < SE_CHUNK / 4; ++c4) {
+        const float4 pv = *reinterpret_cast<const float4*>(&Ps[s][c4 * 4]);
+        const float4 wv = *reinterpret_cast<const float4*>(&Ws[jl][c4 * 4]);
+        acc = fmaf(pv.x, wv.x, acc);
+        acc = fmaf(pv.y, wv.y, acc);
+        acc = fmaf(pv.z, wv.z, acc);
+        acc = fmaf(pv.w, wv.w, acc);
+    }
+    const int b = b0 + s, j = j0 + jl;
+    if (b < p.B && j < p.cse) p.part[((size_t)blockIdx.z * p.B + b) * p.cse + j] = acc;
 }
 
 __global__ __launch_bounds__(256) void se_fc2_kernel(SeFcArgs p) {
-    __shared__ float mids[4][160];
-    const int b0 = blockIdx.y * 4;
-    for (int i = threadIdx.x; i < 4 * p.cse; i += 256) {
-        const int s = i / p.cse, j = i - s * p.cse;
-        mids[s][j] = (b0 + s < p.B) ? p.mid[(size_t)(b0 + s) * p.cse + j] : 0.f;
+    __shared__ __attribute__((aligned(16))) float mids[160][8];          // [j][sample]
+    __shared__ __attribute__((aligned(16))) float4 red[4][8][64];        // [wave][sample][lane]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int b0 = blockIdx.y * 8;
+    const int nkc = (p.C + SE_CHUNK - 1) / SE_CHUNK;
+    for (int i = t; i < 8 * p.cse; i += 256) {
+        const int sm = i / p.cse, j = i - sm * p.cse;
+        float v = 0.f;
+        if (b0 + sm < p.B) {
+            float pv[15];                      // all chunk partials requested at once (one memory round trip), added in order
+#pragma unroll
+            for (int kc = 0; kc < 15; ++kc) pv[kc] = kc < nkc ? p.part[((size_t)kc * p.B + b0 + sm) * p.cse + j] : 0.f;
+            v = p.b1[j];
+#pragma unroll
+            for (int kc = 0; kc < 15; ++kc) v += pv[kc];
+            v = v / (1.0f + expf(-v));
+        }
+        mids[j][sm] = v;
     }
     __syncthreads();
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= p.C) return;
-    float acc[4];
-    const float bias = p.b2[c];
+    const int c = blockIdx.x * 256 + lane * 4;
+    const bool cok = c < p.C;
+    const int jq = (p.cse + 3) >> 2;
+    const int jb = wave * jq, je = min(p.cse, jb + jq);
+    float4 acc[8];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) acc[s] = bias;
+    for (int sm = 0; sm < 8; ++sm) acc[sm] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cok) {
 #pragma unroll 8
-    for (int j = 0; j < p.cse; ++j) {
-        const float wv = p.w2t[(size_t)j * p.C + c];
+        for (int j = jb; j < je; ++j) {
+            const float4 wv = *reinterpret_cast<const float4*>(p.w2t + (size_t)j * p.C + c);
+            const float4 m0 = *reinterpret_cast<const float4*>(&mids[j][0]);
+            const float4 m1 = *reinterpret_cast<const float4*>(&mids[j][4]);
+            const float mm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc[s] = fmaf(mids[s][j], wv, acc[s]);
+            for (int sm = 0; sm < 8; ++sm) {
+                acc[sm].x = fmaf(mm[sm], wv.x, acc[sm].x);
+                acc[sm].y = fmaf(mm[sm], wv.y, acc[sm].y);
+                acc[sm].z = fmaf(mm[sm], wv.z, acc[sm].z);
+                acc[sm].w = fmaf(mm[sm], wv.w, acc[sm].w);
+            }
+        }
     }
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
-        if (b0 + s < p.B) p.gate[(size_t)(b0 + s) * p.C + c] = 1.0f / (1.0f + expf(-acc[s]));
+    for (int sm = 0; sm < 8; ++sm) red[wave][sm][lane] = acc[sm];
+    __syncthreads();
+    if (!cok) return;
+    const float4 bias = *reinterpret_cast<const float4*>(p.b2 + c);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int sm = wave * 2 + q;
+        if (b0 + sm >= p.B) continue;
+        float4 v = red[0][sm][lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float4 u = red[w][sm][lane];
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        v.x = 1.0f / (1.0f + expf(-(v.x + bias.x)));
+        v.y = 1.0f / (1.0f + expf(-(v.y + bias.y)));
+        v.z = 1.0f / (1.0f + expf(-(v.z + bias.z)));
+        v.w = 1.0f / (1.0f + expf(-(v.w + bias.w)));
+        *reinterpret_cast<float4*>(p.gate + (size_t)(b0 + sm) * p.C + c) = v;
+    }
 }
 
 int launch_se_fcs(const SeFcArgs& a, hipStream_t st) {
-    if (a.cse > 160 || a.C % 4 != 0) {
+    if (a.cse > 160 || a.C % 4 != 0 || a.C > 15 * SE_CHUNK || !a.part) {
         set_error("se_fcs: unsupported shape cse=%d C=%d", a.cse, a.C);
         return ISB_ERR_INVALID;
     }
-    hipLaunchKernelGGL(se_fc1_kernel, dim3(cdiv(a.cse, 16), cdiv(a.B, 8)), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(se_fc2_kernel, dim3(cdiv(a.C, 256), cdiv(a.B, 4)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(se_fc1_part_kernel, dim3(cdiv(a.cse, 16), cdiv(a.B, 16), cdiv(a.C, SE_CHUNK)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(se_fc2_kernel, dim3(cdiv(a.C, 256), cdiv(a.B, 8)), dim3(256), 0, st, a);
     ISB_LAUNCHED("se_fcs", st);
     return ISB_OK;
 }

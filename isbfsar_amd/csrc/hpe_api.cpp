@@ -27,10 +27,20 @@ struct BlockW {
 
 // public efficientnetv2-l table (mirrors isbfsar_amd/effnetv2.py::STAGES)
 struct StageDef { bool fused; int repeats, expand, stride, cin, cout; bool se; };
+constexpr int kMinSplit = 64;     // a batch this large is run as two concurrent halves
 const StageDef kStages[] = {
     {true, 4, 1, 1, 32, 32, false},   {true, 7, 4, 2, 32, 64, false},   {true, 7, 4, 2, 64, 96, false},
     {false, 10, 4, 2, 96, 192, true}, {false, 19, 6, 1, 192, 224, true}, {false, 25, 6, 2, 224, 384, true},
     {false, 7, 6, 1, 384, 640, true},
+};
+
+// activation workspace of one micro-batch in flight. Two lanes on two streams run two halves of a batch
+// concurrently: while one half sits in a bandwidth-bound kernel (depthwise conv, SE, tile write-back) the
+// other half's GEMM tiles keep the matrix cores busy.
+struct Lane {
+    hipStream_t side = nullptr;   // lane 1 only: its own stream, forked from / joined into the caller's
+    int ws_B = 0;
+    DevBuf H, newK, R, crops, bufX, bufY, bufE, bufD, pooled, semid, gate, feat, logits;
 };
 
 }  // namespace
@@ -50,11 +60,11 @@ struct isb_hpe {
     DevBuf head_w, head_b;
     DevBuf expand, indices;
     bool has_indices = false;
-    // workspace (per micro-batch)
-    int ws_B = 0;
+    // workspace
     DevBuf zeros;
-    DevBuf H, newK, R, crops, bufX, bufY, bufE, bufD, pooled, semid, gate, feat, logits;
-    DevBuf frames_tmp, bbox_tmp, joints_tmp, valid_tmp;
+    Lane lanes[2];
+    int n_lanes = 2;              // ISB_HPE_LANES=1 disables the split
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
     // profiling of conv_igemm launches
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
@@ -88,23 +98,23 @@ int upload_conv(const std::map<std::string, BlobTensor>& m, const std::string& p
     return ISB_OK;
 }
 
-int ensure_ws(isb_hpe* h, int Bm) {
-    if (Bm <= h->ws_B) return ISB_OK;
+int ensure_ws(Lane& L, int Bm) {
+    if (Bm <= L.ws_B) return ISB_OK;
     const size_t B = Bm;
-    ISB_TRY(h->H.alloc(B * 9 * 4));
-    ISB_TRY(h->newK.alloc(B * 9 * 8));
-    ISB_TRY(h->R.alloc(B * 9 * 8));
-    ISB_TRY(h->crops.alloc(B * 256 * 256 * 3 * 4));
-    ISB_TRY(h->bufX.alloc(B * 128 * 128 * 32 * 2));
-    ISB_TRY(h->bufY.alloc(B * 128 * 128 * 32 * 2));
-    ISB_TRY(h->bufE.alloc(B * 64 * 64 * 256 * 2));
-    ISB_TRY(h->bufD.alloc(B * 32 * 32 * 384 * 2));
-    ISB_TRY(h->pooled.alloc(B * 3840 * 4));
-    ISB_TRY(h->semid.alloc(B * 160 * 4));
-    ISB_TRY(h->gate.alloc(B * 3840 * 4));
-    ISB_TRY(h->feat.alloc(B * 64 * 1280 * 4));
-    ISB_TRY(h->logits.alloc(B * 64 * 288 * 4));
-    h->ws_B = Bm;
+    ISB_TRY(L.H.alloc(B * 9 * 4));
+    ISB_TRY(L.newK.alloc(B * 9 * 8));
+    ISB_TRY(L.R.alloc(B * 9 * 8));
+    ISB_TRY(L.crops.alloc(B * 256 * 256 * 3 * 4));
+    ISB_TRY(L.bufX.alloc(B * 128 * 128 * 32 * 2));
+    ISB_TRY(L.bufY.alloc(B * 128 * 128 * 32 * 2));
+    ISB_TRY(L.bufE.alloc(B * 64 * 64 * 256 * 2));
+    ISB_TRY(L.bufD.alloc(B * 32 * 32 * 384 * 2));
+    ISB_TRY(L.pooled.alloc(B * 3840 * 4));
+    ISB_TRY(L.semid.alloc(B * 160 * 15 * 4));       // SE fc1 partial sums: 15 chunks of 256 channels x 160 outputs
+    ISB_TRY(L.gate.alloc(B * 3840 * 4));
+    ISB_TRY(L.feat.alloc(B * 64 * 1280 * 4));
+    ISB_TRY(L.logits.alloc(B * 64 * 288 * 4));
+    L.ws_B = Bm;
     return ISB_OK;
 }
 
@@ -143,13 +153,13 @@ int gemm(hipStream_t st, const float* A, int lda, const float* W, int ldw, const
 }
 
 // crops f32 [B,256,256,3] (device) -> feat f32 [B*64,1280], logits f32 [B*64,288]
-int run_backbone(isb_hpe* h, hipStream_t st, const float* crops, int B) {
+int run_backbone(isb_hpe* h, Lane& L, hipStream_t st, const float* crops, int B) {
     StemArgs sa{};
-    sa.in = crops; sa.w = h->stem_w.as<float>(); sa.bias = h->stem_b.as<float>(); sa.out = h->bufX.as<uint16_t>();
+    sa.in = crops; sa.w = h->stem_w.as<float>(); sa.bias = h->stem_b.as<float>(); sa.out = L.bufX.as<uint16_t>();
     sa.B = B; sa.H = 256; sa.W = 256;
     ISB_TRY(launch_stem(sa, st));
-    void* X = h->bufX.p;
-    void* Y = h->bufY.p;
+    void* X = L.bufX.p;
+    void* Y = L.bufY.p;
     for (auto& up : h->blocks) {
         BlockW& b = *up;
         const void* res = b.residual ? X : nullptr;
@@ -157,8 +167,8 @@ int run_backbone(isb_hpe* h, hipStream_t st, const float* crops, int B) {
             if (b.cexp == b.cin) {
                 ISB_TRY(conv(h, st, b.expand, X, B, b.in_hw, b.in_hw, b.stride, true, res, nullptr, Y, false));
             } else {
-                ISB_TRY(conv(h, st, b.expand, X, B, b.in_hw, b.in_hw, b.stride, true, nullptr, nullptr, h->bufE.p, false));
-                ISB_TRY(conv(h, st, b.project, h->bufE.p, B, b.out_hw, b.out_hw, 1, false, res, nullptr, Y, false));
+                ISB_TRY(conv(h, st, b.expand, X, B, b.in_hw, b.in_hw, b.stride, true, nullptr, nullptr, L.bufE.p, false));
+                ISB_TRY(conv(h, st, b.project, L.bufE.p, B, b.out_hw, b.out_hw, 1, false, res, nullptr, Y, false));
             }
         } else {
             if (b.stride == 1 && h->fuse_front) {
@@ -168,8 +178,8 @@ int run_backbone(isb_hpe* h, hipStream_t st, const float* crops, int B) {
                 a.B = B; a.H = b.in_hw; a.W = b.in_hw; a.Cin = b.cin; a.Cout = b.cexp; a.KH = 1; a.KW = 1; a.stride = 1;
                 a.OH = b.in_hw; a.OW = b.in_hw; a.pad = 0; a.M = B * b.in_hw * b.in_hw; a.K = b.cin; a.act = 1;
                 a.zeros = h->zeros.as<uint16_t>();
-                a.dw_w = b.dw_w.as<float>(); a.dw_bias = b.dw_b.as<float>(); a.dw_out = h->bufD.as<uint16_t>();
-                a.pooled = h->pooled.as<float>();
+                a.dw_w = b.dw_w.as<float>(); a.dw_bias = b.dw_b.as<float>(); a.dw_out = L.bufD.as<uint16_t>();
+                a.pooled = L.pooled.as<float>();
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (h->prof) {
                     ISB_HIP(hipEventCreate(&e0));
@@ -183,50 +193,50 @@ int run_backbone(isb_hpe* h, hipStream_t st, const float* crops, int B) {
                     h->prof_launches += 1;
                 }
             } else {
-                ISB_TRY(conv(h, st, b.expand, X, B, b.in_hw, b.in_hw, 1, true, nullptr, nullptr, h->bufE.p, false));
+                ISB_TRY(conv(h, st, b.expand, X, B, b.in_hw, b.in_hw, 1, true, nullptr, nullptr, L.bufE.p, false));
                 DwArgs d{};
-                d.in = h->bufE.as<uint16_t>(); d.w = b.dw_w.as<float>(); d.bias = b.dw_b.as<float>(); d.out = h->bufD.as<uint16_t>();
+                d.in = L.bufE.as<uint16_t>(); d.w = b.dw_w.as<float>(); d.bias = b.dw_b.as<float>(); d.out = L.bufD.as<uint16_t>();
                 d.B = B; d.H = b.in_hw; d.W = b.in_hw; d.C = b.cexp; d.OH = b.out_hw; d.OW = b.out_hw; d.stride = b.stride;
                 d.pad = b.stride == 1 ? 1 : 0;
-                d.pooled = h->pooled.as<float>();
+                d.pooled = L.pooled.as<float>();
                 ISB_TRY(launch_dwconv3x3(d, st));
             }
             SeFcArgs se{};
-            se.pooled = h->pooled.as<float>(); se.w1 = b.se_w1.as<float>(); se.b1 = b.se_b1.as<float>();
-            se.w2t = b.se_w2.as<float>(); se.b2 = b.se_b2.as<float>(); se.mid = h->semid.as<float>();
-            se.gate = h->gate.as<float>(); se.B = B; se.C = b.cexp; se.cse = b.cse;
+            se.pooled = L.pooled.as<float>(); se.w1 = b.se_w1.as<float>(); se.b1 = b.se_b1.as<float>();
+            se.w2t = b.se_w2.as<float>(); se.b2 = b.se_b2.as<float>(); se.part = L.semid.as<float>();
+            se.gate = L.gate.as<float>(); se.B = B; se.C = b.cexp; se.cse = b.cse;
             ISB_TRY(launch_se_fcs(se, st));
-            ISB_TRY(conv(h, st, b.project, h->bufD.p, B, b.out_hw, b.out_hw, 1, false, res, h->gate.as<float>(), Y, false));
+            ISB_TRY(conv(h, st, b.project, L.bufD.p, B, b.out_hw, b.out_hw, 1, false, res, L.gate.as<float>(), Y, false));
         }
         std::swap(X, Y);
     }
-    ISB_TRY(conv(h, st, h->headconv, X, B, 8, 8, 1, true, nullptr, nullptr, h->feat.p, true));
-    ISB_TRY(gemm(st, h->feat.as<float>(), 1280, h->head_w.as<float>(), 1280, h->head_b.as<float>(), h->logits.as<float>(), 288,
+    ISB_TRY(conv(h, st, h->headconv, X, B, 8, 8, 1, true, nullptr, nullptr, L.feat.p, true));
+    ISB_TRY(gemm(st, L.feat.as<float>(), 1280, h->head_w.as<float>(), 1280, h->head_b.as<float>(), L.logits.as<float>(), 288,
                  B * 64, 288, 1280, GEMM_ACT_NONE));
     return ISB_OK;
 }
 
-int run_post(isb_hpe* h, hipStream_t st, const float* logits, int B, float* joints, uint8_t* valid, double* dbg,
+int run_post(isb_hpe* h, Lane& L, hipStream_t st, const float* logits, int B, float* joints, uint8_t* valid, double* dbg,
              const int32_t* bbox = nullptr) {
     PostArgs a{};
     a.bbox = bbox;
-    a.logits = logits; a.newK = h->newK.as<double>(); a.R = h->R.as<double>(); a.expand = h->expand.as<float>();
+    a.logits = logits; a.newK = L.newK.as<double>(); a.R = L.R.as<double>(); a.expand = h->expand.as<float>();
     a.indices = h->has_indices ? h->indices.as<int32_t>() : nullptr;
     a.joints = joints; a.valid = valid; a.dbg = dbg; a.B = B; a.n_out = h->n_out;
     return launch_hpe_post(a, st);
 }
 
-int run_crop_params(isb_hpe* h, hipStream_t st, const int32_t* d_bbox, int B) {
+int run_crop_params(isb_hpe* h, Lane& L, hipStream_t st, const int32_t* d_bbox, int B) {
     CropParamArgs a{};
     a.bbox = d_bbox;
     for (int i = 0; i < 9; ++i) a.K[i] = h->K[i];
-    a.H = h->H.as<float>(); a.newK = h->newK.as<double>(); a.R = h->R.as<double>(); a.B = B;
+    a.H = L.H.as<float>(); a.newK = L.newK.as<double>(); a.R = L.R.as<double>(); a.B = B;
     return launch_crop_params(a, st);
 }
 
-int run_warp(isb_hpe* h, hipStream_t st, const uint8_t* d_frames, int B) {
+int run_warp(isb_hpe* h, Lane& L, hipStream_t st, const uint8_t* d_frames, int B) {
     WarpArgs a{};
-    a.frames = d_frames; a.H = h->H.as<float>(); a.crops = h->crops.as<float>();
+    a.frames = d_frames; a.H = L.H.as<float>(); a.crops = L.crops.as<float>();
     a.B = B; a.FH = h->cfg.height; a.FW = h->cfg.width;
     return launch_warp(a, st);
 }
@@ -253,6 +263,10 @@ extern "C" int isb_hpe_create(const isb_hpe_cfg* cfg, isb_hpe** out) {
     ISB_TRY(h->zeros.alloc(256));
     ISB_HIP(hipMemset(h->zeros.p, 0, 256));
     h->fuse_front = getenv("ISB_FUSE_FRONT") != nullptr;
+    if (const char* e = getenv("ISB_HPE_LANES")) h->n_lanes = atoi(e) >= 2 ? 2 : 1;
+    ISB_HIP(hipStreamCreateWithFlags(&h->lanes[1].side, hipStreamNonBlocking));
+    ISB_HIP(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
+    ISB_HIP(hipEventCreateWithFlags(&h->join_ev, hipEventDisableTiming));
     *out = h.release();
     return ISB_OK;
     });
@@ -267,6 +281,9 @@ extern "C" void isb_hpe_destroy(isb_hpe* h) {
         (void)hipEventDestroy(e.second);
     }
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    if (h->lanes[1].side) (void)hipStreamDestroy(h->lanes[1].side);
+    if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
+    if (h->join_ev) (void)hipEventDestroy(h->join_ev);
     delete h;
 }
 
@@ -384,15 +401,31 @@ extern "C" int isb_hpe_forward(isb_hpe* h, const uint8_t* d_frames, const int32_
     ISB_HIP(hipSetDevice(h->cfg.device));
     hipStream_t st = (hipStream_t)stream;   // NULL = the HIP null stream (torch's default stream)
     const int Bm_max = std::min<int>(B, h->cfg.max_batch);
-    ISB_TRY(ensure_ws(h, Bm_max));
     const size_t fsz = (size_t)h->cfg.height * h->cfg.width * 3;
+    auto run_lane = [&](Lane& L, hipStream_t s, int b0, int Bm) -> int {
+        ISB_TRY(ensure_ws(L, Bm));
+        ISB_TRY(run_crop_params(h, L, s, d_bbox + (size_t)b0 * 4, Bm));
+        ISB_TRY(run_warp(h, L, s, d_frames + (size_t)b0 * fsz, Bm));
+        ISB_TRY(run_backbone(h, L, s, L.crops.as<float>(), Bm));
+        return run_post(h, L, s, L.logits.as<float>(), Bm, d_joints + (size_t)b0 * h->n_out * 3, d_valid + b0, nullptr,
+                        d_bbox + (size_t)b0 * 4);
+    };
     for (int b0 = 0; b0 < B; b0 += Bm_max) {
         const int Bm = std::min(Bm_max, B - b0);
-        ISB_TRY(run_crop_params(h, st, d_bbox + (size_t)b0 * 4, Bm));
-        ISB_TRY(run_warp(h, st, d_frames + (size_t)b0 * fsz, Bm));
-        ISB_TRY(run_backbone(h, st, h->crops.as<float>(), Bm));
-        ISB_TRY(run_post(h, st, h->logits.as<float>(), Bm, d_joints + (size_t)b0 * h->n_out * 3, d_valid + b0, nullptr,
-                         d_bbox + (size_t)b0 * 4));
+        // every sample is independent, so the split changes no result. Small batches (latency regime) and the
+        // per-launch profiling pass stay on one lane.
+        if (h->n_lanes >= 2 && Bm >= kMinSplit && !h->prof) {
+            const int B0 = (Bm + 1) / 2;
+            Lane& L1 = h->lanes[1];
+            ISB_HIP(hipEventRecord(h->fork_ev, st));
+            ISB_HIP(hipStreamWaitEvent(L1.side, h->fork_ev, 0));
+            ISB_TRY(run_lane(L1, L1.side, b0 + B0, Bm - B0));
+            ISB_TRY(run_lane(h->lanes[0], st, b0, B0));
+            ISB_HIP(hipEventRecord(h->join_ev, L1.side));
+            ISB_HIP(hipStreamWaitEvent(st, h->join_ev, 0));
+        } else {
+            ISB_TRY(run_lane(h->lanes[0], st, b0, Bm));
+        }
     }
     return ISB_OK;
     });
@@ -428,15 +461,16 @@ extern "C" int isb_hpe_crop_params_host(isb_hpe* h, const int32_t* bbox, int32_t
     ISB_REQUIRE(h && bbox && H && newK && R && B >= 1, ISB_ERR_INVALID, "bad argument");
     ISB_HIP(hipSetDevice(h->cfg.device));
     hipStream_t st = h->own_stream;
-    ISB_TRY(ensure_ws(h, std::min<int>(B, h->cfg.max_batch)));
-    ISB_REQUIRE(B <= h->ws_B, ISB_ERR_INVALID, "B %d exceeds max_batch %d", B, h->cfg.max_batch);
+    Lane& L = h->lanes[0];
+    ISB_TRY(ensure_ws(L, std::min<int>(B, h->cfg.max_batch)));
+    ISB_REQUIRE(B <= L.ws_B, ISB_ERR_INVALID, "B %d exceeds max_batch %d", B, h->cfg.max_batch);
     DevBuf db;
     ISB_TRY(upload(db, bbox, (size_t)B * 16));
-    ISB_TRY(run_crop_params(h, st, db.as<int32_t>(), B));
+    ISB_TRY(run_crop_params(h, L, st, db.as<int32_t>(), B));
     ISB_HIP(hipStreamSynchronize(st));
-    ISB_HIP(hipMemcpy(H, h->H.p, (size_t)B * 36, hipMemcpyDeviceToHost));
-    ISB_HIP(hipMemcpy(newK, h->newK.p, (size_t)B * 72, hipMemcpyDeviceToHost));
-    ISB_HIP(hipMemcpy(R, h->R.p, (size_t)B * 72, hipMemcpyDeviceToHost));
+    ISB_HIP(hipMemcpy(H, L.H.p, (size_t)B * 36, hipMemcpyDeviceToHost));
+    ISB_HIP(hipMemcpy(newK, L.newK.p, (size_t)B * 72, hipMemcpyDeviceToHost));
+    ISB_HIP(hipMemcpy(R, L.R.p, (size_t)B * 72, hipMemcpyDeviceToHost));
     return ISB_OK;
     });
 }
@@ -446,16 +480,17 @@ extern "C" int isb_hpe_warp_host(isb_hpe* h, const uint8_t* frames, const int32_
     ISB_REQUIRE(h && frames && bbox && crops && B >= 1, ISB_ERR_INVALID, "bad argument");
     ISB_HIP(hipSetDevice(h->cfg.device));
     hipStream_t st = h->own_stream;
-    ISB_TRY(ensure_ws(h, std::min<int>(B, h->cfg.max_batch)));
-    ISB_REQUIRE(B <= h->ws_B, ISB_ERR_INVALID, "B %d exceeds max_batch %d", B, h->cfg.max_batch);
+    Lane& L = h->lanes[0];
+    ISB_TRY(ensure_ws(L, std::min<int>(B, h->cfg.max_batch)));
+    ISB_REQUIRE(B <= L.ws_B, ISB_ERR_INVALID, "B %d exceeds max_batch %d", B, h->cfg.max_batch);
     const size_t fsz = (size_t)h->cfg.height * h->cfg.width * 3;
     DevBuf df, db;
     ISB_TRY(upload(df, frames, fsz * B));
     ISB_TRY(upload(db, bbox, (size_t)B * 16));
-    ISB_TRY(run_crop_params(h, st, db.as<int32_t>(), B));
-    ISB_TRY(run_warp(h, st, df.as<uint8_t>(), B));
+    ISB_TRY(run_crop_params(h, L, st, db.as<int32_t>(), B));
+    ISB_TRY(run_warp(h, L, st, df.as<uint8_t>(), B));
     ISB_HIP(hipStreamSynchronize(st));
-    ISB_HIP(hipMemcpy(crops, h->crops.p, (size_t)B * 256 * 256 * 3 * 4, hipMemcpyDeviceToHost));
+    ISB_HIP(hipMemcpy(crops, L.crops.p, (size_t)B * 256 * 256 * 3 * 4, hipMemcpyDeviceToHost));
     return ISB_OK;
     });
 }
@@ -466,13 +501,14 @@ extern "C" int isb_hpe_backbone_host(isb_hpe* h, const float* crops, int32_t B, 
     ISB_REQUIRE(h->weights, ISB_ERR_STATE, "isb_hpe_backbone_host before isb_hpe_load_weights");
     ISB_HIP(hipSetDevice(h->cfg.device));
     hipStream_t st = h->own_stream;
-    ISB_TRY(ensure_ws(h, std::min<int>(B, h->cfg.max_batch)));
-    ISB_REQUIRE(B <= h->ws_B, ISB_ERR_INVALID, "B %d exceeds max_batch %d", B, h->cfg.max_batch);
-    ISB_HIP(hipMemcpy(h->crops.p, crops, (size_t)B * 256 * 256 * 3 * 4, hipMemcpyHostToDevice));
-    ISB_TRY(run_backbone(h, st, h->crops.as<float>(), B));
+    Lane& L = h->lanes[0];
+    ISB_TRY(ensure_ws(L, std::min<int>(B, h->cfg.max_batch)));
+    ISB_REQUIRE(B <= L.ws_B, ISB_ERR_INVALID, "B %d exceeds max_batch %d", B, h->cfg.max_batch);
+    ISB_HIP(hipMemcpy(L.crops.p, crops, (size_t)B * 256 * 256 * 3 * 4, hipMemcpyHostToDevice));
+    ISB_TRY(run_backbone(h, L, st, L.crops.as<float>(), B));
     ISB_HIP(hipStreamSynchronize(st));
-    if (features) ISB_HIP(hipMemcpy(features, h->feat.p, (size_t)B * 64 * 1280 * 4, hipMemcpyDeviceToHost));
-    if (logits) ISB_HIP(hipMemcpy(logits, h->logits.p, (size_t)B * 64 * 288 * 4, hipMemcpyDeviceToHost));
+    if (features) ISB_HIP(hipMemcpy(features, L.feat.p, (size_t)B * 64 * 1280 * 4, hipMemcpyDeviceToHost));
+    if (logits) ISB_HIP(hipMemcpy(logits, L.logits.p, (size_t)B * 64 * 288 * 4, hipMemcpyDeviceToHost));
     return ISB_OK;
     });
 }
@@ -484,16 +520,17 @@ extern "C" int isb_hpe_post_host(isb_hpe* h, const float* logits, const int32_t*
     ISB_REQUIRE(h->jointmap, ISB_ERR_STATE, "isb_hpe_post_host before isb_hpe_set_joint_map");
     ISB_HIP(hipSetDevice(h->cfg.device));
     hipStream_t st = h->own_stream;
-    ISB_TRY(ensure_ws(h, std::min<int>(B, h->cfg.max_batch)));
-    ISB_REQUIRE(B <= h->ws_B, ISB_ERR_INVALID, "B %d exceeds max_batch %d", B, h->cfg.max_batch);
+    Lane& L = h->lanes[0];
+    ISB_TRY(ensure_ws(L, std::min<int>(B, h->cfg.max_batch)));
+    ISB_REQUIRE(B <= L.ws_B, ISB_ERR_INVALID, "B %d exceeds max_batch %d", B, h->cfg.max_batch);
     DevBuf db, dl, dj, dv, dd;
     ISB_TRY(upload(db, bbox, (size_t)B * 16));
     ISB_TRY(upload(dl, logits, (size_t)B * 64 * 288 * 4));
     ISB_TRY(dj.alloc((size_t)B * h->n_out * 12));
     ISB_TRY(dv.alloc((size_t)B));
     if (pred) ISB_TRY(dd.alloc((size_t)B * 32 * 5 * 8));
-    ISB_TRY(run_crop_params(h, st, db.as<int32_t>(), B));
-    ISB_TRY(run_post(h, st, dl.as<float>(), B, dj.as<float>(), dv.as<uint8_t>(), pred ? dd.as<double>() : nullptr));
+    ISB_TRY(run_crop_params(h, L, st, db.as<int32_t>(), B));
+    ISB_TRY(run_post(h, L, st, dl.as<float>(), B, dj.as<float>(), dv.as<uint8_t>(), pred ? dd.as<double>() : nullptr));
     ISB_HIP(hipStreamSynchronize(st));
     ISB_HIP(hipMemcpy(joints, dj.p, (size_t)B * h->n_out * 12, hipMemcpyDeviceToHost));
     ISB_HIP(hipMemcpy(valid, dv.p, (size_t)B, hipMemcpyDeviceToHost));

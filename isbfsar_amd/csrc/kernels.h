@@ -128,6 +128,10 @@ struct ConvArgs {
     const float* dw_bias;   // f32 [Cout]
     uint16_t* dw_out;       // bf16 [B,OH,OW,Cout] depthwise output D
     float* pooled;          // f32 [B,Cout] spatial mean of D
+    // workgroup -> tile mapping (set by launch_conv_igemm): 0 = (blockIdx.x, blockIdx.y) = (M tile, N tile);
+    // 1/2 = 1-D grid decoded per XCD (workgroup id % 8 = XCD): all N tiles of an M tile run back to back on
+    // ONE XCD, so its L2 fetches the A rows once (1: M tiles interleaved over XCDs, 2: contiguous M ranges)
+    int grid_mode, grid_m, grid_n;
 };
 int launch_conv_igemm(const ConvArgs& a, hipStream_t st);
 int launch_conv_expand_dw(const ConvArgs& a, hipStream_t st);
@@ -148,7 +152,7 @@ struct SeFcArgs {
     const float* b1;        // [cse]
     const float* w2t;       // [cse,C]  (se.w2 transposed)
     const float* b2;        // [C]
-    float* mid;             // [B,cse]
+    float* part;            // scratch [ceil(C/256), B, cse]: fc1 partial sums per 256-channel chunk
     float* gate;            // out [B,C]
     int B, C, cse;
 };

@@ -239,6 +239,25 @@ def test_shard_invariance(eng_w):
     assert np.array_equal(np.concatenate([j_a, j_b]), j_all) and np.array_equal(np.concatenate([v_a, v_b]), v_all)
 
 
+def test_two_lane_split_is_bit_identical(bbone_state, assets):
+    """A batch >= 64 runs as two halves on two streams (hpe_api.cpp lanes); every frame is independent,
+    so the poses equal those of the same frames pushed through one lane in small batches."""
+    from isbfsar_amd.hpe_engine import HpeEngine
+    e = HpeEngine(device=0, max_batch=80)
+    try:
+        e.set_joint_map(assets[0], assets[1]["smpl+head_30"]["indices"])
+        e.load_weights(bbone_state)
+        fr = synth.frames(70, seed=300)
+        bb = synth.bboxes(70, seed=300)
+        j_all, v_all = e.forward(fr, bb)                       # 35 + 35 on two lanes
+        parts = [e.forward(fr[i:i + 14], bb[i:i + 14]) for i in range(0, 70, 14)]   # one lane
+        assert np.array_equal(np.concatenate([p[0] for p in parts]), j_all)
+        assert np.array_equal(np.concatenate([p[1] for p in parts]), v_all)
+        assert v_all.sum() > 0
+    finally:
+        e.close()
+
+
 def test_pose_windows_kernel():
     import torch
     from isbfsar_amd.hpe_engine import pose_windows
