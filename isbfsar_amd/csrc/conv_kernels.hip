@@ -402,6 +402,18 @@ typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
 extern __shared__ __attribute__((aligned(16))) unsigned char conv_lds_dyn[];
 
+// One LDS-DMA instruction (1 KiB per wave: lane l's 16 bytes land at ldst + 16 l), issued through inline asm.
+// Through __builtin_amdgcn_global_load_lds the compiler sees an LDS store and orders EVERY later LDS read behind
+// it (s_waitcnt vmcnt(0) before the first ds_read of each k-step): the tile just requested was waited for before
+// the MFMAs of the current one, and nothing overlapped. Hidden in asm, completion is ours to track: every
+// consumer below waits with an explicit (counted) s_waitcnt vmcnt before the barrier that publishes a tile.
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned char* ldst) {
+    const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_ptr_t)ldst);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(la) : "memory");   // m0 is reserved: the compiler
+    // writes it immediately before each of its own uses and keeps nothing live in it
+}
+
+
 // k-tile width KT: 32 (64-B LDS rows, 16 rows per 1-KiB DMA piece) or 64 (128-B rows = whole cache lines per
 // pixel row, 8 rows per piece, half as many barriers and line requests per byte; needs Cin % 64 == 0)
 template <int KT>
@@ -479,9 +491,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_kernel(ConvArgs
                 const int iy = a_iy[s] + ky, ix = a_ix[s] + kx;
                 const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
                 const uint16_t* src = ok ? p.in + (a_off[s] + tap_off) : p.zeros;
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(base + q * 1024), 16, 0, 0);
+                dma16(src, base + q * 1024);
             } else if constexpr (PAD_DMA) {
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)p.zeros, (lds_ptr_t)(lds + DUMP_OFF), 16, 0, 0);
+                dma16(p.zeros, lds + DUMP_OFF);
             }
         }
 #pragma unroll
@@ -489,9 +501,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_kernel(ConvArgs
             const int q = wave + NW * s;
             if (q < B_INST) {
                 const uint16_t* src = b_off[s] >= 0 ? p.w + (b_off[s] + k0) : p.zeros;
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(base + BM * ROWB + q * 1024), 16, 0, 0);
+                dma16(src, base + BM * ROWB + q * 1024);
             } else if constexpr (PAD_DMA) {
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)p.zeros, (lds_ptr_t)(lds + DUMP_OFF), 16, 0, 0);
+                dma16(p.zeros, lds + DUMP_OFF);
             }
         }
     };
@@ -565,11 +577,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_kernel(ConvArgs
     if constexpr (NB == 2) {
         dma(0, 0);
         stage_gate();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         for (int kt = 0; kt < nkt; ++kt) {
             const int cur = kt & 1;
-            if (kt + 1 < nkt) dma(kt + 1, cur ^ 1);
+            if (kt + 1 < nkt) dma(kt + 1, cur ^ 1);     // in flight during this tile's MFMAs
             compute(cur, kt);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
     } else if constexpr (NB == 3) {
@@ -623,6 +637,164 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_kernel(ConvArgs
     else conv_epilogue<TM, TN, WGM, WGN>(p, acc, lds, m0, n0, wm, wn, r, h, tid);
 }
 
+// -------------------------------------------------------------------------------------------
+// 1x1 convolutions without an SE gate = plain GEMMs out[M,Cout] = in[M,Cin] . w[Cout,Cin]^T. PMC counters on the
+// general kernel above (profiles/README.md) show its waves spend 5x more issue cycles on bookkeeping (tap
+// arithmetic, 64-bit addresses, zero-line selects: ~190 scalar+vector instructions per k-step) than on the 6 MFMAs
+// the step exists for. Here the k loop is stripped to what a GEMM needs:
+//   * a lane's source offset never changes (row * Cin * 2 + swizzled chunk, rows past the edge clamped: their
+//     results are never stored), so each DMA is "scalar base + 32-bit lane offset" and the scalar base just
+//     advances 64 bytes per step: no vector instruction per DMA;
+//   * the k loop is unrolled by two, so buffer offsets are immediates of ds_read_b128 and the fragment addresses
+//     are four registers computed once;
+//   * per step: 3 DMA + 8 ds_read + 6 MFMA + ~10 scalar instructions (128 x 192 tile).
+// -------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dma16_s(const void* sbase, uint32_t voff, uint32_t lds_addr) {
+    const uint32_t la = __builtin_amdgcn_readfirstlane(lds_addr);
+    const uint64_t b = (uint64_t)(uintptr_t)sbase;          // wave-uniform by construction; make the compiler see it
+    const uint32_t b_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
+    const uint32_t b_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);   // the builtin returns int: widen unsigned
+    const uint64_t sb = ((uint64_t)b_hi << 32) | (uint64_t)b_lo;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sb), "s"(la) : "memory");
+}
+
+template <int TM, int TN, int WGM, int WGN, bool GATE = false>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_dma_kernel(ConvArgs p) {
+    constexpr int NW = WGM * WGN;
+    constexpr int BM = 32 * TM * WGM;
+    constexpr int BN = 32 * TN * WGN;
+    constexpr int A_INST = BM / 16, B_INST = BN / 16;
+    constexpr int A_PW = (A_INST + NW - 1) / NW, B_PW = (B_INST + NW - 1) / NW;
+    constexpr int BUF = (BM + BN) * ROWB;
+    constexpr int CROW = BN * 2 + 16;
+    constexpr int LDS_BYTES = (2 * BUF > BM * CROW || BM * CROW > 65536) ? 2 * BUF : BM * CROW;
+    constexpr int GATE_OFF = 2 * BUF;                       // GATE: f32 gate rows of the tile's samples (dynamic LDS)
+    __shared__ __attribute__((aligned(16))) unsigned char lds_static[GATE ? 16 : LDS_BYTES];
+    unsigned char* const lds = GATE ? conv_lds_dyn : lds_static;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int r = lane & 31, h = lane >> 5;
+    int m0, n0;
+    if (!conv_tile_origin(p, BM, BN, m0, n0)) return;
+
+    uint32_t a_voff[A_PW], b_voff[B_PW];
+#pragma unroll
+    for (int s = 0; s < A_PW; ++s) {
+        const int row = 16 * (wave + NW * s) + (lane >> 2);
+        const int logical = (lane & 3) ^ ((row >> 2) & 3);
+        a_voff[s] = (uint32_t)min(m0 + row, p.M - 1) * (uint32_t)(p.Cin * 2) + logical * 16;
+    }
+#pragma unroll
+    for (int s = 0; s < B_PW; ++s) {
+        const int row = 16 * (wave + NW * s) + (lane >> 2);
+        const int logical = (lane & 3) ^ ((row >> 2) & 3);
+        b_voff[s] = (uint32_t)min(n0 + row, p.Cout - 1) * (uint32_t)(p.Cin * 2) + logical * 16;
+    }
+    const unsigned char* a_base = reinterpret_cast<const unsigned char*>(p.in);
+    const unsigned char* b_base = reinterpret_cast<const unsigned char*>(p.w);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)lds + wave * 1024;
+    auto dma = [&](auto bufc) {                 // requests the NEXT 32 channels, then advances the scalar bases
+        constexpr int buf = decltype(bufc)::value;
+#pragma unroll
+        for (int s = 0; s < A_PW; ++s)
+            if (wave + NW * s < A_INST) dma16_s(a_base, a_voff[s], lds0 + (buf * BUF + NW * s * 1024));
+#pragma unroll
+        for (int s = 0; s < B_PW; ++s)
+            if (wave + NW * s < B_INST) dma16_s(b_base, b_voff[s], lds0 + (buf * BUF + BM * ROWB + NW * s * 1024));
+        a_base += CK * 2;
+        b_base += CK * 2;
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // fragment addresses: row blocks of 32 are 2048 bytes apart and leave the swizzle untouched -> immediates
+    int a_sw[2], b_sw[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        a_sw[ks] = swz(wm * TM * 32 + r, 2 * ks + h);
+        b_sw[ks] = BM * ROWB + swz(wn * TN * 32 + r, 2 * ks + h);
+    }
+    // SE gate: the A fragment is scaled as it leaves LDS, bf16(f32(x) * g), exactly what the register-staged
+    // kernel does at its LDS store. g_row: float offset of this lane's sample row (+ its 8-channel half)
+    dma(std::integral_constant<int, 0>{});      // first tile in flight while the gate rows are staged
+    int g_row[TM];
+    int kt_now = 0;
+    if constexpr (GATE) {
+        const int ohw = p.OH * p.OW;
+        const int s_first = m0 / ohw;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) g_row[i] = (min(m0 + (wm * TM + i) * 32 + r, p.M - 1) / ohw - s_first) * p.Cin + 8 * h;
+        const int ns = min(m0 + BM - 1, p.M - 1) / ohw - s_first + 1;
+        const float* src = p.gate + (size_t)s_first * p.Cin;
+        float* dst = reinterpret_cast<float*>(lds + GATE_OFF);
+        for (int idx = tid * 4; idx < ns * p.Cin; idx += 64 * NW * 4)
+            *reinterpret_cast<float4*>(dst + idx) = *reinterpret_cast<const float4*>(src + idx);
+    }
+    auto compute = [&](auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[TM], bfr[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                uint4 v = *reinterpret_cast<const uint4*>(lds + a_sw[ks] + (buf * BUF + i * 2048));
+                if constexpr (GATE) {
+                    const float* gs = reinterpret_cast<const float*>(lds + GATE_OFF) + g_row[i] + kt_now * CK + ks * 16;
+                    const float4 g0 = *reinterpret_cast<const float4*>(gs), g1 = *reinterpret_cast<const float4*>(gs + 4);
+                    const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float lo = bf2f_((uint16_t)(w[e] & 0xffff)) * gg[2 * e];
+                        const float hi = bf2f_((uint16_t)(w[e] >> 16)) * gg[2 * e + 1];
+                        w[e] = (uint32_t)f2bf_(lo) | ((uint32_t)f2bf_(hi) << 16);
+                    }
+                    v = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+                af[i] = __builtin_bit_cast(bf16x8, v);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + b_sw[ks] + (buf * BUF + j * 2048)));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        ++kt_now;
+    };
+    auto publish = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+
+    const int nkt = p.Cin / CK;
+    publish();
+    int kt = 0;
+    for (; kt + 2 <= nkt; kt += 2) {            // straight-line body: tile kt in buffer 0, tile kt+1 in buffer 1
+        dma(std::integral_constant<int, 1>{});
+        compute(std::integral_constant<int, 0>{});
+        publish();
+        if (kt + 2 < nkt) dma(std::integral_constant<int, 0>{});
+        compute(std::integral_constant<int, 1>{});
+        publish();
+    }
+    if (kt < nkt) {                             // odd tail: requested into buffer 0 and published above
+        compute(std::integral_constant<int, 0>{});
+        __syncthreads();
+    }
+    conv_epilogue<TM, TN, WGM, WGN>(p, acc, lds, m0, n0, wm, wn, r, h, tid);
+}
+
 static int conv_grid_mode() {
     static const int mode = [] {
         const char* e = getenv("ISB_CONV_GRID");     // tuning override; 1 measured 4 % faster than the 2-D grid
@@ -655,15 +827,28 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t st) {
     // tile variants: 0 = pick by Cout
     int v = a.variant;
     if (v == 0) {
-        // measured on MI355X (tools/conv_sweep.py, profiles/): without an SE gate the LDS-DMA kernels win,
-        // 8-wave 256-row tiles for wide outputs; gated projections stay on the register-staged kernel
-        // High occupancy wins on this chip (many waves of 32-row x 64..96-column sub-tiles); projections
-        // that carry an SE gate stay on the register-staged kernel and prefer full-width tiles (the big
-        // A operand is then read once).
+        // chosen by measurement on MI355X (tools/conv_sweep.py, tools/conv_probe*.py, profiles/README.md):
+        //   * 1x1 stride-1 convolutions are plain GEMMs and run on the lean gemm1x1 kernels (131-139 without,
+        //     141-148 with an SE gate), 8 waves of 32 x 64..96 sub-tiles: high occupancy beats big tiles here;
+        //   * 3x3 convolutions (implicit GEMM with taps and padding) stay on the general LDS-DMA kernels;
+        //   * a single frame (M <= 2048) needs many small workgroups: 64-row tiles.
+        const bool g1 = a.KH == 1 && a.stride == 1 && a.pad == 0 && a.zeros;
+        const int ohw = a.OH * a.OW;
         if (a.M <= 2048 && a.Cout >= 64) {
-            // latency regime (a single frame): a 128/256-row tile would leave most CUs idle; 64-row tiles
-            // and 64-wide columns give M/64 * Cout/64 workgroups
-            v = (!a.gate && a.zeros) ? 64 : 75;
+            if (g1 && !a.gate) v = 138;
+            else if (g1 && a.gate && ohw % 64 == 0) v = 147;
+            else v = (!a.gate && a.zeros) ? 64 : 75;
+        } else if (g1 && !a.gate) {
+            if (a.Cout % 192 == 0) v = 131;            // 128 x 192
+            else if (a.Cout == 64) v = 135;            // 256 x  64
+            else if (a.Cout == 224) v = 137;           // 128 x 224
+            else if (a.Cout == 32) v = 59;
+            else v = 132;                              // 128 x 128
+        } else if (g1 && a.gate && (ohw % 128 == 0 || 128 % ohw == 0)) {
+            if (a.Cout % 320 == 0) v = 144;            // 128 x 320
+            else if (a.Cout == 224) v = 143;           // 128 x 224
+            else if (a.Cout % 192 == 0) v = 141;       // 128 x 192
+            else v = 142;                              // 128 x 128
         } else if (!a.gate && a.zeros) {
             if (a.Cout == 32) v = 59;                 // 256 x  32, 8 waves
             else if (a.Cout % 192 == 0) v = 54;       // 128 x 192, 8 waves of 32 x 96
@@ -684,7 +869,7 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t st) {
     const bool is_dma = (v >= 11 && v <= 39) || (v >= 51 && v <= 69);
     const bool is_gdma = (v >= 81 && v <= 99) || (v >= 111 && v <= 119);
     const bool is_dma64 = v >= 101 && v <= 109;
-    if ((is_dma64 || v >= 111) && a.Cin % 64 != 0) {
+    if ((is_dma64 || (v >= 111 && v <= 119)) && a.Cin % 64 != 0) {
         set_error("conv_igemm: the 64-wide k-tile variants need Cin %% 64 == 0 (Cin=%d)", a.Cin);
         return ISB_ERR_INVALID;
     }
@@ -834,6 +1019,55 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t st) {
         case 107: ISB_CONV_LAUNCH_DMA64(1, 2, 2, 2); break;   //  64 x 128
         case 108: ISB_CONV_LAUNCH_DMA64(2, 3, 4, 2); break;   // 256 x 192
 #undef ISB_CONV_LAUNCH_DMA64
+#define ISB_CONV_LAUNCH_G1(TM, TN, WGM, WGN)                                                                     \
+    do {                                                                                                         \
+        if (a.gate || a.KH != 1 || a.stride != 1 || a.pad != 0) {                                                \
+            set_error("conv_igemm: variants 131-139 are un-gated 1x1 stride-1 GEMMs");                           \
+            return ISB_ERR_INVALID;                                                                              \
+        }                                                                                                        \
+        const dim3 g = conv_grid(aa, 32 * TM * WGM, 32 * TN * WGN);                                              \
+        hipLaunchKernelGGL((gemm1x1_dma_kernel<TM, TN, WGM, WGN>), g, dim3(64 * WGM * WGN), 0, st, aa);          \
+    } while (0)
+        case 131: ISB_CONV_LAUNCH_G1(1, 3, 4, 2); break;   // 128 x 192
+        case 132: ISB_CONV_LAUNCH_G1(1, 2, 4, 2); break;   // 128 x 128
+        case 133: ISB_CONV_LAUNCH_G1(2, 3, 4, 2); break;   // 256 x 192 (8 waves of 64 x 96)
+        case 134: ISB_CONV_LAUNCH_G1(2, 2, 4, 2); break;   // 256 x 128
+        case 135: ISB_CONV_LAUNCH_G1(1, 2, 8, 1); break;   // 256 x  64
+        case 136: ISB_CONV_LAUNCH_G1(1, 3, 8, 1); break;   // 256 x  96
+        case 137: ISB_CONV_LAUNCH_G1(1, 7, 4, 1); break;   // 128 x 224
+        case 138: ISB_CONV_LAUNCH_G1(1, 1, 2, 2); break;   //  64 x  64
+        case 139: ISB_CONV_LAUNCH_G1(2, 4, 4, 2); break;   // 256 x 256 (8 waves of 64 x 128)
+#undef ISB_CONV_LAUNCH_G1
+#define ISB_CONV_LAUNCH_G1G(TM, TN, WGM, WGN)                                                                    \
+    do {                                                                                                         \
+        constexpr int BM_ = 32 * TM * WGM, BN_ = 32 * TN * WGN;                                                  \
+        const int ohw = a.OH * a.OW;                                                                             \
+        if (!a.gate || a.KH != 1 || a.stride != 1 || a.pad != 0 || (ohw % BM_ != 0 && BM_ % ohw != 0)) {        \
+            set_error("conv_igemm: variants 141-149 are gated 1x1 GEMMs on sample-aligned tiles");               \
+            return ISB_ERR_INVALID;                                                                              \
+        }                                                                                                        \
+        const int ns = BM_ > ohw ? BM_ / ohw : 1;                                                                \
+        const int ring = 2 * (BM_ + BN_) * ROWB + ns * a.Cin * 4;                                                \
+        const int stage = BM_ * (BN_ * 2 + 16);                                                                  \
+        const int bytes = ring > stage ? ring : stage;                                                           \
+        auto kern = gemm1x1_dma_kernel<TM, TN, WGM, WGN, true>;                                                  \
+        static int attr_bytes = 0;                                                                               \
+        if (bytes > attr_bytes) {                                                                                \
+            ISB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));  \
+            attr_bytes = bytes;                                                                                  \
+        }                                                                                                        \
+        const dim3 g = conv_grid(aa, BM_, BN_);                                                                  \
+        hipLaunchKernelGGL(kern, g, dim3(64 * WGM * WGN), bytes, st, aa);                                        \
+    } while (0)
+        case 141: ISB_CONV_LAUNCH_G1G(1, 3, 4, 2); break;   // 128 x 192, SE gate on the A fragments
+        case 142: ISB_CONV_LAUNCH_G1G(1, 2, 4, 2); break;   // 128 x 128
+        case 143: ISB_CONV_LAUNCH_G1G(1, 7, 4, 1); break;   // 128 x 224
+        case 144: ISB_CONV_LAUNCH_G1G(1, 5, 4, 2); break;   // 128 x 320
+        case 145: ISB_CONV_LAUNCH_G1G(2, 2, 4, 2); break;   // 256 x 128
+        case 146: ISB_CONV_LAUNCH_G1G(1, 3, 2, 2); break;   //  64 x 192
+        case 147: ISB_CONV_LAUNCH_G1G(1, 2, 2, 2); break;   //  64 x 128
+        case 148: ISB_CONV_LAUNCH_G1G(2, 7, 4, 1); break;   // 256 x 224
+#undef ISB_CONV_LAUNCH_G1G
         default:
             set_error("conv_igemm: unknown tile variant %d", v);
             return ISB_ERR_INVALID;

@@ -12,7 +12,7 @@ for hw, cin, cout in [(8, 2304, 384), (8, 3840, 640), (16, 1344, 224), (16, 768,
     res = f32_to_bf16(rng.normal(0, 1, (B, hw, hw, cout)).astype(np.float32))
     gate = rng.uniform(0.1, 0.9, (B, cin)).astype(np.float32)
     fl = 2.0 * B * hw * hw * cin * cout
-    for g, vs in [(gate, [0, 81, 82, 83, 84, 85, 86, 91, 92, 93, 94, 95, 96]), (None, [54, 55])]:
+    for g, vs in [(gate, [0, 141, 142, 143, 144, 145, 146, 147, 148]), (None, [131, 132])]:
         row = []
         for v in vs:
             try:
