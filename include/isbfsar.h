@@ -191,6 +191,13 @@ int isb_debug_expand_dw(int32_t device, const uint16_t* h_x, const float* h_w1, 
                         const float* h_dww, const float* h_dwscale, const float* h_dwshift, int32_t B, int32_t HW, int32_t Cin,
                         int32_t Cexp, int32_t iters, uint16_t* h_out, float* h_pooled, float* ms_per_iter);
 
+/* test / tuning hook: the depthwise 3x3 (+ folded BN + SiLU) + squeeze-excite mean kernel on host tensors.
+ *   h_x bf16 [B,H,H,C], h_w f32 [C,3,3] (taps are rounded to bf16 after the BN scale is folded in, like every
+ *   conv weight), stride 1 (pad 1) or 2 (TF SAME: pad bottom/right); out bf16 [B,H/stride,H/stride,C], pooled f32 [B,C] */
+int isb_debug_dwconv(int32_t device, const uint16_t* h_x, const float* h_w, const float* h_scale, const float* h_shift,
+                     int32_t B, int32_t H, int32_t C, int32_t stride, int32_t iters, uint16_t* h_out, float* h_pooled,
+                     float* ms_per_iter);
+
 /* ------------------------------------------------------------------------------------------
  * Glue between the two stages (main.py:102-105 + ar.py:42-50): root-centre every pose on joint 0,
  * flatten to 3J and cut sliding windows of L consecutive frames per camera.

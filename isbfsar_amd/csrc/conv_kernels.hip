@@ -1106,8 +1106,16 @@ int launch_conv_expand_dw(const ConvArgs& a, hipStream_t st) {
 // 4 horizontally adjacent outputs share their input columns ((4-1)*S+3 columns x 3 rows of 16-B loads
 // instead of 36). The per-(sample, channel) mean is reduced inside the WG in a fixed order (no atomics:
 // results do not depend on scheduling) and written straight to pooled[b][c].
-// weights tap-major f32 [9][C] (BN scale folded)
+// weights tap-major bf16 [9][C] (BN scale folded); the 9-tap sums run on v_dot2c_f32_bf16 with the other half
+// of the weight pair zeroed = exact f32 FMAs fed by the packed activations
 // =====================================================================================
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+// acc += x.lo * w.lo + x.hi * w.hi on bf16 pairs (v_dot2c_f32_bf16). With one half of w zero this is the exact
+// f32 FMA of ONE channel straight from the packed activations: no bf16 -> f32 unpacking, no operand shuffles.
+__device__ __forceinline__ float dot2_bf16(uint32_t x, uint32_t w, float acc) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, x), __builtin_bit_cast(bf16x2_t, w), acc, false);
+}
+
 template <int S>
 __global__ __launch_bounds__(256) void dwconv3x3_pool_kernel(DwArgs p) {
     __shared__ float red[32][129];
@@ -1119,14 +1127,21 @@ __global__ __launch_bounds__(256) void dwconv3x3_pool_kernel(DwArgs p) {
     const int b = blockIdx.y;
     const int c = (blockIdx.x * CH + cl) * 8;
     const bool cok = c < p.C;
-    float w[9][8], bias[8], psum[8];
+    uint32_t wlo[9][4], whi[9][4];                        // tap weights of the even / odd channel of each pair
+    float bias[8], psum[8];
+    // bf16 (1, 0) and (0, 1) in registers: as a literal 0x3f800000 becomes the INLINE constant 1.0, which a packed
+    // bf16 operand reads as (1, 0) -- the pool would sum the wrong channel
+    uint32_t one_lo, one_hi;
+    asm volatile("v_mov_b32 %0, 0x3f80\n\tv_lshlrev_b32 %1, 16, %0" : "=v"(one_lo), "=v"(one_hi));
 #pragma unroll
     for (int e = 0; e < 8; ++e) psum[e] = 0.f;
     if (cok) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const float4 w0 = *reinterpret_cast<const float4*>(p.w + (size_t)t * p.C + c), w1 = *reinterpret_cast<const float4*>(p.w + (size_t)t * p.C + c + 4);
-            w[t][0] = w0.x; w[t][1] = w0.y; w[t][2] = w0.z; w[t][3] = w0.w; w[t][4] = w1.x; w[t][5] = w1.y; w[t][6] = w1.z; w[t][7] = w1.w;
+            const uint4 wv = *reinterpret_cast<const uint4*>(p.w + (size_t)t * p.C + c);
+            const uint32_t wp[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { wlo[t][e] = wp[e] & 0xffffu; whi[t][e] = wp[e] & 0xffff0000u; }
         }
         const float4 s0 = *reinterpret_cast<const float4*>(p.bias + c), s1 = *reinterpret_cast<const float4*>(p.bias + c + 4);
         bias[0] = s0.x; bias[1] = s0.y; bias[2] = s0.z; bias[3] = s0.w; bias[4] = s1.x; bias[5] = s1.y; bias[6] = s1.z; bias[7] = s1.w;
@@ -1153,17 +1168,16 @@ __global__ __launch_bounds__(256) void dwconv3x3_pool_kernel(DwArgs p) {
                 }
 #pragma unroll
                 for (int col = 0; col < NCOL; ++col) {
-                    float x[8];
-                    x[0] = bf2f_((uint16_t)(v[col].x & 0xffff)); x[1] = bf2f_((uint16_t)(v[col].x >> 16));
-                    x[2] = bf2f_((uint16_t)(v[col].y & 0xffff)); x[3] = bf2f_((uint16_t)(v[col].y >> 16));
-                    x[4] = bf2f_((uint16_t)(v[col].z & 0xffff)); x[5] = bf2f_((uint16_t)(v[col].z >> 16));
-                    x[6] = bf2f_((uint16_t)(v[col].w & 0xffff)); x[7] = bf2f_((uint16_t)(v[col].w >> 16));
+                    const uint32_t x[4] = {v[col].x, v[col].y, v[col].z, v[col].w};
 #pragma unroll
                     for (int o = 0; o < 4; ++o) {
                         const int kx = col - o * S;       // tap of output o that reads this column
                         if (kx >= 0 && kx < 3) {
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) acc[o][e] = fmaf(x[e], w[ky * 3 + kx][e], acc[o][e]);
+                            for (int e = 0; e < 4; ++e) {
+                                acc[o][2 * e] = dot2_bf16(x[e], wlo[ky * 3 + kx][e], acc[o][2 * e]);
+                                acc[o][2 * e + 1] = dot2_bf16(x[e], whi[ky * 3 + kx][e], acc[o][2 * e + 1]);
+                            }
                         }
                     }
                 }
@@ -1175,8 +1189,9 @@ __global__ __launch_bounds__(256) void dwconv3x3_pool_kernel(DwArgs p) {
                 for (int e = 0; e < 4; ++e) {
                     const uint16_t lo = f2bf_(silu_fast(acc[o][2 * e])), hi = f2bf_(silu_fast(acc[o][2 * e + 1]));
                     pk[e] = (uint32_t)lo | ((uint32_t)hi << 16);
-                    psum[2 * e] += bf2f_(lo);              // the pool sees the stored (rounded) activations
-                    psum[2 * e + 1] += bf2f_(hi);
+                    // the pool sees the stored (rounded) activations: x * 1.0 + psum, one instruction per channel
+                    psum[2 * e] = dot2_bf16(pk[e], one_lo, psum[2 * e]);
+                    psum[2 * e + 1] = dot2_bf16(pk[e], one_hi, psum[2 * e + 1]);
                 }
                 *reinterpret_cast<uint4*>(p.out + (((size_t)(b * p.OH + oy) * p.OW + ox0 + o) * p.C + c)) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
             }

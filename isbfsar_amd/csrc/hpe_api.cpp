@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cmath>
+#include <cstring>
 #include <memory>
 #include <utility>
 
@@ -22,7 +23,7 @@ struct BlockW {
     bool fused = false, residual = false;
     int cin = 0, cout = 0, cexp = 0, stride = 1, cse = 0, in_hw = 0, out_hw = 0;
     ConvW expand, project;
-    DevBuf dw_w, dw_b, se_w1, se_b1, se_w2, se_b2;
+    DevBuf dw_w, dw_w16, dw_b, se_w1, se_b1, se_w2, se_b2;   // dw_w: the bf16-rounded taps as f32 (fused kernel), dw_w16: bf16
 };
 
 // public efficientnetv2-l table (mirrors isbfsar_amd/effnetv2.py::STAGES)
@@ -73,6 +74,19 @@ struct isb_hpe {
 };
 
 namespace {
+
+inline uint16_t bf16_rne(float x) {             // round-to-nearest-even, as __bf16(x) on the device
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+inline float bf16_to_float(uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float x;
+    memcpy(&x, &u, 4);
+    return x;
+}
 
 int upload_conv(const std::map<std::string, BlobTensor>& m, const std::string& prefix, int cout, int k, int cin,
                 ConvW& cw, hipStream_t st) {
@@ -195,7 +209,7 @@ int run_backbone(isb_hpe* h, Lane& L, hipStream_t st, const float* crops, int B)
             } else {
                 ISB_TRY(conv(h, st, b.expand, X, B, b.in_hw, b.in_hw, 1, true, nullptr, nullptr, L.bufE.p, false));
                 DwArgs d{};
-                d.in = L.bufE.as<uint16_t>(); d.w = b.dw_w.as<float>(); d.bias = b.dw_b.as<float>(); d.out = L.bufD.as<uint16_t>();
+                d.in = L.bufE.as<uint16_t>(); d.w = b.dw_w16.as<uint16_t>(); d.bias = b.dw_b.as<float>(); d.out = L.bufD.as<uint16_t>();
                 d.B = B; d.H = b.in_hw; d.W = b.in_hw; d.C = b.cexp; d.OH = b.out_hw; d.OW = b.out_hw; d.stride = b.stride;
                 d.pad = b.stride == 1 ? 1 : 0;
                 d.pooled = L.pooled.as<float>();
@@ -340,10 +354,16 @@ extern "C" int isb_hpe_load_weights(isb_hpe* h, const void* blob, size_t nbytes)
                 const BlobTensor *sc, *sh, *w1, *b1, *w2, *b2;
                 ISB_TRY(blob_get(m, (p + ".dw.scale").c_str(), b->cexp, 1, &sc));
                 ISB_TRY(blob_get(m, (p + ".dw.shift").c_str(), b->cexp, 1, &sh));
-                std::vector<float> wt((size_t)9 * b->cexp);      // tap-major, scale folded
+                std::vector<float> wt((size_t)9 * b->cexp);      // tap-major, scale folded, rounded to bf16 like every conv weight
+                std::vector<uint16_t> wt16(wt.size());
                 for (int c = 0; c < b->cexp; ++c)
-                    for (int t = 0; t < 9; ++t) wt[(size_t)t * b->cexp + c] = it->second.data[(size_t)c * 9 + t] * sc->data[c];
+                    for (int t = 0; t < 9; ++t) {
+                        const uint16_t hb = bf16_rne(it->second.data[(size_t)c * 9 + t] * sc->data[c]);
+                        wt16[(size_t)t * b->cexp + c] = hb;
+                        wt[(size_t)t * b->cexp + c] = bf16_to_float(hb);
+                    }
                 ISB_TRY(upload(b->dw_w, wt.data(), wt.size() * 4));
+                ISB_TRY(upload(b->dw_w16, wt16.data(), wt16.size() * 2));
                 ISB_TRY(upload(b->dw_b, sh->data, (size_t)b->cexp * 4));
                 ISB_TRY(blob_get(m, (p + ".se.w1").c_str(), b->cse, b->cexp, &w1));
                 ISB_TRY(blob_get(m, (p + ".se.b1").c_str(), b->cse, 1, &b1));
@@ -654,6 +674,49 @@ extern "C" int isb_hpe_select_person_host(isb_hpe* h, const float* boxes, const 
     });
 }
 
+// test / tuning hook: depthwise 3x3 + SiLU + SE mean on host tensors
+extern "C" int isb_debug_dwconv(int32_t device, const uint16_t* x, const float* w, const float* scale, const float* shift,
+                                int32_t B, int32_t H, int32_t C, int32_t stride, int32_t iters, uint16_t* out, float* pooled,
+                                float* ms_per_iter) {
+    return isb::guard([&]() -> int {
+        ISB_REQUIRE(x && w && scale && shift && out && pooled && ms_per_iter, ISB_ERR_INVALID, "null argument");
+        ISB_REQUIRE((stride == 1 || stride == 2) && iters >= 1 && B >= 1, ISB_ERR_INVALID, "bad depthwise parameters");
+        ISB_HIP(hipSetDevice(device));
+        const int OH = H / stride;
+        const size_t nin = (size_t)B * H * H * C, nout = (size_t)B * OH * OH * C;
+        std::vector<uint16_t> wt16((size_t)9 * C);
+        for (int c = 0; c < C; ++c)
+            for (int t = 0; t < 9; ++t) wt16[(size_t)t * C + c] = bf16_rne(w[(size_t)c * 9 + t] * scale[c]);
+        DevBuf dx, dw, db, dout, dpool;
+        ISB_TRY(upload(dx, x, nin * 2));
+        ISB_TRY(upload(dw, wt16.data(), wt16.size() * 2));
+        ISB_TRY(upload(db, shift, (size_t)C * 4));
+        ISB_TRY(dout.alloc(nout * 2));
+        ISB_TRY(dpool.alloc((size_t)B * C * 4));
+        DwArgs d{};
+        d.in = dx.as<uint16_t>(); d.w = dw.as<uint16_t>(); d.bias = db.as<float>(); d.out = dout.as<uint16_t>();
+        d.pooled = dpool.as<float>(); d.B = B; d.H = H; d.W = H; d.C = C; d.OH = OH; d.OW = OH; d.stride = stride;
+        d.pad = stride == 1 ? 1 : 0;
+        ISB_TRY(launch_dwconv3x3(d, nullptr));
+        ISB_HIP(hipDeviceSynchronize());
+        hipEvent_t e0, e1;
+        ISB_HIP(hipEventCreate(&e0));
+        ISB_HIP(hipEventCreate(&e1));
+        ISB_HIP(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < iters; ++i) ISB_TRY(launch_dwconv3x3(d, nullptr));
+        ISB_HIP(hipEventRecord(e1, nullptr));
+        ISB_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        ISB_HIP(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        *ms_per_iter = ms / iters;
+        ISB_HIP(hipMemcpy(out, dout.p, nout * 2, hipMemcpyDeviceToHost));
+        ISB_HIP(hipMemcpy(pooled, dpool.p, (size_t)B * C * 4, hipMemcpyDeviceToHost));
+        return ISB_OK;
+    });
+}
+
 // test / tuning hook: fused MBConv front half (1x1 expand + SiLU + depthwise 3x3 + SiLU + SE pool) on host tensors
 extern "C" int isb_debug_expand_dw(int32_t device, const uint16_t* x, const float* w1, const float* scale1, const float* shift1,
                                    const float* dww, const float* dwscale, const float* dwshift, int32_t B, int32_t HW,
@@ -675,7 +738,7 @@ extern "C" int isb_debug_expand_dw(int32_t device, const uint16_t* x, const floa
         ISB_TRY(launch_f32_to_bf16_rows(dwf.as<float>(), dsc.as<float>(), dw16.as<uint16_t>(), Cexp, (size_t)Cin, nullptr));
         std::vector<float> wt((size_t)9 * Cexp);
         for (int c = 0; c < Cexp; ++c)
-            for (int t = 0; t < 9; ++t) wt[(size_t)t * Cexp + c] = dww[(size_t)c * 9 + t] * dwscale[c];
+            for (int t = 0; t < 9; ++t) wt[(size_t)t * Cexp + c] = bf16_to_float(bf16_rne(dww[(size_t)c * 9 + t] * dwscale[c]));
         ISB_TRY(upload(ddw, wt.data(), wt.size() * 4));
         ISB_TRY(upload(ddb, dwshift, (size_t)Cexp * 4));
         ISB_TRY(dout.alloc(nout * 2));

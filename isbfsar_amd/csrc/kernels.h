@@ -138,7 +138,7 @@ int launch_conv_expand_dw(const ConvArgs& a, hipStream_t st);
 
 struct DwArgs {
     const uint16_t* in;     // bf16 [B,H,W,C]
-    const float* w;         // f32 [9][C] tap-major, BN scale folded
+    const uint16_t* w;      // bf16 [9][C] tap-major, BN scale folded (rounded once at load, like every conv weight)
     const float* bias;      // [C]
     uint16_t* out;          // bf16 [B,OH,OW,C]
     float* pooled;          // f32 [B,C] spatial mean of `out` (squeeze-excite input) or null

@@ -175,6 +175,20 @@ def conv_debug(x_bf16, w, scale, shift, k, stride, act, res_bf16=None, gate=None
     return out, ms.value
 
 
+def dwconv_debug(x_bf16, w, scale, shift, stride=1, iters=1, device=0):
+    """Depthwise 3x3 + SiLU + SE mean through isb_debug_dwconv. x_bf16 uint16 [B,H,H,C], w f32 [C,3,3].
+    Returns (out uint16 [B,H/stride,H/stride,C], pooled f32 [B,C], ms_per_launch)."""
+    x = np.ascontiguousarray(x_bf16, dtype=np.uint16)
+    B, H, _, Cc = x.shape
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    out = np.empty((B, H // stride, H // stride, Cc), np.uint16)
+    pooled = np.empty((B, Cc), np.float32)
+    ms = C.c_float()
+    _lib.check(_lib.lib().isb_debug_dwconv(device, _ptr(x), _ptr(f(w)), _ptr(f(scale)), _ptr(f(shift)), B, H, Cc, stride,
+                                           iters, _ptr(out), _ptr(pooled), C.byref(ms)), "isb_debug_dwconv")
+    return out, pooled, ms.value
+
+
 def expand_dw_debug(x_bf16, w1, scale1, shift1, dww, dwscale, dwshift, iters=1, device=0):
     """Fused MBConv front half through isb_debug_expand_dw. x_bf16 uint16 [B,HW,HW,Cin].
     Returns (D uint16 [B,HW,HW,Cexp], pooled f32 [B,Cexp], ms_per_launch)."""

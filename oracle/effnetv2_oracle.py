@@ -11,8 +11,8 @@ with it on synthetic weights. What IS pinned is the shape contract.
 
 Two numeric modes:
   * ``mode="f32"``   plain fp32 everywhere;
-  * ``mode="bf16"``  the storage/rounding points of the HIP path: conv weights (BN scale folded in)
-    and every stored activation are rounded to bf16, accumulation / bias / SiLU / SE in fp32, the
+  * ``mode="bf16"``  the storage/rounding points of the HIP path: conv weights incl. the depthwise taps (BN
+    scale folded in) and every stored activation are rounded to bf16, accumulation / bias / SiLU / SE in fp32, the
     last 1x1 conv (640->1280) stores f32 and the pose head runs in f32 -- so a GPU-vs-oracle
     difference is accumulation order only.
 Only tests/, smoke() and bench.py's cpu_baseline leg may import this file.
@@ -56,7 +56,7 @@ class EffNetV2LOracle:
         for b in self.blocks:
             if b.kind == "mb":
                 p = f"bbone.b{b.idx}.dw"
-                self.cw[p] = (self.w[p + ".w"] * self.w[p + ".scale"].view(-1, 1, 1)).unsqueeze(1)  # [c,1,3,3] f32
+                self.cw[p] = _r(self.w[p + ".w"] * self.w[p + ".scale"].view(-1, 1, 1), mode).unsqueeze(1)  # [c,1,3,3], bf16-rounded taps
 
     def _conv(self, x, p, k, stride, act, out_f32=False):
         w = self.cw[p]

@@ -99,7 +99,7 @@ def test_fused_expand_dw_pool(B, HW, Cin, Cexp):
     wf = (torch.from_numpy(w1) * torch.from_numpy(s1)[:, None]).bfloat16().float()
     e = F.conv2d(xb, wf[:, :, None, None]) + torch.from_numpy(b1).view(1, -1, 1, 1)
     e = (e * torch.sigmoid(e)).bfloat16().float()
-    wd = (torch.from_numpy(dww) * torch.from_numpy(s2)[:, None, None]).unsqueeze(1)
+    wd = (torch.from_numpy(dww) * torch.from_numpy(s2)[:, None, None]).bfloat16().float().unsqueeze(1)   # taps are stored as bf16
     d = F.conv2d(e, wd, padding=1, groups=Cexp) + torch.from_numpy(b2).view(1, -1, 1, 1)
     d = (d * torch.sigmoid(d)).bfloat16().float()
     ref = d.permute(0, 2, 3, 1).numpy()
@@ -109,3 +109,28 @@ def test_fused_expand_dw_pool(B, HW, Cin, Cexp):
     assert np.abs(got - ref).max() < 3e-2 * max(1.0, np.abs(ref).max()), float(np.abs(got - ref).max())
     assert np.mean(np.abs(got - ref) > 2.0 ** -7 * np.maximum(1.0, np.abs(ref))) < 0.02
     np.testing.assert_allclose(pooled, got.reshape(B, HW * HW, Cexp).mean(1), rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,H,C,stride", [(2, 16, 768, 1), (3, 8, 2304, 1), (2, 16, 1344, 2), (1, 32, 384, 2), (2, 8, 3840, 1)])
+def test_depthwise_pool(B, H, C, stride):
+    """Depthwise 3x3 + folded BN + SiLU + SE mean (v_dot2c_f32_bf16 on bf16 taps) vs torch-CPU on the same rounded taps."""
+    from isbfsar_amd.hpe_engine import dwconv_debug
+    rng = np.random.default_rng(B * 100 + C + stride)
+    x = rng.normal(0, 1, (B, H, H, C)).astype(np.float32)
+    w = (rng.normal(0, 1, (C, 3, 3)) / 3).astype(np.float32)
+    sc = rng.uniform(0.8, 1.2, C).astype(np.float32)
+    sh = rng.uniform(-0.1, 0.1, C).astype(np.float32)
+    out, pooled, _ = dwconv_debug(f32_to_bf16(x), w, sc, sh, stride)
+    xb = torch.from_numpy(bf16_to_f32(f32_to_bf16(x))).permute(0, 3, 1, 2)
+    wd = (torch.from_numpy(w) * torch.from_numpy(sc)[:, None, None]).bfloat16().float().unsqueeze(1)
+    if stride == 2:
+        d = F.conv2d(F.pad(xb, (0, 1, 0, 1)), wd, stride=2, groups=C)
+    else:
+        d = F.conv2d(xb, wd, padding=1, groups=C)
+    d = d + torch.from_numpy(sh).view(1, -1, 1, 1)
+    ref = (d * torch.sigmoid(d)).bfloat16().float().permute(0, 2, 3, 1).numpy()
+    got = bf16_to_f32(out)
+    tol = 2.0 ** -7 * np.maximum(1.0, np.abs(ref))
+    assert np.all(np.abs(got - ref) <= tol), float(np.abs(got - ref).max())
+    assert np.mean(got != ref) < 0.02                       # identical bf16 values except at rounding boundaries
+    np.testing.assert_allclose(pooled, got.reshape(B, -1, C).mean(1), rtol=0, atol=1e-5)
