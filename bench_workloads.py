@@ -83,10 +83,10 @@ class _HpeBase:
             with open(tj) as f:     # (FETCH_SIZE / WRITE_SIZE, collected separately; see profiles/README.md)
                 t = json.load(f)["hpe_b256"]["conv_igemm"]["hbm_bytes_per_forward"]
             traffic = t * self.B / 256.0
-        return {"bound": "mfma", "kernel": "conv_igemm_kernel (all launches of a forward pass)",
+        return {"bound": "mfma", "kernel": "conv_igemm / gemm1x1 family (all convolution launches of a forward pass)",
                 "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS_BF16, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_PEAK_TFLOPS_BF16, 4), "traffic": traffic,
-                "traffic_unit": "HBM bytes per forward pass over all conv_igemm launches (PMC, measured at B=256)",
+                "traffic_unit": "HBM bytes per forward pass over all convolution launches (PMC, measured at B=256)",
                 "avg_launch_ms": round(ms / max(launches, 1), 5), "launches": int(launches),
                 "flops_per_step": flops / steps}
 

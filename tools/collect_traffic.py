@@ -1,0 +1,47 @@
+"""Turn two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, as MI355X_MICROARCH.md prescribes) of
+`ISB_HPE_LANES=1 python3 bench.py --workload hpe --steps 1 --warmup 1 --no-cpu-baseline` into profiles/rNN_traffic.json:
+HBM bytes per forward pass (B=256 frames) for each kernel family.
+usage: python tools/collect_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
+FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE is doubled (gfx950 tallies the 128-B requests of 16-B/lane reads at 64 B)."""
+import collections
+import csv
+import json
+import sys
+
+
+def family(name: str) -> str:
+    if "conv_igemm" in name or "gemm1x1" in name:
+        return "conv_igemm"
+    if "dwconv3x3" in name:
+        return "dwconv3x3_pool"
+    if "se_fc" in name:
+        return "se_fc"
+    if "ar_" in name:
+        return "ar"
+    return "other" if "isb::" in name else "_skip"
+
+
+def load(path, counter):
+    tot = collections.Counter()
+    n = collections.Counter()
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        f = family(r["Kernel_Name"])
+        if f == "_skip":
+            continue
+        tot[f] += float(r["Counter_Value"])
+        n[f] += 1
+    return tot, n
+
+
+fetch, nf = load(sys.argv[1], "FETCH_SIZE")
+write, nw = load(sys.argv[2], "WRITE_SIZE")
+forwards = nf["conv_igemm"] / 155.0                      # 155 conv launches per forward pass on one lane
+out = {"_how": __doc__, "forwards_in_trace": forwards, "hpe_b256": {}}
+for f in sorted(set(fetch) | set(write)):
+    fk, wk = fetch[f] / forwards, write[f] / forwards
+    out["hpe_b256"][f] = {"FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "launches": nf[f] / forwards,
+                          "hbm_bytes_per_forward": (2.0 * fk + wk) * 1024.0}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print(json.dumps({k: round(v["hbm_bytes_per_forward"] / 1e9, 2) for k, v in out["hpe_b256"].items()}), "GB per forward;", forwards, "forwards")

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Regenerates the round's evidence under gpurun_out/ (copy into profiles/ afterwards). Run on the MI355X box.
+set -e
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+echo "== bench lines"
+for w in pipeline hpe ar stream; do
+  timeout -k 10 400 python bench.py --workload $w $( [ $w = stream ] && echo "--steps 300 --warmup 20" ) > gpurun_out/bench_$w.log 2>&1
+  tail -1 gpurun_out/bench_$w.log > gpurun_out/bench_$w.json
+  python3 -c "import json;d=json.load(open('gpurun_out/bench_$w.json'));print('$w',d['value'],d['unit'],d['ms_per_step'],'ms',d['roofline']['achieved'],d['roofline']['frac'],d['cpu_baseline']['value'] if d.get('cpu_baseline') else None)"
+done
+echo "== kernel stats (pipeline)"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_pipe -o run -- python3 bench.py --workload pipeline --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/prof_pipe.log 2>&1
+echo "== kernel stats (ar)"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_ar -o run -- python3 bench.py --workload ar --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/prof_ar.log 2>&1
+echo "== PMC traffic"
+ISB_HPE_LANES=1 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o run -- python3 bench.py --workload hpe --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_fetch.log 2>&1
+ISB_HPE_LANES=1 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o run -- python3 bench.py --workload hpe --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_write.log 2>&1
+python3 tools/collect_traffic.py gpurun_out/pmc_fetch/run_counter_collection.csv gpurun_out/pmc_write/run_counter_collection.csv gpurun_out/traffic.json
+echo done
