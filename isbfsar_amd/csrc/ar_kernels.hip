@@ -48,6 +48,28 @@ __device__ __forceinline__ bf16x8 ld_frag(const uint16_t* p) {
 
 #define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
+// One LDS-DMA instruction (lane l's 16 bytes land at LDS byte address lds_addr + 16 l), issued through inline asm:
+// through the builtin the compiler models an LDS store and orders every later LDS read behind it (vmcnt(0)),
+// and __syncthreads() drains the queue; hidden in asm, the rings below keep 2-3 tiles in flight and wait with
+// counted s_waitcnt vmcnt + the raw s_barrier. Consequence: no ordinary register-returning global load may sit
+// inside a loop that relies on those counts (vmcnt retires in order and the compiler's own waits would drain it).
+__device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_addr) {
+    const uint32_t la = __builtin_amdgcn_readfirstlane(lds_addr);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(la) : "memory");
+}
+// make the compiler's own wait for an ordinary load happen HERE (a use), before any asm DMA is in flight
+#define ISB_PIN(x) asm volatile("" ::"v"(x))
+
+__device__ __forceinline__ void wait_tiles_in_flight(int tiles, int per_tile) {   // wave-uniform arguments
+    const int n = tiles * per_tile;
+    if (n >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (n >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (n >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (n >= 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // row of accumulator register r inside a 32x32 tile for lane-half h
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -184,7 +206,9 @@ template <bool X3, bool ONLINE>
 __global__ __launch_bounds__(512, 2) void ar_stats_kernel(ArStatsArgs p) {
     constexpr int TILE_U16 = 8 * 64 * 8;                  // one K tile: 8 chunks of 1 KiB
     constexpr int NBUF_U16 = TILE_U16 * (X3 ? 2 : 1);
-    __shared__ __attribute__((aligned(16))) uint16_t lds[2 * NBUF_U16];
+    constexpr int NB = 4;                                 // ring: tile it is consumed while it+1 .. it+3 are in flight
+    constexpr int PER = X3 ? 2 : 1;                       // DMA instructions per wave and tile
+    __shared__ __attribute__((aligned(16))) uint16_t lds[NB * NBUF_U16];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, r = lane & 31;
     const int b = blockIdx.y;
     const int slot = blockIdx.x * 8 + wave;
@@ -212,36 +236,52 @@ __global__ __launch_bounds__(512, 2) void ar_stats_kernel(ArStatsArgs p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) { lsum[i] = 0.f; mrun[i] = -3.0e38f; }
 
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) { ISB_PIN(a_hi[ks]); if (X3) ISB_PIN(a_lo[ks]); }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ISB_PIN(ubr[i]);
+
     // the window's Kq fragment tiles go global -> LDS by LDS-DMA (lane-linear images: wave w fills
-    // KiB w of the 8-KiB tile); tile it+1 is in flight while tile it feeds the MFMAs
+    // KiB w of the 8-KiB tile)
     const uint16_t* gq = p.KqF + (size_t)b * p.NT * TILE_U16 + tid * 8;
     const uint16_t* gq_lo = X3 ? p.KqF_lo + (size_t)b * p.NT * TILE_U16 + tid * 8 : nullptr;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    auto dma_tile = [&](int it2, int buf) {
-        uint16_t* base = lds + buf * NBUF_U16 + wave_u * 512;
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)(gq + (size_t)it2 * TILE_U16), (lds_ptr_t)base, 16, 0, 0);
-        if (X3) __builtin_amdgcn_global_load_lds((glb_ptr_t)(gq_lo + (size_t)it2 * TILE_U16), (lds_ptr_t)(base + TILE_U16), 16, 0, 0);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)lds + wave_u * 1024;
+    auto dma_tile = [&](int it2) {
+        const uint32_t base = lds0 + (it2 % NB) * (NBUF_U16 * 2);
+        dma16(gq + (size_t)it2 * TILE_U16, base);
+        if (X3) dma16(gq_lo + (size_t)it2 * TILE_U16, base + TILE_U16 * 2);
     };
-    dma_tile(0, 0);
-    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NB - 1; ++t)
+        if (t < p.NT) dma_tile(t);
 
     for (int it = 0; it < p.NT; ++it) {
-        const int cur = it & 1;
-        const bool more = it + 1 < p.NT;
-        if (more) dma_tile(it + 1, cur ^ 1);
+        // tile `it` has landed when at most the 2 newer tiles are still in flight; behind the barrier every wave
+        // is done with tile it-1, whose buffer the next request overwrites
+        wait_tiles_in_flight(min(NB - 2, p.NT - 1 - it), PER);
+        __builtin_amdgcn_s_barrier();
+        if (it + NB - 1 < p.NT) dma_tile(it + NB - 1);
         if (active) {
-            const uint16_t* bt = lds + cur * NBUF_U16 + lane * 8;
+            const uint16_t* bt = lds + (it % NB) * NBUF_U16 + lane * 8;
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            // all fragment reads of the tile first (one LDS round trip), then the MFMA chain: left to itself the
+            // compiler reads one fragment, waits for it, issues one MFMA, and pays the LDS latency 8 times
+            bf16x8 bh[8], bl[X3 ? 8 : 1];
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
-                const bf16x8 bh = ld_frag(bt + ks * 512);
-                acc = MFMA_BF16(a_hi[ks], bh, acc);
+                bh[ks] = ld_frag(bt + ks * 512);
+                if (X3) bl[ks] = ld_frag(bt + TILE_U16 + ks * 512);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                acc = MFMA_BF16(a_hi[ks], bh[ks], acc);
                 if (X3) {
-                    const bf16x8 bl = ld_frag(bt + TILE_U16 + ks * 512);
-                    acc = MFMA_BF16(a_hi[ks], bl, acc);
-                    acc = MFMA_BF16(a_lo[ks], bh, acc);
+                    acc = MFMA_BF16(a_hi[ks], bl[ks], acc);
+                    acc = MFMA_BF16(a_lo[ks], bh[ks], acc);
                 }
             }
             const bool ivalid = it * 32 + r < p.T;
@@ -262,7 +302,6 @@ __global__ __launch_bounds__(512, 2) void ar_stats_kernel(ArStatsArgs p) {
                 }
             }
         }
-        __syncthreads();
     }
     if (!active) return;
     // combine the 32 lanes (i within the tile) of each half-wave
@@ -313,7 +352,10 @@ __global__ __launch_bounds__(512, 2) void ar_proto_kernel(ArProtoArgs p) {
     constexpr int VT_U16 = 4 * 2 * 64 * 8;                // V^T tile (8 KiB)
     constexpr int PART_U16 = KT_U16 + VT_U16;
     constexpr int NBUF_U16 = PART_U16 * (X3 ? 2 : 1);
-    __shared__ __attribute__((aligned(16))) uint16_t lds[CHOSEN ? 8 : 2 * NBUF_U16];
+    constexpr int NB = 3;                                 // ring: tile jt is consumed while jt+1, jt+2 are in flight
+    constexpr int PER = X3 ? 5 : 3;                       // DMA instructions per wave and tile (K, V^T [, lo parts], lse2)
+    constexpr int LSE_U16 = 8 * NB * 64;                  // per wave and ring slot: the tile's 32 lse2 values (128 B)
+    __shared__ __attribute__((aligned(16))) uint16_t lds[CHOSEN ? 8 : NB * NBUF_U16 + LSE_U16];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, r = lane & 31;
     const int slot = blockIdx.x * 8 + wave;
     const bool active = slot < p.B * p.NT;
@@ -339,46 +381,67 @@ __global__ __launch_bounds__(512, 2) void ar_proto_kernel(ArProtoArgs p) {
         for (int i = 0; i < 16; ++i) pacc[dt][i] = 0.f;
 
     const float* lse_row = p.lse2 + ((size_t)b * p.n + c) * Tp + 4 * h;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) { ISB_PIN(q_hi[ks]); if (X3) ISB_PIN(q_lo[ks]); }
 
     // staging (ALL mode): the class's Kc / V^T fragment tiles go global -> LDS by LDS-DMA (the fragment
-    // images are lane-linear, so wave w simply fills bytes [w KiB, (w+1) KiB) of each 8-KiB tile);
-    // tile jt+1 is in flight while tile jt feeds the MFMAs, __syncthreads() waits for it (vmcnt).
+    // images are lane-linear, so wave w simply fills bytes [w KiB, (w+1) KiB) of each 8-KiB tile), and so do the 32
+    // lse2 values of the wave's own (window, class) row for that tile: nothing in the loop is an ordinary global load
     const uint16_t* gk = p.KcF + (size_t)c * p.NT * KT_U16 + tid * 8;
     const uint16_t* gv = p.VtF + (size_t)c * p.NT * VT_U16 + tid * 8;
     const uint16_t* gk_lo = X3 ? p.KcF_lo + (size_t)c * p.NT * KT_U16 + tid * 8 : nullptr;
     const uint16_t* gv_lo = X3 ? p.VtF_lo + (size_t)c * p.NT * VT_U16 + tid * 8 : nullptr;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    auto dma_tile = [&](int jt2, int buf) {
-        uint16_t* base = lds + buf * NBUF_U16 + wave_u * 512;
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)(gk + (size_t)jt2 * KT_U16), (lds_ptr_t)base, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)(gv + (size_t)jt2 * VT_U16), (lds_ptr_t)(base + KT_U16), 16, 0, 0);
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)lds;
+    const uint32_t lds0 = lds_base + wave_u * 1024;
+    const float* lse_src = p.lse2 + ((size_t)b * p.n + c) * Tp + (lane & 7) * 4;
+    const uint32_t lse0 = lds_base + NB * NBUF_U16 * 2 + wave_u * (NB * 128);
+    auto dma_tile = [&](int jt2) {
+        const uint32_t base = lds0 + (jt2 % NB) * (NBUF_U16 * 2);
+        dma16(gk + (size_t)jt2 * KT_U16, base);
+        dma16(gv + (size_t)jt2 * VT_U16, base + KT_U16 * 2);
         if (X3) {
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(gk_lo + (size_t)jt2 * KT_U16), (lds_ptr_t)(base + PART_U16), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(gv_lo + (size_t)jt2 * VT_U16), (lds_ptr_t)(base + PART_U16 + KT_U16), 16, 0, 0);
+            dma16(gk_lo + (size_t)jt2 * KT_U16, base + PART_U16 * 2);
+            dma16(gv_lo + (size_t)jt2 * VT_U16, base + (PART_U16 + KT_U16) * 2);
         }
+        if (lane < 8) dma16(lse_src + jt2 * 32, lse0 + (jt2 % NB) * 128);
     };
+    const float* lse_lds = reinterpret_cast<const float*>(lds + NB * NBUF_U16) + wave * (NB * 32) + 4 * h;
     float lse_nx[16];
-    auto load_lse = [&](int jt2) {
+    auto load_lse = [&](int jt2) {                         // CHOSEN mode only (no DMA ring there)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 u = *reinterpret_cast<const float4*>(lse_row + jt2 * 32 + 8 * q);
             lse_nx[4 * q + 0] = u.x; lse_nx[4 * q + 1] = u.y; lse_nx[4 * q + 2] = u.z; lse_nx[4 * q + 3] = u.w;
         }
     };
-    load_lse(0);
-    if (!CHOSEN) {
-        dma_tile(0, 0);
-        __syncthreads();
+    if constexpr (CHOSEN) {
+        load_lse(0);
+    } else {
+#pragma unroll
+        for (int t = 0; t < NB - 1; ++t)
+            if (t < p.NT) dma_tile(t);
     }
 
     for (int jt = 0; jt < p.NT; ++jt) {
-        const int cur = jt & 1;
         const bool more = jt + 1 < p.NT;
-        if (!CHOSEN && more) dma_tile(jt + 1, cur ^ 1);
         float lse[16];
+        if constexpr (CHOSEN) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) lse[e] = lse_nx[e];
-        if (more) load_lse(jt + 1);                        // next tile's lse2 arrives under this tile's MFMAs
+            for (int e = 0; e < 16; ++e) lse[e] = lse_nx[e];
+            if (more) load_lse(jt + 1);                    // next tile's lse2 arrives under this tile's MFMAs
+        } else {
+            // tile jt has landed when at most the newer tile is still in flight;
+            // behind the barrier every wave is done with tile jt-1, whose buffer the next request overwrites
+            wait_tiles_in_flight(min(NB - 2, p.NT - 1 - jt), PER);
+            __builtin_amdgcn_s_barrier();
+            if (jt + NB - 1 < p.NT) dma_tile(jt + NB - 1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 u = *reinterpret_cast<const float4*>(lse_lds + (jt % NB) * 32 + 8 * q);
+                lse[4 * q + 0] = u.x; lse[4 * q + 1] = u.y; lse[4 * q + 2] = u.z; lse[4 * q + 3] = u.w;
+            }
+        }
         if (active) {
             const uint16_t* kt;
             const uint16_t* vt;
@@ -392,7 +455,7 @@ __global__ __launch_bounds__(512, 2) void ar_proto_kernel(ArProtoArgs p) {
                     vt_lo = p.VtF_lo + ((size_t)c * p.NT + jt) * VT_U16 + lane * 8;
                 }
             } else {
-                kt = lds + cur * NBUF_U16 + lane * 8;
+                kt = lds + (jt % NB) * NBUF_U16 + lane * 8;
                 vt = kt + KT_U16;
                 if (X3) { kt_lo = kt + PART_U16; vt_lo = vt + PART_U16; }
             }
@@ -400,16 +463,31 @@ __global__ __launch_bounds__(512, 2) void ar_proto_kernel(ArProtoArgs p) {
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            {   // fragment reads first, then the MFMA chain (see ar_stats)
+                bf16x8 ah[8], al[X3 ? 8 : 1];
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const bf16x8 ah = ld_frag(kt + ks * 512);
-                acc = MFMA_BF16(ah, q_hi[ks], acc);
-                if (X3) {
-                    const bf16x8 al = ld_frag(kt_lo + ks * 512);
-                    acc = MFMA_BF16(ah, q_lo[ks], acc);
-                    acc = MFMA_BF16(al, q_hi[ks], acc);
+                for (int ks = 0; ks < 8; ++ks) {
+                    ah[ks] = ld_frag(kt + ks * 512);
+                    if (X3) al[ks] = ld_frag(kt_lo + ks * 512);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    acc = MFMA_BF16(ah[ks], q_hi[ks], acc);
+                    if (X3) {
+                        acc = MFMA_BF16(ah[ks], q_lo[ks], acc);
+                        acc = MFMA_BF16(al[ks], q_hi[ks], acc);
+                    }
                 }
             }
+            // the V^T fragments are requested before the exponentials: their LDS latency hides under the vector work
+            bf16x8 vh[8], vl[X3 ? 8 : 1];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                vh[i] = ld_frag(vt + i * 512);
+                if (X3) vl[i] = ld_frag(vt_lo + i * 512);
+            }
+            __builtin_amdgcn_sched_barrier(0);
             // A^T = exp2(S^T - lse2): accumulator rows 8s..8s+7 become k-step s of the B operand
             bf16x8 a_hi[2], a_lo[2];
 #pragma unroll
@@ -426,16 +504,13 @@ __global__ __launch_bounds__(512, 2) void ar_proto_kernel(ArProtoArgs p) {
             for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const bf16x8 vh = ld_frag(vt + (dt * 2 + s) * 512);
-                    pacc[dt] = MFMA_BF16(vh, a_hi[s], pacc[dt]);
+                    pacc[dt] = MFMA_BF16(vh[dt * 2 + s], a_hi[s], pacc[dt]);
                     if (X3) {
-                        const bf16x8 vl = ld_frag(vt_lo + (dt * 2 + s) * 512);
-                        pacc[dt] = MFMA_BF16(vh, a_lo[s], pacc[dt]);
-                        pacc[dt] = MFMA_BF16(vl, a_hi[s], pacc[dt]);
+                        pacc[dt] = MFMA_BF16(vh[dt * 2 + s], a_lo[s], pacc[dt]);
+                        pacc[dt] = MFMA_BF16(vl[dt * 2 + s], a_hi[s], pacc[dt]);
                     }
                 }
         }
-        if (!CHOSEN) __syncthreads();
     }
     if (!active) return;
 
