@@ -153,3 +153,105 @@ def make_state(seed: int = 0) -> "OrderedDict[str, np.ndarray]":
             a = gain * np.sqrt(3.0 / fan_in)
             out[name] = uniform(name, shape, -a, a, seed)
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# Real-weight ingestion. The reference extracts the backbone from a MetrABS SavedModel
+# (modules/hpe/setup/2_extract_bbone_heads.py:35-60) whose EfficientNetV2-L lives in the un-vendored
+# isarandi/metrabs repo, so there is no checkpoint here to test against: what follows is the layout contract
+# (TF HWIO kernels + BatchNorm statistics -> this repo's OHWI weights + folded scale/shift), with the variable
+# names of the public efficientnetv2 implementation the reference names ('efficientnetv2-l', line 27). It is
+# exercised by a round trip through `to_keras_variables` (tests/test_abi.py); it is NOT verified on a real export.
+# ------------------------------------------------------------------------------------------------
+BN_EPS = 1e-3
+
+
+def _bn_suffix(i: int) -> str:
+    return "tpu_batch_normalization" if i == 0 else f"tpu_batch_normalization_{i}"
+
+
+def _conv_suffix(i: int) -> str:
+    return "conv2d" if i == 0 else f"conv2d_{i}"
+
+
+def keras_name_map() -> "OrderedDict[str, dict]":
+    """blob conv prefix -> {'kernel': tf name, 'bn': tf BN scope} (+ SE / depthwise entries) for every layer."""
+    m: "OrderedDict[str, dict]" = OrderedDict()
+    m["bbone.stem"] = {"kernel": "stem/conv2d/kernel", "bn": "stem/tpu_batch_normalization"}
+    for b in blocks():
+        scope = f"blocks_{b.idx}"
+        p = f"bbone.b{b.idx}"
+        if b.kind == "fused":
+            m[p + ".expand"] = {"kernel": f"{scope}/conv2d/kernel", "bn": f"{scope}/{_bn_suffix(0)}"}
+            if b.cexp != b.cin:
+                m[p + ".project"] = {"kernel": f"{scope}/conv2d_1/kernel", "bn": f"{scope}/{_bn_suffix(1)}"}
+        else:
+            m[p + ".expand"] = {"kernel": f"{scope}/conv2d/kernel", "bn": f"{scope}/{_bn_suffix(0)}"}
+            m[p + ".dw"] = {"kernel": f"{scope}/depthwise_conv2d/depthwise_kernel", "bn": f"{scope}/{_bn_suffix(1)}"}
+            m[p + ".se"] = {"reduce": f"{scope}/se/conv2d", "expand": f"{scope}/se/conv2d_1"}
+            m[p + ".project"] = {"kernel": f"{scope}/conv2d_1/kernel", "bn": f"{scope}/{_bn_suffix(2)}"}
+    m["bbone.head"] = {"kernel": "head/conv2d/kernel", "bn": "head/tpu_batch_normalization"}
+    return m
+
+
+def state_from_keras(variables, head_kernel=None, head_bias=None, eps: float = BN_EPS) -> "OrderedDict[str, np.ndarray]":
+    """TF/Keras variables (name -> array, names as in `keras_name_map`) -> this repo's state:
+    conv kernels HWIO -> [O,H,W,I]; depthwise [3,3,C,1] -> [C,3,3]; SE 1x1 convs [1,1,I,O] -> [O,I];
+    BatchNorm folded: scale = gamma / sqrt(moving_variance + eps), shift = beta - moving_mean * scale.
+    `head_kernel` [1,1,1280,288] / `head_bias` = MetrABS `heatmap_heads.conv_final`
+    (2_extract_bbone_heads.py:66-67, 4_create_heads_onnx.py:22-25: weight = W.squeeze().T)."""
+    v = {k.split(":")[0]: np.asarray(a, dtype=np.float32) for k, a in variables.items()}
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+
+    def bn(scope):
+        g, b2 = v[scope + "/gamma"], v[scope + "/beta"]
+        mu, var = v[scope + "/moving_mean"], v[scope + "/moving_variance"]
+        sc = g / np.sqrt(var + eps)
+        return sc.astype(np.float32), (b2 - mu * sc).astype(np.float32)
+
+    for p, e in keras_name_map().items():
+        if p.endswith(".se"):
+            r, x = e["reduce"], e["expand"]
+            out[p + ".w1"] = np.ascontiguousarray(v[r + "/kernel"][0, 0].T)          # [cse, C]
+            out[p + ".b1"] = v[r + "/bias"]
+            out[p + ".w2"] = np.ascontiguousarray(v[x + "/kernel"][0, 0].T)          # [C, cse]
+            out[p + ".b2"] = v[x + "/bias"]
+            continue
+        k = v[e["kernel"]]
+        if p.endswith(".dw"):
+            out[p + ".w"] = np.ascontiguousarray(np.transpose(k[:, :, :, 0], (2, 0, 1)))   # [C,3,3]
+        else:
+            out[p + ".w"] = np.ascontiguousarray(np.transpose(k, (3, 0, 1, 2)))            # HWIO -> OHWI
+        out[p + ".scale"], out[p + ".shift"] = bn(e["bn"])
+    if head_kernel is not None:
+        out["head.weight"] = np.ascontiguousarray(np.asarray(head_kernel, np.float32).squeeze().T)
+        out["head.bias"] = np.asarray(head_bias, np.float32)
+    shapes = tensor_shapes()
+    for name, a in out.items():
+        if tuple(a.shape) != tuple(shapes[name]):
+            raise ValueError(f"{name}: converted shape {a.shape} != expected {shapes[name]}")
+    # same tensor order as tensor_shapes()
+    return OrderedDict((n, out[n]) for n in shapes if n in out)
+
+
+def to_keras_variables(state, eps: float = BN_EPS):
+    """Inverse of `state_from_keras` with gamma = scale, beta = shift, mean 0, variance 1 - eps (test helper)."""
+    v = {}
+    for p, e in keras_name_map().items():
+        if p.endswith(".se"):
+            v[e["reduce"] + "/kernel"] = np.ascontiguousarray(state[p + ".w1"].T)[None, None]
+            v[e["reduce"] + "/bias"] = state[p + ".b1"]
+            v[e["expand"] + "/kernel"] = np.ascontiguousarray(state[p + ".w2"].T)[None, None]
+            v[e["expand"] + "/bias"] = state[p + ".b2"]
+            continue
+        w = state[p + ".w"]
+        if p.endswith(".dw"):
+            v[e["kernel"]] = np.ascontiguousarray(np.transpose(w, (1, 2, 0)))[..., None]
+        else:
+            v[e["kernel"]] = np.ascontiguousarray(np.transpose(w, (1, 2, 3, 0)))
+        c = w.shape[0]
+        v[e["bn"] + "/gamma"] = state[p + ".scale"]
+        v[e["bn"] + "/beta"] = state[p + ".shift"]
+        v[e["bn"] + "/moving_mean"] = np.zeros(c, np.float32)
+        v[e["bn"] + "/moving_variance"] = np.full(c, 1.0 - eps, np.float32)
+    return v

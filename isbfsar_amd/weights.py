@@ -167,11 +167,22 @@ def unpack_blob(blob: bytes) -> "OrderedDict[str, np.ndarray]":
 
 def state_from_torch(state_dict: Mapping[str, "object"], keys: Iterable[str] | None = None) -> Dict[str, np.ndarray]:
     """Convert a torch ``state_dict`` (e.g. the reference's ``DISC.pth['model_state_dict']``,
-    ``modules/ar/ar.py:17-19``) into the numpy mapping ``pack_blob`` takes. ``.module`` infixes
-    left by ``DataParallel`` are stripped exactly as ``ar.py:18`` does."""
+    ``modules/ar/ar.py:17-19``) into the numpy mapping ``pack_blob`` takes.
+
+    * ``.module`` infixes left by ``DataParallel`` are stripped exactly as ``ar.py:18`` does;
+    * checkpoints written before the reference grew its RGB branch name the skeleton MLP
+      ``features_extractor.fc1/fc2``; the reference migrates them once with
+      ``utils/rename_torch_layers_and_parameters.py:11`` (``features_extractor`` -> ``features_extractor.sk``):
+      the same rename is applied here to keys that do not carry the ``.sk`` level yet;
+    * ``post_resnet.*`` (RGB branch, zero-filled by that script, lines 12-13) is not on the skeleton path and
+      is dropped."""
     out = {}
     for k, v in state_dict.items():
         k2 = k.replace(".module", "")
+        if k2.startswith("features_extractor.") and not k2.startswith("features_extractor.sk."):
+            k2 = "features_extractor.sk." + k2[len("features_extractor."):]
+        if k2.startswith("post_resnet.") or k2.startswith("features_extractor.rgb."):
+            continue
         if keys is not None and k2 not in keys:
             continue
         out[k2] = np.asarray(v.detach().cpu().numpy() if hasattr(v, "detach") else v, dtype=np.float32)

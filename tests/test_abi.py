@@ -70,3 +70,44 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 txt = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), os.path.join(dp, f)
+
+
+def test_checkpoint_key_migration():
+    """state_from_torch accepts the three key dialects the reference has used for DISC.pth: DataParallel's
+    `.module` infix (ar.py:18), the pre-RGB `features_extractor.fc1` names migrated by
+    utils/rename_torch_layers_and_parameters.py:11, and the current names; the RGB-only `post_resnet.*` is dropped."""
+    import numpy as np
+    from isbfsar_amd import weights
+    ref = weights.make_ar_state(16, 30, seed=3)
+    old = {}
+    for k, v in ref.items():
+        k_old = k.replace("features_extractor.sk.", "features_extractor.")
+        k_old = k_old.replace("transformers.0.", "transformers.module.0.", 1) if k_old.startswith("transformers.0.k_linear") else k_old
+        old[k_old] = v
+    old["post_resnet.l1.weight"] = np.zeros((256, 2048), np.float32)
+    old["post_resnet.l1.bias"] = np.zeros(256, np.float32)
+    got = weights.state_from_torch(old)
+    assert set(got) == set(ref)
+    for k in ref:
+        np.testing.assert_array_equal(got[k], ref[k])
+    # idempotent on current names
+    again = weights.state_from_torch(ref)
+    assert set(again) == set(ref)
+
+
+def test_keras_variable_round_trip():
+    """effnetv2.state_from_keras: TF layouts (HWIO kernels, [3,3,C,1] depthwise, 1x1 SE convs, BatchNorm statistics)
+    -> blob tensors. Round trip through the inverse helper reproduces the state (variance 1-eps, mean 0 make the
+    fold exact up to one float32 rounding)."""
+    import numpy as np
+    from isbfsar_amd import effnetv2
+    st = effnetv2.make_state(1)
+    kv = effnetv2.to_keras_variables(st)
+    hk = np.ascontiguousarray(st["head.weight"].T)[None, None]
+    back = effnetv2.state_from_keras({k + ":0": a for k, a in kv.items()}, hk, st["head.bias"])
+    assert list(back) == list(st)
+    for k in st:
+        if k.endswith(".scale") or k.endswith(".shift"):
+            np.testing.assert_allclose(back[k], st[k], rtol=2e-7, atol=0)
+        else:
+            np.testing.assert_array_equal(back[k], st[k])
