@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libisbfsar_hip.so")
+# ISB_LIB_PATH: load another build of the SAME library (A/B timing of two builds inside one GPU session)
+LIB_PATH = os.environ.get("ISB_LIB_PATH") or os.path.join(_HERE, "csrc", "libisbfsar_hip.so")
 
 ISB_AR_PREC_BF16 = 0
 ISB_AR_PREC_BF16X3 = 1

@@ -132,6 +132,7 @@ struct ConvArgs {
     // 1/2 = 1-D grid decoded per XCD (workgroup id % 8 = XCD): all N tiles of an M tile run back to back on
     // ONE XCD, so its L2 fetches the A rows once (1: M tiles interleaved over XCDs, 2: contiguous M ranges)
     int grid_mode, grid_m, grid_n;
+    int grid_bias_off;      // gated gemm1x1 kernels: LDS byte offset of the tile's bias row (set by the launcher)
 };
 int launch_conv_igemm(const ConvArgs& a, hipStream_t st);
 int launch_conv_expand_dw(const ConvArgs& a, hipStream_t st);
