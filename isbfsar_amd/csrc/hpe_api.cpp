@@ -28,7 +28,8 @@ struct BlockW {
 
 // public efficientnetv2-l table (mirrors isbfsar_amd/effnetv2.py::STAGES)
 struct StageDef { bool fused; int repeats, expand, stride, cin, cout; bool se; };
-constexpr int kMinSplit = 64;     // a batch this large is run as two concurrent halves
+constexpr int kMinSplit = 64;     // a batch this large is run as concurrent parts (>= 32 frames each)
+constexpr int kMaxLanes = 4;
 const StageDef kStages[] = {
     {true, 4, 1, 1, 32, 32, false},   {true, 7, 4, 2, 32, 64, false},   {true, 7, 4, 2, 64, 96, false},
     {false, 10, 4, 2, 96, 192, true}, {false, 19, 6, 1, 192, 224, true}, {false, 25, 6, 2, 224, 384, true},
@@ -63,9 +64,9 @@ struct isb_hpe {
     bool has_indices = false;
     // workspace
     DevBuf zeros;
-    Lane lanes[2];
-    int n_lanes = 2;              // ISB_HPE_LANES=1 disables the split
-    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    Lane lanes[kMaxLanes];
+    int n_lanes = 2;              // ISB_HPE_LANES=1 disables the split, up to kMaxLanes
+    hipEvent_t fork_ev = nullptr, join_ev[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
     // profiling of conv_igemm launches
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
@@ -277,10 +278,12 @@ extern "C" int isb_hpe_create(const isb_hpe_cfg* cfg, isb_hpe** out) {
     ISB_TRY(h->zeros.alloc(256));
     ISB_HIP(hipMemset(h->zeros.p, 0, 256));
     h->fuse_front = getenv("ISB_FUSE_FRONT") != nullptr;
-    if (const char* e = getenv("ISB_HPE_LANES")) h->n_lanes = atoi(e) >= 2 ? 2 : 1;
-    ISB_HIP(hipStreamCreateWithFlags(&h->lanes[1].side, hipStreamNonBlocking));
+    if (const char* e = getenv("ISB_HPE_LANES")) h->n_lanes = std::max(1, std::min(kMaxLanes, atoi(e)));
     ISB_HIP(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
-    ISB_HIP(hipEventCreateWithFlags(&h->join_ev, hipEventDisableTiming));
+    for (int l = 1; l < kMaxLanes; ++l) {
+        ISB_HIP(hipStreamCreateWithFlags(&h->lanes[l].side, hipStreamNonBlocking));
+        ISB_HIP(hipEventCreateWithFlags(&h->join_ev[l], hipEventDisableTiming));
+    }
     *out = h.release();
     return ISB_OK;
     });
@@ -295,9 +298,11 @@ extern "C" void isb_hpe_destroy(isb_hpe* h) {
         (void)hipEventDestroy(e.second);
     }
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
-    if (h->lanes[1].side) (void)hipStreamDestroy(h->lanes[1].side);
+    for (int l = 1; l < kMaxLanes; ++l) {
+        if (h->lanes[l].side) (void)hipStreamDestroy(h->lanes[l].side);
+        if (h->join_ev[l]) (void)hipEventDestroy(h->join_ev[l]);
+    }
     if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
-    if (h->join_ev) (void)hipEventDestroy(h->join_ev);
     delete h;
 }
 
@@ -434,15 +439,21 @@ extern "C" int isb_hpe_forward(isb_hpe* h, const uint8_t* d_frames, const int32_
         const int Bm = std::min(Bm_max, B - b0);
         // every sample is independent, so the split changes no result. Small batches (latency regime) and the
         // per-launch profiling pass stay on one lane.
-        if (h->n_lanes >= 2 && Bm >= kMinSplit && !h->prof) {
-            const int B0 = (Bm + 1) / 2;
-            Lane& L1 = h->lanes[1];
+        const int nl = std::min(h->n_lanes, Bm / 32);
+        if (nl >= 2 && Bm >= kMinSplit && !h->prof) {
+            const int part = (Bm + nl - 1) / nl;
             ISB_HIP(hipEventRecord(h->fork_ev, st));
-            ISB_HIP(hipStreamWaitEvent(L1.side, h->fork_ev, 0));
-            ISB_TRY(run_lane(L1, L1.side, b0 + B0, Bm - B0));
-            ISB_TRY(run_lane(h->lanes[0], st, b0, B0));
-            ISB_HIP(hipEventRecord(h->join_ev, L1.side));
-            ISB_HIP(hipStreamWaitEvent(st, h->join_ev, 0));
+            for (int l = 1; l < nl; ++l) {
+                Lane& L = h->lanes[l];
+                const int lo = l * part, n = std::min(part, Bm - lo);
+                if (n <= 0) break;
+                ISB_HIP(hipStreamWaitEvent(L.side, h->fork_ev, 0));
+                ISB_TRY(run_lane(L, L.side, b0 + lo, n));
+                ISB_HIP(hipEventRecord(h->join_ev[l], L.side));
+            }
+            ISB_TRY(run_lane(h->lanes[0], st, b0, std::min(part, Bm)));
+            for (int l = 1; l < nl; ++l)
+                if (l * part < Bm) ISB_HIP(hipStreamWaitEvent(st, h->join_ev[l], 0));
         } else {
             ISB_TRY(run_lane(h->lanes[0], st, b0, Bm));
         }
