@@ -827,6 +827,168 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_dma_kernel(ConvArgs p)
     conv_epilogue<TM, TN, WGM, WGN, true>(p, acc, lds, m0, n0, wm, wn, r, h, tid, bias_off);
 }
 
+// -------------------------------------------------------------------------------------------
+// 3x3 convolutions (stride 1 pad 1, or stride 2 with TF-SAME bottom/right padding) with the same lean k loop as
+// gemm1x1_dma_kernel. The A operand is addressed as a RAW BUFFER: a lane's byte offset is fixed (its output pixel,
+// window origin), the filter tap and channel block are one SCALAR offset per k-step, and padding costs no data
+// movement at all -- a lane whose tap falls outside the image (9-bit mask, computed once) submits an out-of-range
+// offset and the hardware returns zeros (buffer_load ... lds). The buffer base sits pad*(W+1) pixels before the
+// tensor so that window origins of border pixels are non-negative offsets.
+// -------------------------------------------------------------------------------------------
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void dma16_buf(i32x4_t rsrc, uint32_t voff, uint32_t soff, uint32_t lds_addr) {
+    const uint32_t la = __builtin_amdgcn_readfirstlane(lds_addr);
+    const uint32_t so = __builtin_amdgcn_readfirstlane(soff);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(voff), "s"(rsrc), "s"(la), "s"(so) : "memory");
+}
+
+template <int TM, int TN, int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_dma_kernel(ConvArgs p) {
+    constexpr int NW = WGM * WGN;
+    constexpr int BM = 32 * TM * WGM;
+    constexpr int BN = 32 * TN * WGN;
+    constexpr int A_INST = BM / 16, B_INST = BN / 16;
+    constexpr int A_PW = (A_INST + NW - 1) / NW, B_PW = (B_INST + NW - 1) / NW;
+    constexpr int BUF = (BM + BN) * ROWB;
+    constexpr int CROW = BN * 2 + 16;
+    constexpr int LDS_BYTES = (2 * BUF > BM * CROW || BM * CROW > 65536) ? 2 * BUF : BM * CROW;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES + BN * 4];
+    constexpr int bias_off = LDS_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int r = lane & 31, h = lane >> 5;
+    int m0, n0;
+    if (!conv_tile_origin(p, BM, BN, m0, n0)) return;
+
+    // A: per-lane window origin (relative to the shifted base) + validity of the 9 taps
+    const int ohw = p.OH * p.OW;
+    const uint32_t pix = (uint32_t)p.Cin * 2u;                                  // bytes per pixel
+    const uint32_t shift = (uint32_t)(p.pad * (p.W + 1)) * pix;                 // base' = in - shift
+    const uint32_t nrec = (uint32_t)((size_t)p.B * p.H * p.W * p.Cin * 2) + shift;
+    i32x4_t rsrc;
+    {
+        const uint64_t base = (uint64_t)(uintptr_t)p.in - shift;
+        rsrc.x = (int)(uint32_t)base;
+        rsrc.y = (int)(uint32_t)(base >> 32);                                   // stride 0, no swizzle
+        rsrc.z = (int)nrec;
+        rsrc.w = 0x00020000;
+    }
+    uint32_t a_voff[A_PW], a_mask[A_PW], b_voff[B_PW];
+#pragma unroll
+    for (int s = 0; s < A_PW; ++s) {
+        const int row = 16 * (wave + NW * s) + (lane >> 2);
+        const int logical = (lane & 3) ^ ((row >> 2) & 3);
+        const int m = m0 + row;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int b = mm / ohw, rem = mm - b * ohw;
+        const int oy = rem / p.OW, ox = rem - oy * p.OW;
+        const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+        a_voff[s] = (uint32_t)((b * p.H + oy * p.stride) * p.W + ox * p.stride) * pix + logical * 16;
+        uint32_t mk = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int iy = iy0 + t / 3, ix = ix0 + t % 3;
+            if (ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) mk |= 1u << t;
+        }
+        a_mask[s] = mk;
+    }
+#pragma unroll
+    for (int s = 0; s < B_PW; ++s) {
+        const int row = 16 * (wave + NW * s) + (lane >> 2);
+        const int logical = (lane & 3) ^ ((row >> 2) & 3);
+        b_voff[s] = (uint32_t)min(n0 + row, p.Cout - 1) * (uint32_t)(p.K * 2) + logical * 16;
+    }
+    const unsigned char* b_base = reinterpret_cast<const unsigned char*>(p.w);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)lds + wave * 1024;
+    if (wave == 0) {
+#pragma unroll
+        for (int o = 0; o < BN / 4; o += 64)
+            if (lane + o < BN / 4)
+                dma16_s(p.bias, (uint32_t)min(n0 + (lane + o) * 4, p.Cout - 4) * 4,
+                        (uint32_t)(uintptr_t)(lds_ptr_t)lds + bias_off + o * 16);
+    }
+    // scalar k-step state: tap index, channel offset inside the tap, byte offset of the tap's pixel
+    int tap = 0, c0 = 0;
+    uint32_t tap_soff = 0;
+    auto dma = [&](auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+        const uint32_t soff = tap_soff + (uint32_t)c0 * 2u;
+#pragma unroll
+        for (int s = 0; s < A_PW; ++s)
+            if (wave + NW * s < A_INST) {
+                const uint32_t vo = ((a_mask[s] >> tap) & 1u) ? a_voff[s] : 0x80000000u;   // + soff cannot wrap back in range
+                dma16_buf(rsrc, vo, soff, lds0 + (buf * BUF + NW * s * 1024));
+            }
+#pragma unroll
+        for (int s = 0; s < B_PW; ++s)
+            if (wave + NW * s < B_INST) dma16_s(b_base, b_voff[s], lds0 + (buf * BUF + BM * ROWB + NW * s * 1024));
+        b_base += CK * 2;
+        c0 += CK;
+        if (c0 == p.Cin) {                      // next tap: one pixel to the right, or back two and down a row
+            c0 = 0;
+            ++tap;
+            tap_soff += (tap % 3 == 0) ? (uint32_t)(p.W - 2) * pix : pix;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    int a_sw[2], b_sw[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        a_sw[ks] = swz(wm * TM * 32 + r, 2 * ks + h);
+        b_sw[ks] = BM * ROWB + swz(wn * TN * 32 + r, 2 * ks + h);
+    }
+    auto compute = [&](auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[TM], bfr[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + a_sw[ks] + (buf * BUF + i * 2048)));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + b_sw[ks] + (buf * BUF + j * 2048)));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    };
+    auto publish = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+
+    const int nkt = p.K / CK;
+    dma(std::integral_constant<int, 0>{});
+    publish();
+    int kt = 0;
+    for (; kt + 2 <= nkt; kt += 2) {
+        dma(std::integral_constant<int, 1>{});
+        compute(std::integral_constant<int, 0>{});
+        publish();
+        if (kt + 2 < nkt) dma(std::integral_constant<int, 0>{});
+        compute(std::integral_constant<int, 1>{});
+        publish();
+    }
+    if (kt < nkt) {
+        compute(std::integral_constant<int, 0>{});
+        __syncthreads();
+    }
+    conv_epilogue<TM, TN, WGM, WGN, true>(p, acc, lds, m0, n0, wm, wn, r, h, tid, bias_off);
+}
+
 static int conv_grid_mode() {
     static const int mode = [] {
         const char* e = getenv("ISB_CONV_GRID");     // tuning override; 1 measured 4 % faster than the 2-D grid
@@ -862,7 +1024,8 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t st) {
         // chosen by measurement on MI355X (tools/conv_sweep.py, tools/conv_probe*.py, profiles/README.md):
         //   * 1x1 stride-1 convolutions are plain GEMMs and run on the lean gemm1x1 kernels (131-139 without,
         //     141-148 with an SE gate), 8 waves of 32 x 64..96 sub-tiles: high occupancy beats big tiles here;
-        //   * 3x3 convolutions (implicit GEMM with taps and padding) stay on the general LDS-DMA kernels;
+        //   * 3x3 convolutions run on conv3x3_dma_kernel (161-166: raw-buffer A operand, hardware zero padding);
+        //     the general LDS-DMA kernels remain for shapes outside its contract;
         //   * a single frame (M <= 2048) needs many small workgroups: 64-row tiles.
         const bool g1 = a.KH == 1 && a.stride == 1 && a.pad == 0 && a.zeros;
         const int ohw = a.OH * a.OW;
@@ -881,6 +1044,11 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t st) {
             else if (a.Cout == 224) v = 143;           // 128 x 224
             else if (a.Cout % 192 == 0) v = 141;       // 128 x 192
             else v = 142;                              // 128 x 128
+        } else if (!a.gate && a.KH == 3 && a.KW == 3 && ((a.stride == 1 && a.pad == 1) || (a.stride == 2 && a.pad == 0)) &&
+                   (size_t)a.B * a.H * a.W * a.Cin * 2 + (size_t)(a.W + 1) * a.Cin * 2 < 0x7ffffff0ull) {
+            if (a.Cout == 32) v = 163;                // 256 x  32   (lean 3x3, buffer-addressed A operand)
+            else if (a.Cout % 192 == 0) v = 161;      // 128 x 192
+            else v = 162;                             // 128 x 128
         } else if (!a.gate && a.zeros) {
             if (a.Cout == 32) v = 59;                 // 256 x  32, 8 waves
             else if (a.Cout % 192 == 0) v = 54;       // 128 x 192, 8 waves of 32 x 96
@@ -1070,6 +1238,24 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t st) {
         case 138: ISB_CONV_LAUNCH_G1(1, 1, 2, 2); break;   //  64 x  64
         case 139: ISB_CONV_LAUNCH_G1(2, 4, 4, 2); break;   // 256 x 256 (8 waves of 64 x 128)
 #undef ISB_CONV_LAUNCH_G1
+#define ISB_CONV_LAUNCH_C3(TM, TN, WGM, WGN)                                                                     \
+    do {                                                                                                         \
+        const bool same1 = a.stride == 1 && a.pad == 1, same2 = a.stride == 2 && a.pad == 0;                     \
+        if (a.gate || a.KH != 3 || a.KW != 3 || !(same1 || same2) ||                                             \
+            (size_t)a.B * a.H * a.W * a.Cin * 2 + (size_t)(a.W + 1) * a.Cin * 2 >= 0x7ffffff0ull) {             \
+            set_error("conv_igemm: variants 161-169 are un-gated 3x3 convolutions on tensors below 2 GiB");      \
+            return ISB_ERR_INVALID;                                                                              \
+        }                                                                                                        \
+        const dim3 g = conv_grid(aa, 32 * TM * WGM, 32 * TN * WGN);                                              \
+        hipLaunchKernelGGL((conv3x3_dma_kernel<TM, TN, WGM, WGN>), g, dim3(64 * WGM * WGN), 0, st, aa);          \
+    } while (0)
+        case 161: ISB_CONV_LAUNCH_C3(1, 3, 4, 2); break;   // 128 x 192
+        case 162: ISB_CONV_LAUNCH_C3(1, 2, 4, 2); break;   // 128 x 128
+        case 163: ISB_CONV_LAUNCH_C3(1, 1, 8, 1); break;   // 256 x  32
+        case 164: ISB_CONV_LAUNCH_C3(2, 2, 4, 2); break;   // 256 x 128
+        case 165: ISB_CONV_LAUNCH_C3(1, 2, 8, 1); break;   // 256 x  64
+        case 166: ISB_CONV_LAUNCH_C3(2, 3, 4, 2); break;   // 256 x 192
+#undef ISB_CONV_LAUNCH_C3
 #define ISB_CONV_LAUNCH_G1G(TM, TN, WGM, WGN)                                                                    \
     do {                                                                                                         \
         constexpr int BM_ = 32 * TM * WGM, BN_ = 32 * TN * WGN;                                                  \

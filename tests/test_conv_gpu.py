@@ -44,18 +44,23 @@ CASES = [
     (5, 8, 256, 384, 1, 1, 0, True, True),
     (3, 16, 96, 64, 1, 1, 0, True, False),        # un-gated projection with residual, 3 k-steps, ragged M
     (4, 32, 160, 224, 1, 1, 1, False, False),     # 5 k-steps (odd), 224 = 7 x 32 output channels
+    (3, 16, 96, 160, 3, 1, 1, False, False),      # 3x3, 3 k-steps per tap, ragged M (768 rows), Cout tile overhang
+    (2, 32, 64, 64, 3, 2, 0, True, False),        # 3x3 stride 2 (TF SAME), residual, no activation
 ]
 G1 = [131, 132, 133, 134, 135, 136, 137, 138, 139]   # lean 1x1 GEMM kernels
+C3 = [161, 162, 163, 164, 165, 166]                  # lean 3x3 kernels (buffer-addressed A operand)
 GATED_DMA = [81, 82, 83, 84, 85, 86, 91, 92, 93, 94, 95, 96, 111, 112, 113, 114, 115, 116, 141, 142, 143, 144, 145, 146, 147, 148]
 K64 = [101, 102, 103, 104, 105, 106, 107, 108, 111, 112, 113, 114, 115, 116]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 13, 14, 15, 16, 17, 18, 19, 21, 23, 26, 27, 28, 31, 33, 36, 37, 41, 42, 43, 44, 45, 47, 48, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63, 64, 65, 71, 72, 73, 74, 75, 76, 101, 102, 103, 104, 105, 106, 107, 108] + GATED_DMA + G1)
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 13, 14, 15, 16, 17, 18, 19, 21, 23, 26, 27, 28, 31, 33, 36, 37, 41, 42, 43, 44, 45, 47, 48, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63, 64, 65, 71, 72, 73, 74, 75, 76, 101, 102, 103, 104, 105, 106, 107, 108] + GATED_DMA + G1 + C3)
 @pytest.mark.parametrize("case", CASES)
 def test_conv_variants(case, variant):
     B, H, Cin, Cout, k, stride, act, use_res, use_gate = case
     if (11 <= variant <= 39 or 51 <= variant <= 69) and use_gate:
         pytest.skip("the LDS-DMA kernels take no SE gate")
+    if variant in C3 and (use_gate or k != 3):
+        pytest.skip("161-169 are un-gated 3x3 convolutions")
     if variant in G1 and (use_gate or k != 1 or stride != 1):
         pytest.skip("131-139 are un-gated 1x1 stride-1 GEMMs")
     if 101 <= variant <= 109 and use_gate:
