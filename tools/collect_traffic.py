@@ -10,10 +10,10 @@ import sys
 
 
 def family(name: str) -> str:
-    if "conv_igemm" in name or "gemm1x1" in name:
-        return "conv_igemm"
     if "dwconv3x3" in name:
         return "dwconv3x3_pool"
+    if "conv_igemm" in name or "gemm1x1" in name or "conv3x3_dma" in name:
+        return "conv_igemm"
     if "se_fc" in name:
         return "se_fc"
     if "ar_" in name:

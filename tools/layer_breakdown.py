@@ -9,7 +9,7 @@ from isbfsar_amd import effnetv2 as E
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-ig = [r for r in rows if 'conv_igemm' in r['Kernel_Name'] or 'gemm1x1' in r['Kernel_Name']]
+ig = [r for r in rows if 'conv_igemm' in r['Kernel_Name'] or 'gemm1x1' in r['Kernel_Name'] or 'isb::conv3x3_dma' in r['Kernel_Name']]
 convs = []
 for b in E.blocks():
     if b.kind == 'fused':
