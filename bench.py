@@ -146,11 +146,19 @@ def main():
         args.gpus = 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
+    # rehearsal of the N > 1 code path on a ONE-GPU box: ISB_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
+    # ISB_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device); never used by the driver
+    if os.environ.get("ISB_BENCH_ONE_DEVICE") == "1":
+        local = 0
+    backend = os.environ.get("ISB_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     W = pick_workload(args.workload)(args, rank, world, local)
 
@@ -174,7 +182,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    roof = W.roofline(max(1, min(args.steps, 3))) if rank == 0 else None
+    # EVERY rank runs the profiling pass: its steps contain the step's all-gather, a collective that rank 0 alone
+    # would wait on forever; only rank 0's numbers are reported
+    roof = W.roofline(max(1, min(args.steps, 3)))
+    barrier()
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = W.cpu_baseline(args.cpu_sample)

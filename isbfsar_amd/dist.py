@@ -46,6 +46,10 @@ def all_gather_records(rec, counts=None):
     world = dist.get_world_size()
     if world == 1:
         return rec
+    if rec.is_cuda and dist.get_backend() == "gloo":
+        # gloo has no device all-gather: only reached when the N > 1 path is rehearsed on a one-GPU box
+        # (bench.py, ISB_BENCH_BACKEND=gloo); RCCL ("nccl") gathers the device tensors directly
+        return all_gather_records(rec.cpu(), counts).to(rec.device)
     if counts is None or len(set(counts)) == 1:
         out = torch.empty((world * rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=rec.device)
         dist.all_gather_into_tensor(out, rec)
