@@ -258,6 +258,32 @@ def test_two_lane_split_is_bit_identical(bbone_state, assets):
         e.close()
 
 
+def test_full_size_properties(bbone_state, assets):
+    """BASELINE configs[1] size (256 frames per GPU): properties that need no oracle run --
+    determinism, invariance under re-batching (4 x 64 through two lanes each vs 256 through two lanes),
+    a permutation of the frames permutes the poses, all poses finite, every synthetic frame valid."""
+    from isbfsar_amd.hpe_engine import HpeEngine
+    e = HpeEngine(device=0, max_batch=256)
+    try:
+        e.set_joint_map(assets[0], None)
+        e.load_weights(bbone_state)
+        fr = synth.frames(256, seed=4000)
+        bb = synth.bboxes(256, seed=4000)
+        j1, v1 = e.forward(fr, bb)
+        j2, v2 = e.forward(fr, bb)
+        assert np.array_equal(j1, j2) and np.array_equal(v1, v2)
+        parts = [e.forward(fr[i:i + 64], bb[i:i + 64]) for i in range(0, 256, 64)]
+        assert np.array_equal(np.concatenate([p[0] for p in parts]), j1)
+        assert np.array_equal(np.concatenate([p[1] for p in parts]), v1)
+        perm = np.random.default_rng(0).permutation(256)
+        jp, vp = e.forward(fr[perm], bb[perm])
+        assert np.array_equal(jp, j1[perm]) and np.array_equal(vp, v1[perm])
+        assert np.isfinite(j1).all() and j1.shape == (256, 122, 3)
+        assert v1.all()
+    finally:
+        e.close()
+
+
 def test_pose_windows_kernel():
     import torch
     from isbfsar_amd.hpe_engine import pose_windows
