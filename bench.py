@@ -95,8 +95,13 @@ class ArWorkload:
         avg_s = ms / max(launches, 1) / 1e3
         achieved = flops_per_launch / avg_s / 1e12
         peak = MFMA_PEAK_TFLOPS[self.precision]
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tj) and chunk == 1024 and self.way == 60 and self.precision == "bf16":
+            with open(tj) as f:       # HBM bytes of one ar_proto launch (PMC passes, profiles/README.md)
+                traffic = json.load(f).get("ar_b1024", {}).get("ar_proto", {}).get("hbm_bytes_per_launch")
         return {"bound": "mfma", "kernel": "ar_proto_kernel", "achieved": round(achieved, 2), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                 "avg_launch_ms": round(ms / max(launches, 1), 4), "launches": int(launches)}
 
     def cpu_baseline(self, sample):

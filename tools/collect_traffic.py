@@ -43,5 +43,20 @@ for f in sorted(set(fetch) | set(write)):
     fk, wk = fetch[f] / forwards, write[f] / forwards
     out["hpe_b256"][f] = {"FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "launches": nf[f] / forwards,
                           "hbm_bytes_per_forward": (2.0 * fk + wk) * 1024.0}
+# optional: the same two passes of `bench.py --workload ar --steps 1 --warmup 1 --no-cpu-baseline` (argv[4], argv[5])
+if len(sys.argv) > 5:
+    def per_launch(path, counter, key):
+        tot = n = 0
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] == counter and key in r["Kernel_Name"]:
+                tot += float(r["Counter_Value"])
+                n += 1
+        return tot / max(n, 1), n
+    out["ar_b1024"] = {}
+    for key, name in (("ar_proto_kernel<false, false>", "ar_proto"), ("ar_stats_kernel", "ar_stats")):
+        fk, n = per_launch(sys.argv[4], "FETCH_SIZE", key)
+        wk, _ = per_launch(sys.argv[5], "WRITE_SIZE", key)
+        out["ar_b1024"][name] = {"FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "launches_in_trace": n,
+                                 "hbm_bytes_per_launch": (2.0 * fk + wk) * 1024.0}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps({k: round(v["hbm_bytes_per_forward"] / 1e9, 2) for k, v in out["hpe_b256"].items()}), "GB per forward;", forwards, "forwards")

@@ -16,5 +16,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun
 echo "== PMC traffic"
 ISB_HPE_LANES=1 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o run -- python3 bench.py --workload hpe --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_fetch.log 2>&1
 ISB_HPE_LANES=1 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o run -- python3 bench.py --workload hpe --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_write.log 2>&1
-python3 tools/collect_traffic.py gpurun_out/pmc_fetch/run_counter_collection.csv gpurun_out/pmc_write/run_counter_collection.csv gpurun_out/traffic.json
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_ar_fetch -o run -- python3 bench.py --workload ar --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_ar_fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_ar_write -o run -- python3 bench.py --workload ar --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_ar_write.log 2>&1
+python3 tools/collect_traffic.py gpurun_out/pmc_fetch/run_counter_collection.csv gpurun_out/pmc_write/run_counter_collection.csv gpurun_out/traffic.json gpurun_out/pmc_ar_fetch/run_counter_collection.csv gpurun_out/pmc_ar_write/run_counter_collection.csv
 echo done
