@@ -199,9 +199,11 @@ int launch_ar_tuples(const ArTupleArgs& a, hipStream_t st) {
 
 // =====================================================================================
 // stats: lse2[b,c,j] = log2 sum_{i<T} exp2(s'[j,i]),  s' = Kc_j . Kq'_i
-// grid (ceil(n*NT/8), B), block 512 = 8 waves; wave = one (class, j-tile) slot of window b.
+// 1-D grid (see the decode below), block 512 = 8 waves; wave = one (class, j-tile) slot of window b.
 // The window's Kq fragment tiles stream through a double-buffered LDS ring shared by the 8 waves.
 // =====================================================================================
+constexpr int STATS_WT = 8, STATS_ST = 16;
+
 template <bool X3, bool ONLINE>
 __global__ __launch_bounds__(512, 2) void ar_stats_kernel(ArStatsArgs p) {
     constexpr int TILE_U16 = 8 * 64 * 8;                  // one K tile: 8 chunks of 1 KiB
@@ -210,8 +212,17 @@ __global__ __launch_bounds__(512, 2) void ar_stats_kernel(ArStatsArgs p) {
     constexpr int PER = X3 ? 2 : 1;                       // DMA instructions per wave and tile
     __shared__ __attribute__((aligned(16))) uint16_t lds[NB * NBUF_U16];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, r = lane & 31;
-    const int b = blockIdx.y;
-    const int slot = blockIdx.x * 8 + wave;
+    // 1-D grid decoded per XCD (workgroup id % 8 = XCD) into blocks of STATS_WT windows x STATS_ST slot groups, slot
+    // groups fastest: the block's Kq tiles (0.9 MiB) and class K fragments (1 MiB) are reused out of that XCD's L2
+    const int id = blockIdx.x, xcd = id & 7, sl = id >> 3;
+    const int nsg = (p.n * p.NT + 7) >> 3;                          // groups of 8 (class, j-tile) slots
+    const int nsb = (nsg + STATS_ST - 1) / STATS_ST;
+    const int blk = sl / (STATS_WT * STATS_ST), within = sl - blk * (STATS_WT * STATS_ST);
+    const int wbi = blk / nsb, sb = blk - wbi * nsb;
+    const int sg = sb * STATS_ST + within % STATS_ST;
+    const int b = ((wbi * STATS_WT + within / STATS_ST) << 3) + xcd;
+    if (sg >= nsg || b >= p.B) return;
+    const int slot = sg * 8 + wave;
     const bool active = slot < p.n * p.NT;
     const int c = active ? slot / p.NT : 0, jt = active ? slot % p.NT : 0;
     const int Tp = p.NT * 32;
@@ -326,7 +337,7 @@ __global__ __launch_bounds__(512, 2) void ar_stats_kernel(ArStatsArgs p) {
 
 int launch_ar_stats(const ArStatsArgs& a, hipStream_t st) {
     const bool online = a.online != 0;
-    dim3 grid(cdiv(a.n * a.NT, 8), a.B);
+    dim3 grid(8 * cdiv(cdiv(a.B, 8), STATS_WT) * cdiv(cdiv(a.n * a.NT, 8), STATS_ST) * (STATS_WT * STATS_ST));
     if (a.x3) {
         if (online) hipLaunchKernelGGL((ar_stats_kernel<true, true>), grid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((ar_stats_kernel<true, false>), grid, dim3(512), 0, st, a);
@@ -340,12 +351,14 @@ int launch_ar_stats(const ArStatsArgs& a, hipStream_t st) {
 
 // =====================================================================================
 // proto: P^T = V^T A^T with A^T = exp2(S^T - lse2), fused distance / diff epilogue.
-// ALL mode   : grid (ceil(B*NT/8), n); wave = one (window, i-tile) slot, class = blockIdx.y;
+// ALL mode   : 1-D grid over (window group, class) blocks; wave = one (window, i-tile) slot of its class;
 //              the class's Kc / V^T fragment tiles stream through LDS shared by the 8 waves;
 //              out: part[b,c,it] = sum_{i in tile, d} (Vq - P)^2
 // CHOSEN mode: grid (ceil(B*NT/8), 1); class = chosen[b] per wave, operands straight from L2;
 //              out: diff[b,i,:] (input of the Discriminator, model.py:324)
 // =====================================================================================
+constexpr int PROTO_WT = 16, PROTO_CT = 8;
+
 template <bool X3, bool CHOSEN>
 __global__ __launch_bounds__(512, 2) void ar_proto_kernel(ArProtoArgs p) {
     constexpr int KT_U16 = 8 * 64 * 8;                    // Kc tile (8 KiB)
@@ -357,10 +370,24 @@ __global__ __launch_bounds__(512, 2) void ar_proto_kernel(ArProtoArgs p) {
     constexpr int LSE_U16 = 8 * NB * 64;                  // per wave and ring slot: the tile's 32 lse2 values (128 B)
     __shared__ __attribute__((aligned(16))) uint16_t lds[CHOSEN ? 8 : NB * NBUF_U16 + LSE_U16];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, r = lane & 31;
-    const int slot = blockIdx.x * 8 + wave;
+    // ALL mode: 1-D grid decoded per XCD (workgroup id % 8 = XCD) into blocks of PROTO_WT window groups x PROTO_CT
+    // classes, classes fastest: a block's Kq fragments (1 MiB) and its classes' K / V^T tiles (1.8 MiB) stay in
+    // that XCD's 4-MiB L2 while they are reused, instead of every class streaming all windows from HBM again
+    int bx = blockIdx.x, cls = 0;
+    if constexpr (!CHOSEN) {
+        const int id = blockIdx.x, xcd = id & 7, sl = id >> 3;
+        const int nx = (p.B * p.NT + 7) >> 3;                       // window groups
+        const int ncg = (p.n + PROTO_CT - 1) / PROTO_CT;
+        const int blk = sl / (PROTO_WT * PROTO_CT), within = sl - blk * (PROTO_WT * PROTO_CT);
+        const int wb = blk / ncg, cg = blk - wb * ncg;
+        bx = ((wb * PROTO_WT + within / PROTO_CT) << 3) + xcd;
+        cls = cg * PROTO_CT + within % PROTO_CT;
+        if (bx >= nx || cls >= p.n) return;
+    }
+    const int slot = bx * 8 + wave;
     const bool active = slot < p.B * p.NT;
     const int b = active ? slot / p.NT : 0, it = active ? slot % p.NT : 0;
-    const int c = CHOSEN ? p.chosen[b] : blockIdx.y;
+    const int c = CHOSEN ? p.chosen[b] : cls;
     const int Tp = p.NT * 32;
 
     bf16x8 q_hi[8], q_lo[8];
@@ -550,7 +577,11 @@ __global__ __launch_bounds__(512, 2) void ar_proto_kernel(ArProtoArgs p) {
 
 int launch_ar_proto(const ArProtoArgs& a, hipStream_t st) {
     const bool chosen = a.chosen != nullptr;
-    dim3 grid(cdiv(a.B * a.NT, 8), chosen ? 1 : a.n);
+    dim3 grid(cdiv(a.B * a.NT, 8));
+    if (!chosen) {
+        const int nxl = cdiv(cdiv(a.B * a.NT, 8), 8);               // window groups per XCD
+        grid = dim3(8 * cdiv(nxl, PROTO_WT) * cdiv(a.n, PROTO_CT) * (PROTO_WT * PROTO_CT));
+    }
     if (a.x3) {
         if (chosen) hipLaunchKernelGGL((ar_proto_kernel<true, true>), grid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((ar_proto_kernel<true, false>), grid, dim3(512), 0, st, a);
