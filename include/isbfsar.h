@@ -191,6 +191,14 @@ int isb_debug_expand_dw(int32_t device, const uint16_t* h_x, const float* h_w1, 
                         const float* h_dww, const float* h_dwscale, const float* h_dwshift, int32_t B, int32_t HW, int32_t Cin,
                         int32_t Cexp, int32_t iters, uint16_t* h_out, float* h_pooled, float* ms_per_iter);
 
+/* test / tuning hook: a whole Fused-MBConv block (3x3 expand + BN + SiLU -> 1x1 project + BN [+ residual]) in ONE
+ * launch on host tensors. h_x bf16 [B,H,H,Cin], h_w1 f32 [Cexp,3,3,Cin] (Cexp = 128, 256 or 384), h_w2 f32 [Cout2,Cexp]
+ * (Cout2 <= 128), optional residual h_res bf16 [B,H/stride,H/stride,Cout2]; out bf16 of that shape. */
+int isb_debug_fused_mb(int32_t device, const uint16_t* h_x, const float* h_w1, const float* h_scale1, const float* h_shift1,
+                       const float* h_w2, const float* h_scale2, const float* h_shift2, const uint16_t* h_res, int32_t B,
+                       int32_t H, int32_t Cin, int32_t Cexp, int32_t Cout2, int32_t stride, int32_t iters, uint16_t* h_out,
+                       float* ms_per_iter);
+
 /* test / tuning hook: the depthwise 3x3 (+ folded BN + SiLU) + squeeze-excite mean kernel on host tensors.
  *   h_x bf16 [B,H,H,C], h_w f32 [C,3,3] (taps are rounded to bf16 after the BN scale is folded in, like every
  *   conv weight), stride 1 (pad 1) or 2 (TF SAME: pad bottom/right); out bf16 [B,H/stride,H/stride,C], pooled f32 [B,C] */

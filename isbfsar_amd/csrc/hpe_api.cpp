@@ -51,6 +51,8 @@ struct isb_hpe {
     isb_hpe_cfg cfg{};
     hipStream_t own_stream = nullptr;
     bool weights = false, jointmap = false;
+    bool fuse_block = true;       // Fused-MBConv blocks (3x3 expand + 1x1 project) in one launch; ISB_FUSE_BLOCK=0 disables
+    int fuse_block_max_cexp = 256;
     bool fuse_front = false;      // MBConv expand + depthwise + pool in one kernel (ISB_FUSE_FRONT=1): measured equal to
                                   // the two-launch form on MI355X (E stays in the 256 MiB Infinity Cache), so off by default
     int n_out = 0;
@@ -181,6 +183,28 @@ int run_backbone(isb_hpe* h, Lane& L, hipStream_t st, const float* crops, int B)
         if (b.fused) {
             if (b.cexp == b.cin) {
                 ISB_TRY(conv(h, st, b.expand, X, B, b.in_hw, b.in_hw, b.stride, true, res, nullptr, Y, false));
+            } else if (h->fuse_block && b.cexp <= h->fuse_block_max_cexp && b.cout <= 64) {
+                // whole Fused-MBConv block in one launch: the expanded tensor never leaves the chip (bit-identical to
+                // the two-launch path below; -26...32 % on the 64-channel stage, see launch_fused_mb)
+                ConvArgs a{};
+                a.in = (const uint16_t*)X; a.w = b.expand.w16.as<uint16_t>(); a.bias = b.expand.bias.as<float>();
+                a.res = (const uint16_t*)res; a.out = Y;
+                a.B = B; a.H = b.in_hw; a.W = b.in_hw; a.Cin = b.cin; a.Cout = b.cexp; a.KH = 3; a.KW = 3; a.stride = b.stride;
+                a.OH = b.out_hw; a.OW = b.out_hw; a.pad = b.stride == 1 ? 1 : 0; a.M = B * b.out_hw * b.out_hw; a.K = 9 * b.cin;
+                a.act = 1;
+                a.w2 = b.project.w16.as<uint16_t>(); a.bias2 = b.project.bias.as<float>(); a.Cout2 = b.cout;
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (h->prof) {
+                    ISB_HIP(hipEventCreate(&e0));
+                    ISB_HIP(hipEventCreate(&e1));
+                    ISB_HIP(hipEventRecord(e0, st));
+                }
+                ISB_TRY(launch_fused_mb(a, st));
+                if (h->prof) {
+                    ISB_HIP(hipEventRecord(e1, st));
+                    h->prof_ev.emplace_back(e0, e1);
+                    h->prof_launches += 1;
+                }
             } else {
                 ISB_TRY(conv(h, st, b.expand, X, B, b.in_hw, b.in_hw, b.stride, true, nullptr, nullptr, L.bufE.p, false));
                 ISB_TRY(conv(h, st, b.project, L.bufE.p, B, b.out_hw, b.out_hw, 1, false, res, nullptr, Y, false));
@@ -278,6 +302,7 @@ extern "C" int isb_hpe_create(const isb_hpe_cfg* cfg, isb_hpe** out) {
     ISB_TRY(h->zeros.alloc(256));
     ISB_HIP(hipMemset(h->zeros.p, 0, 256));
     h->fuse_front = getenv("ISB_FUSE_FRONT") != nullptr;
+    if (const char* e = getenv("ISB_FUSE_BLOCK")) h->fuse_block = atoi(e) != 0;
     if (const char* e = getenv("ISB_HPE_LANES")) h->n_lanes = std::max(1, std::min(kMaxLanes, atoi(e)));
     ISB_HIP(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
     for (int l = 1; l < kMaxLanes; ++l) {
@@ -681,6 +706,57 @@ extern "C" int isb_hpe_select_person_host(isb_hpe* h, const float* boxes, const 
         ISB_HIP(hipStreamSynchronize(h->own_stream));
         ISB_HIP(hipMemcpy(bbox, dbb.p, (size_t)B * 16, hipMemcpyDeviceToHost));
         ISB_HIP(hipMemcpy(found, df.p, (size_t)B, hipMemcpyDeviceToHost));
+        return ISB_OK;
+    });
+}
+
+// test / tuning hook: a whole Fused-MBConv block in one launch on host tensors
+extern "C" int isb_debug_fused_mb(int32_t device, const uint16_t* x, const float* w1, const float* scale1, const float* shift1,
+                                  const float* w2, const float* scale2, const float* shift2, const uint16_t* res, int32_t B,
+                                  int32_t H, int32_t Cin, int32_t Cexp, int32_t Cout2, int32_t stride, int32_t iters,
+                                  uint16_t* out, float* ms_per_iter) {
+    return isb::guard([&]() -> int {
+        ISB_REQUIRE(x && w1 && scale1 && shift1 && w2 && scale2 && shift2 && out && ms_per_iter, ISB_ERR_INVALID, "null argument");
+        ISB_REQUIRE((stride == 1 || stride == 2) && iters >= 1 && B >= 1, ISB_ERR_INVALID, "bad parameters");
+        ISB_HIP(hipSetDevice(device));
+        const int OH = H / stride;
+        const size_t nin = (size_t)B * H * H * Cin, nout = (size_t)B * OH * OH * Cout2;
+        const size_t nw1 = (size_t)Cexp * 9 * Cin, nw2 = (size_t)Cout2 * Cexp;
+        DevBuf dx, dw1f, ds1, db1, dw1, dw2f, ds2, db2, dw2, dres, dout;
+        ISB_TRY(upload(dx, x, nin * 2));
+        ISB_TRY(upload(dw1f, w1, nw1 * 4));
+        ISB_TRY(upload(ds1, scale1, (size_t)Cexp * 4));
+        ISB_TRY(upload(db1, shift1, (size_t)Cexp * 4));
+        ISB_TRY(upload(dw2f, w2, nw2 * 4));
+        ISB_TRY(upload(ds2, scale2, (size_t)Cout2 * 4));
+        ISB_TRY(upload(db2, shift2, (size_t)Cout2 * 4));
+        ISB_TRY(dw1.alloc(nw1 * 2));
+        ISB_TRY(dw2.alloc(nw2 * 2));
+        ISB_TRY(dout.alloc(nout * 2));
+        if (res) ISB_TRY(upload(dres, res, nout * 2));
+        ISB_TRY(launch_f32_to_bf16_rows(dw1f.as<float>(), ds1.as<float>(), dw1.as<uint16_t>(), Cexp, (size_t)9 * Cin, nullptr));
+        ISB_TRY(launch_f32_to_bf16_rows(dw2f.as<float>(), ds2.as<float>(), dw2.as<uint16_t>(), Cout2, (size_t)Cexp, nullptr));
+        ConvArgs a{};
+        a.in = dx.as<uint16_t>(); a.w = dw1.as<uint16_t>(); a.bias = db1.as<float>();
+        a.res = res ? dres.as<uint16_t>() : nullptr; a.out = dout.p;
+        a.B = B; a.H = H; a.W = H; a.Cin = Cin; a.Cout = Cexp; a.KH = 3; a.KW = 3; a.stride = stride; a.OH = OH; a.OW = OH;
+        a.pad = stride == 1 ? 1 : 0; a.M = B * OH * OH; a.K = 9 * Cin; a.act = 1;
+        a.w2 = dw2.as<uint16_t>(); a.bias2 = db2.as<float>(); a.Cout2 = Cout2;
+        ISB_TRY(launch_fused_mb(a, nullptr));
+        ISB_HIP(hipDeviceSynchronize());
+        hipEvent_t e0, e1;
+        ISB_HIP(hipEventCreate(&e0));
+        ISB_HIP(hipEventCreate(&e1));
+        ISB_HIP(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < iters; ++i) ISB_TRY(launch_fused_mb(a, nullptr));
+        ISB_HIP(hipEventRecord(e1, nullptr));
+        ISB_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        ISB_HIP(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        *ms_per_iter = ms / iters;
+        ISB_HIP(hipMemcpy(out, dout.p, nout * 2, hipMemcpyDeviceToHost));
         return ISB_OK;
     });
 }

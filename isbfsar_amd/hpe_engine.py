@@ -175,6 +175,23 @@ def conv_debug(x_bf16, w, scale, shift, k, stride, act, res_bf16=None, gate=None
     return out, ms.value
 
 
+def fused_mb_debug(x_bf16, w1, scale1, shift1, w2, scale2, shift2, res_bf16=None, stride=1, iters=1, device=0):
+    """A whole Fused-MBConv block through isb_debug_fused_mb. x_bf16 uint16 [B,H,H,Cin], w1 f32 [Cexp,3,3,Cin],
+    w2 f32 [Cout2,Cexp]. Returns (out uint16 [B,H/stride,H/stride,Cout2], ms_per_launch)."""
+    x = np.ascontiguousarray(x_bf16, dtype=np.uint16)
+    B, H, _, Cin = x.shape
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    w1, w2 = f(w1), f(w2)
+    Cexp, Cout2 = w1.shape[0], w2.shape[0]
+    out = np.empty((B, H // stride, H // stride, Cout2), np.uint16)
+    r = None if res_bf16 is None else np.ascontiguousarray(res_bf16, dtype=np.uint16)
+    ms = C.c_float()
+    _lib.check(_lib.lib().isb_debug_fused_mb(device, _ptr(x), _ptr(w1), _ptr(f(scale1)), _ptr(f(shift1)), _ptr(w2),
+                                             _ptr(f(scale2)), _ptr(f(shift2)), _ptr(r), B, H, Cin, Cexp, Cout2, stride, iters,
+                                             _ptr(out), C.byref(ms)), "isb_debug_fused_mb")
+    return out, ms.value
+
+
 def dwconv_debug(x_bf16, w, scale, shift, stride=1, iters=1, device=0):
     """Depthwise 3x3 + SiLU + SE mean through isb_debug_dwconv. x_bf16 uint16 [B,H,H,C], w f32 [C,3,3].
     Returns (out uint16 [B,H/stride,H/stride,C], pooled f32 [B,C], ms_per_launch)."""

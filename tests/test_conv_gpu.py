@@ -139,3 +139,35 @@ def test_depthwise_pool(B, H, C, stride):
     assert np.all(np.abs(got - ref) <= tol), float(np.abs(got - ref).max())
     assert np.mean(got != ref) < 0.02                       # identical bf16 values except at rounding boundaries
     np.testing.assert_allclose(pooled, got.reshape(B, -1, C).mean(1), rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,H,Cin,Cexp,Cout2,stride,use_res", [
+    (2, 32, 64, 256, 64, 1, True),      # stage 2 body block
+    (3, 16, 32, 128, 64, 2, False),     # stage 2 first block (stride 2), ragged M (192 rows)
+    (2, 16, 96, 384, 96, 1, True),      # stage 3 body block (wide projection path)
+    (1, 32, 64, 256, 96, 2, False),     # stage 3 first block
+])
+def test_fused_mbconv_block(B, H, Cin, Cexp, Cout2, stride, use_res):
+    """One-launch Fused-MBConv block: bit-identical to the two-launch path (lean 3x3 kernel -> 1x1 GEMM kernel), and
+    within one bf16 ulp of torch-CPU on the same rounded operands."""
+    from isbfsar_amd.hpe_engine import fused_mb_debug
+    rng = np.random.default_rng(Cexp * 10 + Cout2 + stride)
+    x = rng.normal(0, 1, (B, H, H, Cin)).astype(np.float32)
+    w1 = (rng.normal(0, 1, (Cexp, 3, 3, Cin)) / np.sqrt(9 * Cin)).astype(np.float32)
+    s1 = rng.uniform(0.8, 1.2, Cexp).astype(np.float32); b1 = rng.uniform(-0.1, 0.1, Cexp).astype(np.float32)
+    w2 = (rng.normal(0, 1, (Cout2, Cexp)) / np.sqrt(Cexp)).astype(np.float32)
+    s2 = rng.uniform(0.8, 1.2, Cout2).astype(np.float32); b2 = rng.uniform(-0.1, 0.1, Cout2).astype(np.float32)
+    OH = H // stride
+    res = rng.normal(0, 1, (B, OH, OH, Cout2)).astype(np.float32) if use_res else None
+    xb, rb = f32_to_bf16(x), (None if res is None else f32_to_bf16(res))
+    out, _ = fused_mb_debug(xb, w1, s1, b1, w2, s2, b2, rb, stride)
+    # two-launch path through the same library
+    e, _ = conv_debug(xb, w1, s1, b1, 3, stride, 1, None, None, variant=0)
+    two, _ = conv_debug(e, w2.reshape(Cout2, 1, 1, Cexp), s2, b2, 1, 1, 0, rb, None, variant=0)
+    assert np.array_equal(out, two)
+    # torch-CPU
+    e_ref = _ref(x, w1, s1, b1, 3, stride, 1, None, None)
+    ref = _ref(e_ref, w2.reshape(Cout2, 1, 1, Cexp), s2, b2, 1, 1, 0, res, None)
+    got = bf16_to_f32(out)
+    assert np.mean(np.abs(got - ref) > 2.0 ** -7 * np.maximum(1.0, np.abs(ref))) < 0.02
+    assert np.abs(got - ref).max() < 3e-2 * max(1.0, np.abs(ref).max())
