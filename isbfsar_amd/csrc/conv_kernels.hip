@@ -999,21 +999,26 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_dma_kernel(ConvArgs p)
 //   second GEMM: wave tile 32 pixels x 64 output channels (Cout2 <= 128), K = Cexp fully unrolled.
 // Both sums run in the same order as the separate kernels, so the result is bit-identical to the two-launch path.
 // -------------------------------------------------------------------------------------------
-template <int TN, int TN2>    // Cexp = 64 * TN expanded channels, up to 64 * TN2 projected channels
-__global__ __launch_bounds__(512) void fused_mb_kernel(ConvArgs p) {
-    constexpr int NW = 8, WGN = 2;
-    constexpr int BM = 128, BN = 64 * TN;                    // BN = Cexp
+// WGM: 32-pixel blocks per workgroup (4 -> 128 pixels, 8 waves; 2 -> 64 pixels, 4 waves: two workgroups per CU
+// when the E tile of 384 channels would otherwise fill the LDS); Cexp = 64 * TN; WPR = projected channels rounded up
+// to 64 / 96 / 128 (rows of the projection-weight buffers)
+template <int WGM, int TN, int WPR>
+__global__ __launch_bounds__(128 * WGM) void fused_mb_kernel(ConvArgs p) {
+    constexpr int WGN = 2, NW = WGM * WGN;
+    constexpr int TN2 = (WPR / 32 + 1) / 2;                  // 32-channel tiles of the projection per wave
+    constexpr int BM = 32 * WGM, BN = 64 * TN;               // BN = Cexp
     constexpr int B_INST = BN / 16;
     constexpr int B_PW = (B_INST + NW - 1) / NW;
     constexpr int BUF = (BM + BN) * ROWB;
     constexpr int NKB = BN / 32;                             // k-blocks of the second GEMM
     constexpr int E_BYTES = NKB * BM * ROWB;                 // E tile: NKB blocks of [128 rows][64 B], swizzled like A tiles
-    constexpr int WP_ROWS = 64 * TN2, WP_BUF = WP_ROWS * ROWB;   // projection weights of one k-block (rows past Cout2 unused)
-    constexpr int STAGE2 = BM * (WP_ROWS * 2 + 16);          // epilogue staging of the 128 x WP_ROWS output tile
+    constexpr int WP_ROWS = WPR, WP_BUF = WP_ROWS * ROWB;    // projection weights of one k-block (rows past Cout2 unused)
+    constexpr int W2_PW = (WP_ROWS / 16 + NW - 1) / NW;
+    constexpr int STAGE2 = BM * (64 * TN2 * 2 + 16);         // epilogue staging of the output tile
     constexpr int REG_A0 = 2 * BUF > E_BYTES ? 2 * BUF : E_BYTES;
     constexpr int REG_A = REG_A0 > STAGE2 ? REG_A0 : STAGE2;
     constexpr int WP_OFF = REG_A, BIAS1_OFF = WP_OFF + 2 * WP_BUF, BIAS2_OFF = BIAS1_OFF + BN * 4;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[BIAS2_OFF + WP_ROWS * 4];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[BIAS2_OFF + 128 * 4];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1033,7 +1038,7 @@ __global__ __launch_bounds__(512) void fused_mb_kernel(ConvArgs p) {
         rsrc.z = (int)nrec;
         rsrc.w = 0x00020000;
     }
-    uint32_t a_voff, a_mask, b_voff[B_PW], w2_voff;
+    uint32_t a_voff, a_mask, b_voff[B_PW], w2_voff[W2_PW];
     {
         const int row = 16 * wave + (lane >> 2);             // A: one piece per wave (8 pieces = 128 rows)
         const int logical = (lane & 3) ^ ((row >> 2) & 3);
@@ -1051,8 +1056,12 @@ __global__ __launch_bounds__(512) void fused_mb_kernel(ConvArgs p) {
             if (ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) mk |= 1u << t;
         }
         a_mask = mk;
-        // projection weights: wave w stages rows 16 w .. 16 w + 15 of each k-block (waves past WP_ROWS / 16 none)
-        w2_voff = (uint32_t)min(row, p.Cout2 - 1) * (uint32_t)(BN * 2) + logical * 16;
+    }
+#pragma unroll
+    for (int s = 0; s < W2_PW; ++s) {                        // projection weights: 16 rows of each k-block per piece
+        const int row = 16 * (wave + NW * s) + (lane >> 2);
+        const int logical = (lane & 3) ^ ((row >> 2) & 3);
+        w2_voff[s] = (uint32_t)min(row, p.Cout2 - 1) * (uint32_t)(BN * 2) + logical * 16;
     }
 #pragma unroll
     for (int s = 0; s < B_PW; ++s) {
@@ -1068,8 +1077,7 @@ __global__ __launch_bounds__(512) void fused_mb_kernel(ConvArgs p) {
         for (int o = 0; o < BN / 4; o += 64)
             if (lane + o < BN / 4) dma16_s(p.bias, (uint32_t)(lane + o) * 16, ldsA + BIAS1_OFF + o * 16);
     }
-    if (wave == 1 && lane < WP_ROWS / 4)
-        dma16_s(p.bias2, (uint32_t)min(lane * 4, p.Cout2 - 4) * 4, ldsA + BIAS2_OFF);
+    if (wave == 1 && lane < 32) dma16_s(p.bias2, (uint32_t)min(lane * 4, p.Cout2 - 4) * 4, ldsA + BIAS2_OFF);
     int tap = 0, c0 = 0;
     uint32_t tap_soff = 0;
     auto dma = [&](auto bufc) {
@@ -1138,7 +1146,9 @@ __global__ __launch_bounds__(512) void fused_mb_kernel(ConvArgs p) {
     const unsigned char* w2_base = reinterpret_cast<const unsigned char*>(p.w2);
     auto dma_w2 = [&](auto bufc) {                           // next 32 expanded channels of the projection weights
         constexpr int buf = decltype(bufc)::value;
-        if (wave < WP_ROWS / 16) dma16_s(w2_base, w2_voff, lds0 + WP_OFF + buf * WP_BUF);
+#pragma unroll
+        for (int s = 0; s < W2_PW; ++s)
+            if (wave + NW * s < WP_ROWS / 16) dma16_s(w2_base, w2_voff[s], lds0 + WP_OFF + buf * WP_BUF + NW * s * 1024);
         w2_base += CK * 2;
     };
     dma_w2(std::integral_constant<int, 0>{});
@@ -1167,6 +1177,7 @@ __global__ __launch_bounds__(512) void fused_mb_kernel(ConvArgs p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc2[0][j][e] = 0.f;
     const bool n_live = wn * 32 * TN2 < p.Cout2;             // a wave whose channels all lie past Cout2 only keeps the barriers
+    const bool t1_live = (wn * TN2 + 1) * 32 < p.Cout2;     // second tile of the wave (TN2 == 2)
     auto gemm2_step = [&](auto kbc) {
         constexpr int kb = decltype(kbc)::value;
         constexpr int buf = kb & 1;
@@ -1177,6 +1188,7 @@ __global__ __launch_bounds__(512) void fused_mb_kernel(ConvArgs p) {
                 const bf16x8 af = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + a_sw[ks] + kb * (BM * ROWB)));
 #pragma unroll
                 for (int j = 0; j < TN2; ++j) {
+                    if (j == 1 && !t1_live) continue;        // rows past WP_ROWS are not staged
                     const bf16x8 bw = __builtin_bit_cast(
                         bf16x8, *reinterpret_cast<const uint4*>(lds + WP_OFF + buf * WP_BUF + swz((wn * TN2 + j) * 32 + r, 2 * ks + h)));
                     acc2[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw, af, acc2[0][j], 0, 0, 0);
@@ -1206,7 +1218,7 @@ __global__ __launch_bounds__(512) void fused_mb_kernel(ConvArgs p) {
     ConvArgs p2 = p;                                         // epilogue of the projection: bias2, no activation, residual
     p2.Cout = p.Cout2;
     p2.act = 0;
-    conv_epilogue<1, TN2, 4, 2, true>(p2, acc2, lds, m0, 0, wm, wn, r, h, tid, BIAS2_OFF);
+    conv_epilogue<1, TN2, WGM, 2, true>(p2, acc2, lds, m0, 0, wm, wn, r, h, tid, BIAS2_OFF);
 }
 
 int launch_fused_mb(const ConvArgs& a, hipStream_t st) {
@@ -1220,18 +1232,16 @@ int launch_fused_mb(const ConvArgs& a, hipStream_t st) {
     }
     ConvArgs aa = a;
     aa.grid_mode = 0;
-    const dim3 g(cdiv(a.M, 128));
-    const bool narrow = a.Cout2 <= 64;
+    const int wpr = a.Cout2 <= 64 ? 64 : a.Cout2 <= 96 ? 96 : 128;
+#define ISB_FMB(WGM, TN, WPR) hipLaunchKernelGGL((fused_mb_kernel<WGM, TN, WPR>), dim3(cdiv(a.M, 32 * WGM)), dim3(128 * WGM), 0, st, aa)
     if (a.Cout == 128) {
-        if (narrow) hipLaunchKernelGGL((fused_mb_kernel<2, 1>), g, dim3(512), 0, st, aa);
-        else hipLaunchKernelGGL((fused_mb_kernel<2, 2>), g, dim3(512), 0, st, aa);
+        if (wpr == 64) ISB_FMB(4, 2, 64); else if (wpr == 96) ISB_FMB(4, 2, 96); else ISB_FMB(4, 2, 128);
     } else if (a.Cout == 256) {
-        if (narrow) hipLaunchKernelGGL((fused_mb_kernel<4, 1>), g, dim3(512), 0, st, aa);
-        else hipLaunchKernelGGL((fused_mb_kernel<4, 2>), g, dim3(512), 0, st, aa);
-    } else {
-        if (narrow) hipLaunchKernelGGL((fused_mb_kernel<6, 1>), g, dim3(512), 0, st, aa);
-        else hipLaunchKernelGGL((fused_mb_kernel<6, 2>), g, dim3(512), 0, st, aa);
+        if (wpr == 64) ISB_FMB(4, 4, 64); else if (wpr == 96) ISB_FMB(4, 4, 96); else ISB_FMB(4, 4, 128);
+    } else {                                                 // 384 expanded channels: 64-pixel tiles, two workgroups per CU
+        if (wpr == 64) ISB_FMB(2, 6, 64); else if (wpr == 96) ISB_FMB(2, 6, 96); else ISB_FMB(2, 6, 128);
     }
+#undef ISB_FMB
     ISB_LAUNCHED("fused_mb", st);
     return ISB_OK;
 }

@@ -52,7 +52,7 @@ struct isb_hpe {
     hipStream_t own_stream = nullptr;
     bool weights = false, jointmap = false;
     bool fuse_block = true;       // Fused-MBConv blocks (3x3 expand + 1x1 project) in one launch; ISB_FUSE_BLOCK=0 disables
-    int fuse_block_max_cexp = 256;
+    int fuse_block_max_cexp = 256;   // 384 expanded channels (E tile 96 KiB) measured 10 % slower than two launches
     bool fuse_front = false;      // MBConv expand + depthwise + pool in one kernel (ISB_FUSE_FRONT=1): measured equal to
                                   // the two-launch form on MI355X (E stays in the 256 MiB Infinity Cache), so off by default
     int n_out = 0;
@@ -183,7 +183,7 @@ int run_backbone(isb_hpe* h, Lane& L, hipStream_t st, const float* crops, int B)
         if (b.fused) {
             if (b.cexp == b.cin) {
                 ISB_TRY(conv(h, st, b.expand, X, B, b.in_hw, b.in_hw, b.stride, true, res, nullptr, Y, false));
-            } else if (h->fuse_block && b.cexp <= h->fuse_block_max_cexp && b.cout <= 64) {
+            } else if (h->fuse_block && b.cexp <= h->fuse_block_max_cexp && b.cout <= 128) {
                 // whole Fused-MBConv block in one launch: the expanded tensor never leaves the chip (bit-identical to
                 // the two-launch path below; -26...32 % on the 64-channel stage, see launch_fused_mb)
                 ConvArgs a{};
@@ -303,6 +303,7 @@ extern "C" int isb_hpe_create(const isb_hpe_cfg* cfg, isb_hpe** out) {
     ISB_HIP(hipMemset(h->zeros.p, 0, 256));
     h->fuse_front = getenv("ISB_FUSE_FRONT") != nullptr;
     if (const char* e = getenv("ISB_FUSE_BLOCK")) h->fuse_block = atoi(e) != 0;
+    if (const char* e = getenv("ISB_FUSE_BLOCK_CEXP")) h->fuse_block_max_cexp = atoi(e);
     if (const char* e = getenv("ISB_HPE_LANES")) h->n_lanes = std::max(1, std::min(kMaxLanes, atoi(e)));
     ISB_HIP(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
     for (int l = 1; l < kMaxLanes; ++l) {
