@@ -169,8 +169,8 @@ int launch_gemm_f32(const GemmF32Args& a, hipStream_t st) {
     } else if (a.N <= 64) {
         dim3 grid(cdiv(a.M, 128), cdiv(a.N, 64), z);
         hipLaunchKernelGGL((gemm_f32_kernel<2, 1, 2, 2>), grid, dim3(256), 0, st, a);
-    } else if ((long)cdiv(a.M, 128) * cdiv(a.N, 128) * z < 512) {
-        // too few 128 x 128 tiles to fill 256 CUs twice (AR layers at a few thousand rows): 64 x 64 tiles
+    } else if ((long)cdiv(a.M, 128) * cdiv(a.N, 128) * z < 256) {
+        // fewer 128 x 128 tiles than CUs (AR layers at a few thousand rows): 64 x 64 tiles
         dim3 grid(cdiv(a.M, 64), cdiv(a.N, 64), z);
         hipLaunchKernelGGL((gemm_f32_kernel<1, 1, 2, 2>), grid, dim3(256), 0, st, a);
     } else {
