@@ -37,7 +37,8 @@ def load(path, counter):
 
 fetch, nf = load(sys.argv[1], "FETCH_SIZE")
 write, nw = load(sys.argv[2], "WRITE_SIZE")
-forwards = nf["conv_igemm"] / 155.0                      # 155 conv launches per forward pass on one lane
+forwards = sum(1 for r in csv.DictReader(open(sys.argv[1]))     # one stem launch per forward pass (one lane)
+               if r["Counter_Name"] == "FETCH_SIZE" and "stem_kernel" in r["Kernel_Name"])
 out = {"_how": __doc__, "forwards_in_trace": forwards, "hpe_b256": {}}
 for f in sorted(set(fetch) | set(write)):
     fk, wk = fetch[f] / forwards, write[f] / forwards
