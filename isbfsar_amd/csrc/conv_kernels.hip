@@ -54,6 +54,24 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
     constexpr int BN = 32 * TN * WGN;
     constexpr int CROW = BN * 2 + 16;
     // ---- epilogue. acc[i][j][e]: channel n = n0 + (wn*TN+j)*32 + 8*(e>>2) + 4*h + (e&3), pixel m = m0 + (wm*TM+i)*32 + r
+    if (p.splits > 1) {       // split-K partial: raw f32 accumulators to part[split][M][Cout]
+        float* out32 = p.part + (size_t)blockIdx.z * p.M * p.Cout;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + (wm * TM + i) * 32 + r;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = n0 + (wn * TN + j) * 32 + 8 * q + 4 * h;
+                    if (n >= p.Cout) continue;
+                    *reinterpret_cast<float4*>(out32 + (size_t)m * p.Cout + n) =
+                        make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                }
+        }
+        return;
+    }
     if (p.out_f32) {          // f32 output (last 1x1 conv feeding the f32 pose head): direct stores
         float* out32 = reinterpret_cast<float*>(p.out);
 #pragma unroll
@@ -717,8 +735,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_dma_kernel(ConvArgs p)
         const int logical = (lane & 3) ^ ((row >> 2) & 3);
         b_voff[s] = (uint32_t)min(n0 + row, p.Cout - 1) * (uint32_t)(p.Cin * 2) + logical * 16;
     }
-    const unsigned char* a_base = reinterpret_cast<const unsigned char*>(p.in);
-    const unsigned char* b_base = reinterpret_cast<const unsigned char*>(p.w);
+    // k range of this workgroup: all of K, or one split of it (blockIdx.z)
+    int kt_first = 0, nkt = p.Cin / CK;
+    if (p.splits > 1) {
+        const int per = (nkt + p.splits - 1) / p.splits;
+        kt_first = min((int)blockIdx.z * per, nkt);
+        nkt = min(per, nkt - kt_first);
+    }
+    const unsigned char* a_base = reinterpret_cast<const unsigned char*>(p.in) + kt_first * (CK * 2);
+    const unsigned char* b_base = reinterpret_cast<const unsigned char*>(p.w) + kt_first * (CK * 2);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)lds + wave * 1024;
     if (wave == 0) {
 #pragma unroll
@@ -758,7 +783,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_dma_kernel(ConvArgs p)
     // kernel does at its LDS store. g_row: float offset of this lane's sample row (+ its 8-channel half)
     dma(std::integral_constant<int, 0>{});      // first tile in flight while the gate rows are staged
     int g_row[TM];
-    int kt_now = 0;
+    int kt_now = kt_first;
     if constexpr (GATE) {
         const int ohw = p.OH * p.OW;
         const int s_first = m0 / ohw;
@@ -809,7 +834,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_dma_kernel(ConvArgs p)
         __syncthreads();
     };
 
-    const int nkt = p.Cin / CK;
     publish();
     int kt = 0;
     for (; kt + 2 <= nkt; kt += 2) {            // straight-line body: tile kt in buffer 0, tile kt+1 in buffer 1
@@ -1221,6 +1245,28 @@ __global__ __launch_bounds__(128 * WGM) void fused_mb_kernel(ConvArgs p) {
     conv_epilogue<1, TN2, WGM, 2, true>(p2, acc2, lds, m0, 0, wm, wn, r, h, tid, BIAS2_OFF);
 }
 
+static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st);
+
+// public entry: one convolution, or (splits > 1) a split-K GEMM into f32 partials followed by the reduction
+int launch_conv_igemm(const ConvArgs& a, hipStream_t st) {
+    if (a.splits <= 1) return launch_conv_igemm_impl(a, st);
+    ConvArgs b = a;
+    const int nkt = a.Cin / CK;
+    const int per = cdiv(nkt, a.splits);
+    b.splits = cdiv(nkt, per);                  // no empty split: every workgroup owns at least one k-tile
+    if (b.splits <= 1) {
+        b.splits = 0;
+        return launch_conv_igemm_impl(b, st);
+    }
+    if (a.out_f32 || a.KH != 1 || a.stride != 1) {
+        set_error("conv_igemm: split-K needs a 1x1 stride-1 convolution with bf16 output");
+        return ISB_ERR_INVALID;
+    }
+    const int rc = launch_conv_igemm_impl(b, st);
+    if (rc != ISB_OK) return rc;
+    return launch_splitk_reduce(b, st);
+}
+
 int launch_fused_mb(const ConvArgs& a, hipStream_t st) {
     const bool same1 = a.stride == 1 && a.pad == 1, same2 = a.stride == 2 && a.pad == 0;
     if (a.gate || a.KH != 3 || a.KW != 3 || !(same1 || same2) || a.Cin % 32 != 0 || a.K != 9 * a.Cin || !a.w2 || !a.bias2 ||
@@ -1246,6 +1292,43 @@ int launch_fused_mb(const ConvArgs& a, hipStream_t st) {
     return ISB_OK;
 }
 
+// split-K reduction: out[m][n] = bf16( sum_s part[s][m][n] (in split order) + bias[n] (+ res[m][n]) )
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs p) {
+    const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x;       // one thread = 4 consecutive channels
+    const size_t total4 = (size_t)p.M * p.Cout / 4;
+    if (i4 >= total4) return;
+    const size_t e = i4 * 4;
+    const int n = (int)(e % p.Cout);
+    float4 v = *reinterpret_cast<const float4*>(p.part + e);
+    for (int s = 1; s < p.splits; ++s) {
+        const float4 u = *reinterpret_cast<const float4*>(p.part + (size_t)s * p.M * p.Cout + e);
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    const float4 bs = *reinterpret_cast<const float4*>(p.bias + n);
+    v.x += bs.x; v.y += bs.y; v.z += bs.z; v.w += bs.w;
+    if (p.act) { v.x = silu_fast(v.x); v.y = silu_fast(v.y); v.z = silu_fast(v.z); v.w = silu_fast(v.w); }
+    if (p.res) {
+        const uint2 rr = *reinterpret_cast<const uint2*>(p.res + e);
+        v.x += bf2f_((uint16_t)(rr.x & 0xffff)); v.y += bf2f_((uint16_t)(rr.x >> 16));
+        v.z += bf2f_((uint16_t)(rr.y & 0xffff)); v.w += bf2f_((uint16_t)(rr.y >> 16));
+    }
+    uint2 pk;
+    pk.x = (uint32_t)f2bf_(v.x) | ((uint32_t)f2bf_(v.y) << 16);
+    pk.y = (uint32_t)f2bf_(v.z) | ((uint32_t)f2bf_(v.w) << 16);
+    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + e) = pk;
+}
+
+int launch_splitk_reduce(const ConvArgs& a, hipStream_t st) {
+    if (a.splits < 2 || !a.part || a.Cout % 4 != 0 || a.out_f32) {
+        set_error("splitk_reduce: needs splits >= 2, a partial buffer and bf16 output");
+        return ISB_ERR_INVALID;
+    }
+    const size_t total4 = (size_t)a.M * a.Cout / 4;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdivz(total4, 256)), dim3(256), 0, st, a);
+    ISB_LAUNCHED("splitk_reduce", st);
+    return ISB_OK;
+}
+
 static int conv_grid_mode() {
     static const int mode = [] {
         const char* e = getenv("ISB_CONV_GRID");     // tuning override; 1 measured 4 % faster than the 2-D grid
@@ -1257,14 +1340,15 @@ static int conv_grid_mode() {
 static dim3 conv_grid(ConvArgs& a, int BM, int BN) {
     a.grid_m = cdiv(a.M, BM);
     a.grid_n = cdiv(a.Cout, BN);
+    const unsigned z = a.splits > 1 ? (unsigned)a.splits : 1u;      // split-K (gemm1x1 kernels only)
     if (a.grid_mode == 0 || a.grid_n == 1) {
         a.grid_mode = 0;
-        return dim3(a.grid_m, a.grid_n);
+        return dim3(a.grid_m, a.grid_n, z);
     }
-    return dim3(8 * ((a.grid_m + 7) / 8) * a.grid_n);
+    return dim3(8 * ((a.grid_m + 7) / 8) * a.grid_n, 1, z);
 }
 
-int launch_conv_igemm(const ConvArgs& a, hipStream_t st) {
+static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
     ConvArgs aa = a;
     aa.grid_mode = conv_grid_mode();
     if (a.Cin % 32 != 0 || a.Cout % 32 != 0 || a.K != a.KH * a.KW * a.Cin || a.M <= 0) {
@@ -1322,6 +1406,11 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t st) {
             else if (a.Cout % 64 == 0) v = 3;
             else v = 5;
         }
+    }
+    const bool is_g1 = (v >= 131 && v <= 149);
+    if (aa.splits > 1 && !(is_g1 && aa.part)) {
+        set_error("conv_igemm: split-K is implemented by the gemm1x1 variants (131-149) and needs a partial buffer");
+        return ISB_ERR_INVALID;
     }
     const bool is_dma = (v >= 11 && v <= 39) || (v >= 51 && v <= 69);
     const bool is_gdma = (v >= 81 && v <= 99) || (v >= 111 && v <= 119);

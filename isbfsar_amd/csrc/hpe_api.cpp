@@ -39,10 +39,13 @@ const StageDef kStages[] = {
 // activation workspace of one micro-batch in flight. Two lanes on two streams run two halves of a batch
 // concurrently: while one half sits in a bandwidth-bound kernel (depthwise conv, SE, tile write-back) the
 // other half's GEMM tiles keep the matrix cores busy.
+constexpr size_t kSplitKBytes = 8u << 20;
+
 struct Lane {
     hipStream_t side = nullptr;   // lane 1 only: its own stream, forked from / joined into the caller's
     int ws_B = 0;
     DevBuf H, newK, R, crops, bufX, bufY, bufE, bufD, pooled, semid, gate, feat, logits;
+    DevBuf part;                  // split-K partial tiles of the small-M projections (kSplitKBytes)
 };
 
 }  // namespace
@@ -51,6 +54,7 @@ struct isb_hpe {
     isb_hpe_cfg cfg{};
     hipStream_t own_stream = nullptr;
     bool weights = false, jointmap = false;
+    bool split_k = true;          // split-K for the projections of single-frame calls; ISB_SPLIT_K=0 disables
     bool fuse_block = true;       // Fused-MBConv blocks (3x3 expand + 1x1 project) in one launch; ISB_FUSE_BLOCK=0 disables
     int fuse_block_max_cexp = 256;   // 384 expanded channels (E tile 96 KiB) measured 10 % slower than two launches
     bool fuse_front = false;      // MBConv expand + depthwise + pool in one kernel (ISB_FUSE_FRONT=1): measured equal to
@@ -131,12 +135,13 @@ int ensure_ws(Lane& L, int Bm) {
     ISB_TRY(L.gate.alloc(B * 3840 * 4));
     ISB_TRY(L.feat.alloc(B * 64 * 1280 * 4));
     ISB_TRY(L.logits.alloc(B * 64 * 288 * 4));
+    if (!L.part.p) ISB_TRY(L.part.alloc(kSplitKBytes));
     L.ws_B = Bm;
     return ISB_OK;
 }
 
 int conv(isb_hpe* h, hipStream_t st, const ConvW& cw, const void* in, int B, int H, int W, int stride, bool act,
-         const void* res, const float* gate, void* out, bool out_f32) {
+         const void* res, const float* gate, void* out, bool out_f32, Lane* lane = nullptr) {
     ConvArgs a{};
     a.in = (const uint16_t*)in; a.w = cw.w16.as<uint16_t>(); a.bias = cw.bias.as<float>();
     a.res = (const uint16_t*)res; a.gate = gate; a.out = out;
@@ -146,6 +151,15 @@ int conv(isb_hpe* h, hipStream_t st, const ConvW& cw, const void* in, int B, int
     a.M = B * a.OH * a.OW; a.K = cw.k * cw.k * cw.cin;
     a.act = act ? 1 : 0; a.out_f32 = out_f32 ? 1 : 0;
     a.zeros = h->zeros.as<uint16_t>();
+    // ONE frame (the live loop) x a long K: the SE-gated projections of the last stages are 3-8 tiles of 64 x 128
+    // each walking up to 120 k-tiles in series. Split K across workgroups so that the launch covers more of the chip.
+    // Only for single-frame calls, and with a split count that depends on the layer alone: batches of two or more
+    // frames keep one summation order whatever their size, so any sharding of a batch stays bit-identical.
+    if (lane && h->split_k && B == 1 && cw.k == 1 && stride == 1 && !out_f32 && a.Cout >= 64 &&
+        (!gate || (a.OH * a.OW) % 64 == 0)) {
+        const int s = std::min(a.Cin / 32 / 6, 16);
+        if (s > 1 && (size_t)s * a.M * a.Cout * 4 <= kSplitKBytes) { a.splits = s; a.part = lane->part.as<float>(); }
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->prof) {
         ISB_HIP(hipEventCreate(&e0));
@@ -245,11 +259,22 @@ int run_backbone(isb_hpe* h, Lane& L, hipStream_t st, const float* crops, int B)
             se.w2t = b.se_w2.as<float>(); se.b2 = b.se_b2.as<float>(); se.part = L.semid.as<float>();
             se.gate = L.gate.as<float>(); se.B = B; se.C = b.cexp; se.cse = b.cse;
             ISB_TRY(launch_se_fcs(se, st));
-            ISB_TRY(conv(h, st, b.project, L.bufD.p, B, b.out_hw, b.out_hw, 1, false, res, L.gate.as<float>(), Y, false));
+            ISB_TRY(conv(h, st, b.project, L.bufD.p, B, b.out_hw, b.out_hw, 1, false, res, L.gate.as<float>(), Y, false, &L));
         }
         std::swap(X, Y);
     }
     ISB_TRY(conv(h, st, h->headconv, X, B, 8, 8, 1, true, nullptr, nullptr, L.feat.p, true));
+    if (B == 1 && h->split_k) {
+        // one frame: 64 rows x 288 outputs are 5 tiles walking 40 k-tiles each -> 8 K-splits + an in-order reduction
+        constexpr int kHeadSplits = 8;
+        GemmF32Args g{};
+        g.A = L.feat.as<float>(); g.lda = 1280; g.W = h->head_w.as<float>(); g.ldw = 1280; g.C = L.part.as<float>(); g.ldc = 288;
+        g.M = 64; g.N = 288; g.K = 1280; g.add_period = 1; g.act = GEMM_ACT_NONE;
+        g.splits = kHeadSplits; g.split_stride = (size_t)64 * 288;
+        ISB_TRY(launch_gemm_f32(g, st));
+        return launch_reduce_parts(L.part.as<float>(), kHeadSplits, g.split_stride, h->head_b.as<float>(), GEMM_ACT_NONE,
+                                   L.logits.as<float>(), 64, 288, st);
+    }
     ISB_TRY(gemm(st, L.feat.as<float>(), 1280, h->head_w.as<float>(), 1280, h->head_b.as<float>(), L.logits.as<float>(), 288,
                  B * 64, 288, 1280, GEMM_ACT_NONE));
     return ISB_OK;
@@ -303,6 +328,7 @@ extern "C" int isb_hpe_create(const isb_hpe_cfg* cfg, isb_hpe** out) {
     ISB_HIP(hipMemset(h->zeros.p, 0, 256));
     h->fuse_front = getenv("ISB_FUSE_FRONT") != nullptr;
     if (const char* e = getenv("ISB_FUSE_BLOCK")) h->fuse_block = atoi(e) != 0;
+    if (const char* e = getenv("ISB_SPLIT_K")) h->split_k = atoi(e) != 0;
     if (const char* e = getenv("ISB_FUSE_BLOCK_CEXP")) h->fuse_block_max_cexp = atoi(e);
     if (const char* e = getenv("ISB_HPE_LANES")) h->n_lanes = std::max(1, std::min(kMaxLanes, atoi(e)));
     ISB_HIP(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
@@ -662,7 +688,14 @@ extern "C" int isb_debug_conv(int32_t device, const uint16_t* x, const float* w,
     a.in = dx.as<uint16_t>(); a.w = dw16.as<uint16_t>(); a.bias = dsh.as<float>();
     a.res = res ? dres.as<uint16_t>() : nullptr; a.gate = gate ? dgate.as<float>() : nullptr; a.out = dout.p;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = k; a.KW = k; a.stride = stride; a.OH = OH; a.OW = OW;
-    a.pad = (k == 3 && stride == 1) ? 1 : 0; a.M = B * OH * OW; a.K = k * k * Cin; a.act = act; a.out_f32 = 0; a.variant = variant; a.zeros = dzero.as<uint16_t>();
+    a.pad = (k == 3 && stride == 1) ? 1 : 0; a.M = B * OH * OW; a.K = k * k * Cin; a.act = act; a.out_f32 = 0; a.zeros = dzero.as<uint16_t>();
+    a.variant = variant % 1000;
+    DevBuf dpart;
+    if (variant >= 2000) {                      // variant = 1000 * splits + tile variant: split-K
+        a.splits = variant / 1000;
+        ISB_TRY(dpart.alloc((size_t)a.splits * a.M * Cout * 4));
+        a.part = dpart.as<float>();
+    }
     ISB_TRY(launch_conv_igemm(a, nullptr));       // warm-up + result
     ISB_HIP(hipDeviceSynchronize());
     hipEvent_t e0, e1;

@@ -175,38 +175,77 @@ __device__ void solve_sym3_pinv(const double A[6], const double rhs[3], double o
     }
 }
 
-__global__ __launch_bounds__(64) void hpe_post_kernel(PostArgs p) {
+// 512 threads per frame: thread = (joint j, part of the heatmap). The soft-argmax sums run as 16 partial sums per
+// joint (4 heatmap cells x 8 depths each, in (h, w, d) order) combined in part order -- a fixed order, the same for
+// every frame and batch size; the geometry that follows runs on the first wave.
+__global__ __launch_bounds__(512) void hpe_post_kernel(PostArgs p) {
     __shared__ double sh2d[32][2];
     __shared__ double pose32[32][3];
-    const int b = blockIdx.x, lane = threadIdx.x, j = lane & 31, half = lane >> 5;
+    __shared__ float red_mx[2][16][32];
+    __shared__ double red_den[2][16][32];
+    __shared__ double red_c[5][16][32];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, j = tid & 31, half = lane >> 5, part = tid >> 5;
     const float* lg = p.logits + (size_t)b * 64 * 288;
 
+    float x3[4][8], x2d[4];                 // this thread's cells: hw = 4 * part + c
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int hw = 4 * part + c;
+        x2d[c] = lg[hw * 288 + j];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) x3[c][d] = lg[hw * 288 + 32 + d * 32 + j];
+    }
+    float m3 = -INFINITY, m2 = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        m2 = fmaxf(m2, x2d[c]);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) m3 = fmaxf(m3, x3[c][d]);
+    }
+    red_mx[0][part][j] = m3; red_mx[1][part][j] = m2;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { m3 = fmaxf(m3, red_mx[0][q][j]); m2 = fmaxf(m2, red_mx[1][q][j]); }
+    // exponentials once; 3D: softmax jointly over (h, w, d), hpe.py:114-129; 2D: over (h, w), hpe.py:131-146
+    double den3 = 0, den2 = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        x2d[c] = expf(x2d[c] - m2);
+        den2 += (double)x2d[c];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            x3[c][d] = expf(x3[c][d] - m3);
+            den3 += (double)x3[c][d];
+        }
+    }
+    red_den[0][part][j] = den3; red_den[1][part][j] = den2;
+    __syncthreads();
+    den3 = 0; den2 = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { den3 += red_den[0][q][j]; den2 += red_den[1][q][j]; }
+    const float den3f = (float)den3, den2f = (float)den2;
+    double s0 = 0, s1 = 0, s2 = 0, t0 = 0, t1 = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int hw = 4 * part + c, hh = hw >> 3, ww = hw & 7;
+        const double r2 = (double)__fdiv_rn(x2d[c], den2f);
+        t0 += r2 * ((double)ww / 7.0); t1 += r2 * ((double)hh / 7.0);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            const double r = (double)__fdiv_rn(x3[c][d], den3f);
+            s0 += r * ((double)ww / 7.0); s1 += r * ((double)hh / 7.0); s2 += r * ((double)d / 7.0);
+        }
+    }
+    red_c[0][part][j] = s0; red_c[1][part][j] = s1; red_c[2][part][j] = s2; red_c[3][part][j] = t0; red_c[4][part][j] = t1;
+    __syncthreads();
+    if (tid >= 64) return;                  // the rest is one wave's work: lanes 0-31 carry the 3D joint, 32-63 the 2D one
     double c0 = 0, c1 = 0, c2 = 0;
-    if (half == 0) {          // 3D: softmax jointly over (h, w, d), hpe.py:114-129
-        float mx = -INFINITY;
-        for (int hw = 0; hw < 64; ++hw)
-            for (int d = 0; d < 8; ++d) mx = fmaxf(mx, lg[hw * 288 + 32 + d * 32 + j]);
-        double den = 0;
-        for (int hw = 0; hw < 64; ++hw)
-            for (int d = 0; d < 8; ++d) den += (double)expf(lg[hw * 288 + 32 + d * 32 + j] - mx);
-        const float denf = (float)den;
-        for (int hw = 0; hw < 64; ++hw) {
-            const int hh = hw >> 3, ww = hw & 7;
-            for (int d = 0; d < 8; ++d) {
-                const double r = (double)__fdiv_rn(expf(lg[hw * 288 + 32 + d * 32 + j] - mx), denf);
-                c0 += r * ((double)ww / 7.0); c1 += r * ((double)hh / 7.0); c2 += r * ((double)d / 7.0);
-            }
-        }
-    } else {                  // 2D: softmax over (h, w), hpe.py:131-146
-        float mx = -INFINITY;
-        for (int hw = 0; hw < 64; ++hw) mx = fmaxf(mx, lg[hw * 288 + j]);
-        double den = 0;
-        for (int hw = 0; hw < 64; ++hw) den += (double)expf(lg[hw * 288 + j] - mx);
-        const float denf = (float)den;
-        for (int hw = 0; hw < 64; ++hw) {
-            const double r = (double)__fdiv_rn(expf(lg[hw * 288 + j] - mx), denf);
-            c0 += r * ((double)(hw & 7) / 7.0); c1 += r * ((double)(hw >> 3) / 7.0);
-        }
+    if (half == 0) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { c0 += red_c[0][q][j]; c1 += red_c[1][q][j]; c2 += red_c[2][q][j]; }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { c0 += red_c[3][q][j]; c1 += red_c[4][q][j]; }
         sh2d[j][0] = c0 * 255.0; sh2d[j][1] = c1 * 255.0;
     }
     __syncthreads();
@@ -265,7 +304,7 @@ __global__ __launch_bounds__(64) void hpe_post_kernel(PostArgs p) {
 }
 
 int launch_hpe_post(const PostArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(hpe_post_kernel, dim3(a.B), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(hpe_post_kernel, dim3(a.B), dim3(512), 0, st, a);
     ISB_LAUNCHED("hpe_post", st);
     return ISB_OK;
 }

@@ -133,6 +133,11 @@ struct ConvArgs {
     // ONE XCD, so its L2 fetches the A rows once (1: M tiles interleaved over XCDs, 2: contiguous M ranges)
     int grid_mode, grid_m, grid_n;
     int grid_bias_off;      // gated gemm1x1 kernels: LDS byte offset of the tile's bias row (set by the launcher)
+    // split-K (gemm1x1 kernels on single-frame launches: a few rows x a long K would run on a handful of CUs):
+    // blockIdx.z = split; each split writes its f32 partial tile to part[split][M][Cout]; launch_splitk_reduce
+    // adds the partials in split order + bias + residual and rounds once
+    int splits;
+    float* part;
     // fused Fused-MBConv block (launch_fused_mb): 3x3 expand (w, bias, act) -> bf16 -> 1x1 project (w2, bias2) + residual
     const uint16_t* w2;     // bf16 [Cout2][Cout] (BN scale folded)
     const float* bias2;     // [Cout2]
@@ -141,6 +146,7 @@ struct ConvArgs {
 int launch_conv_igemm(const ConvArgs& a, hipStream_t st);
 int launch_conv_expand_dw(const ConvArgs& a, hipStream_t st);
 int launch_fused_mb(const ConvArgs& a, hipStream_t st);
+int launch_splitk_reduce(const ConvArgs& a, hipStream_t st);
 
 struct DwArgs {
     const uint16_t* in;     // bf16 [B,H,W,C]

@@ -87,6 +87,42 @@ def test_conv_variants(case, variant):
     assert ms >= 0
 
 
+SPLITK_CASES = [
+    # B, H, Cin, Cout, act, res, gate, splits, tile variant
+    (1, 8, 2304, 384, 0, True, True, 12, 147),     # stage-6 projection of one frame
+    (1, 8, 3840, 640, 0, True, True, 16, 147),     # stage-7 projection: 120 k-tiles
+    (1, 16, 1344, 224, 0, True, True, 7, 147),     # stage-5 projection, 42 k-tiles in 7 splits
+    (2, 8, 416, 192, 0, False, True, 5, 147),      # 13 k-tiles in 5 splits -> ceil 3 per split, 5 splits, last one short
+    (3, 8, 320, 128, 1, True, False, 4, 138),      # un-gated, SiLU in the reduction, ragged M (192 rows)
+    (1, 8, 224, 64, 0, False, False, 16, 138),     # more splits asked for than k-tiles (7): clamped, none empty
+    (2, 8, 96, 96, 0, True, False, 3, 132),        # one k-tile per split on a 128 x 128 tile with overhang
+]
+
+
+@pytest.mark.parametrize("case", SPLITK_CASES)
+def test_conv_split_k(case):
+    """split-K GEMM + reduction (single-frame projections) against the torch reference and the one-launch kernel."""
+    B, H, Cin, Cout, act, use_res, use_gate, splits, variant = case
+    rng = np.random.default_rng(hash((case, 11)) % (2 ** 31))
+    x = rng.normal(0, 1, (B, H, H, Cin)).astype(np.float32)
+    w = (rng.normal(0, 1, (Cout, 1, 1, Cin)) / np.sqrt(Cin)).astype(np.float32)
+    scale = rng.uniform(0.8, 1.2, Cout).astype(np.float32)
+    shift = rng.uniform(-0.1, 0.1, Cout).astype(np.float32)
+    res = rng.normal(0, 1, (B, H, H, Cout)).astype(np.float32) if use_res else None
+    gate = rng.uniform(0.1, 0.9, (B, Cin)).astype(np.float32) if use_gate else None
+    r16 = None if res is None else f32_to_bf16(res)
+    out, _ = conv_debug(f32_to_bf16(x), w, scale, shift, 1, 1, act, r16, gate, variant=1000 * splits + variant)
+    one, _ = conv_debug(f32_to_bf16(x), w, scale, shift, 1, 1, act, r16, gate, variant=variant)
+    got, single = bf16_to_f32(out), bf16_to_f32(one)
+    ref = _ref(x, w, scale, shift, 1, 1, act, res, gate)
+    tol = 2.0 ** -7 * np.maximum(1.0, np.abs(ref))
+    assert np.all(np.abs(got - ref) <= tol), float(np.abs(got - ref).max())
+    assert np.all(np.abs(got - single) <= tol)
+    # the reduction adds the partials in split order: repeated launches are bit-identical
+    again, _ = conv_debug(f32_to_bf16(x), w, scale, shift, 1, 1, act, r16, gate, variant=1000 * splits + variant)
+    assert np.array_equal(out, again)
+
+
 @pytest.mark.parametrize("B,HW,Cin,Cexp", [(2, 16, 192, 768), (3, 8, 384, 2304), (1, 16, 224, 1344), (2, 8, 640, 3840)])
 def test_fused_expand_dw_pool(B, HW, Cin, Cexp):
     """Fused MBConv front half vs torch-CPU: expand 1x1 -> SiLU -> (bf16) -> depthwise 3x3 -> SiLU -> (bf16), SE mean."""

@@ -228,9 +228,32 @@ def test_no_person_gives_invalid_pose(eng_w):
     assert valid[0] == 1 and valid[1] == 0 and np.all(joints[1] == 0) and np.isfinite(joints).all()
 
 
+def test_single_frame_call_vs_oracle(eng_w, bbone_state, assets):
+    """The live loop's call: ONE frame. Its SE-gated projections run split-K (hpe_api.cpp conv()), a different f32
+    summation order from the batched launch: same tolerance against the oracle, within bf16 re-rounding noise of
+    the same frame inside a batch, and reproducible bit for bit."""
+    from oracle import hpe_oracle as ho
+    from oracle.effnetv2_oracle import EffNetV2LOracle
+    W, st = assets
+    idx = st["smpl+head_30"]["indices"]
+    fr = synth.frames(2, seed=31)
+    bb = synth.bboxes(2, seed=31)
+    j1, v1 = eng_w.forward(fr[:1], bb[:1])
+    j1b, _ = eng_w.forward(fr[:1], bb[:1])
+    j2, v2 = eng_w.forward(fr, bb)
+    assert np.array_equal(j1, j1b) and v1[0] == v2[0] == 1
+    nk, r, H = ho.crop_params(bb[0], _K())
+    o16 = EffNetV2LOracle(bbone_state, "bf16")
+    ref = ho.postprocess(o16.head(o16.backbone(ho.warp(fr[0], H[0])[None])), nk, r, W, idx)
+    np.testing.assert_allclose(j1[0] - j1[0][0], ref - ref[0], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(j1[0], ref, rtol=0, atol=4e-3)
+    np.testing.assert_allclose(j1[0] - j1[0][0], j2[0] - j2[0][0], rtol=0, atol=1e-3)
+
+
 def test_shard_invariance(eng_w):
-    """Frames are independent units: any split of a batch (what DP sharding across GPUs does)
-    gives bit-identical poses (SURVEY.md 8e correctness check)."""
+    """Frames are independent units: any split of a batch into shards of two or more frames (what DP sharding
+    across GPUs does) gives bit-identical poses (SURVEY.md 8e correctness check). Single-frame calls take the
+    split-K projections -- test_single_frame_call_vs_oracle."""
     fr = synth.frames(5, seed=70)
     bb = synth.bboxes(5, seed=70)
     j_all, v_all = eng_w.forward(fr, bb)
