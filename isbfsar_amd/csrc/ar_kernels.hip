@@ -29,6 +29,7 @@
 //     bound, `ub[c,j]` is that bound and exp2(s' - ub) cannot overflow; the host picks the ONLINE
 //     (running max) variant when the bound is too loose to rule out underflow.
 //   * bf16x3: operands split hi+lo, three MFMAs per product (lo*lo dropped) -> ~2^-16 relative.
+#include <algorithm>
 #include "isb_common.h"
 #include "kernels.h"
 
@@ -217,10 +218,10 @@ __global__ __launch_bounds__(512, 2) void ar_stats_kernel(ArStatsArgs p) {
     const int id = blockIdx.x, xcd = id & 7, sl = id >> 3;
     const int nsg = (p.n * p.NT + 7) >> 3;                          // groups of 8 (class, j-tile) slots
     const int nsb = (nsg + STATS_ST - 1) / STATS_ST;
-    const int blk = sl / (STATS_WT * STATS_ST), within = sl - blk * (STATS_WT * STATS_ST);
+    const int blk = sl / (p.wt * STATS_ST), within = sl - blk * (p.wt * STATS_ST);
     const int wbi = blk / nsb, sb = blk - wbi * nsb;
     const int sg = sb * STATS_ST + within % STATS_ST;
-    const int b = ((wbi * STATS_WT + within / STATS_ST) << 3) + xcd;
+    const int b = ((wbi * p.wt + within / STATS_ST) << 3) + xcd;
     if (sg >= nsg || b >= p.B) return;
     const int slot = sg * 8 + wave;
     const bool active = slot < p.n * p.NT;
@@ -335,9 +336,11 @@ __global__ __launch_bounds__(512, 2) void ar_stats_kernel(ArStatsArgs p) {
     }
 }
 
-int launch_ar_stats(const ArStatsArgs& a, hipStream_t st) {
+int launch_ar_stats(const ArStatsArgs& a0, hipStream_t st) {
+    ArStatsArgs a = a0;
     const bool online = a.online != 0;
-    dim3 grid(8 * cdiv(cdiv(a.B, 8), STATS_WT) * cdiv(cdiv(a.n * a.NT, 8), STATS_ST) * (STATS_WT * STATS_ST));
+    a.wt = std::min(STATS_WT, cdiv(a.B, 8));      // a few windows (the live loop): no grid padding to a full L2 block
+    dim3 grid(8 * cdiv(cdiv(a.B, 8), a.wt) * cdiv(cdiv(a.n * a.NT, 8), STATS_ST) * (a.wt * STATS_ST));
     if (a.x3) {
         if (online) hipLaunchKernelGGL((ar_stats_kernel<true, true>), grid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((ar_stats_kernel<true, false>), grid, dim3(512), 0, st, a);
@@ -378,9 +381,9 @@ __global__ __launch_bounds__(512, 2) void ar_proto_kernel(ArProtoArgs p) {
         const int id = blockIdx.x, xcd = id & 7, sl = id >> 3;
         const int nx = (p.B * p.NT + 7) >> 3;                       // window groups
         const int ncg = (p.n + PROTO_CT - 1) / PROTO_CT;
-        const int blk = sl / (PROTO_WT * PROTO_CT), within = sl - blk * (PROTO_WT * PROTO_CT);
+        const int blk = sl / (p.wt * PROTO_CT), within = sl - blk * (p.wt * PROTO_CT);
         const int wb = blk / ncg, cg = blk - wb * ncg;
-        bx = ((wb * PROTO_WT + within / PROTO_CT) << 3) + xcd;
+        bx = ((wb * p.wt + within / PROTO_CT) << 3) + xcd;
         cls = cg * PROTO_CT + within % PROTO_CT;
         if (bx >= nx || cls >= p.n) return;
     }
@@ -575,12 +578,15 @@ __global__ __launch_bounds__(512, 2) void ar_proto_kernel(ArProtoArgs p) {
     }
 }
 
-int launch_ar_proto(const ArProtoArgs& a, hipStream_t st) {
+int launch_ar_proto(const ArProtoArgs& a0, hipStream_t st) {
+    ArProtoArgs a = a0;
     const bool chosen = a.chosen != nullptr;
     dim3 grid(cdiv(a.B * a.NT, 8));
+    a.wt = PROTO_WT;
     if (!chosen) {
         const int nxl = cdiv(cdiv(a.B * a.NT, 8), 8);               // window groups per XCD
-        grid = dim3(8 * cdiv(nxl, PROTO_WT) * cdiv(a.n, PROTO_CT) * (PROTO_WT * PROTO_CT));
+        a.wt = std::min(PROTO_WT, nxl);                             // a few windows: no grid padding to a full L2 block
+        grid = dim3(8 * cdiv(nxl, a.wt) * cdiv(a.n, PROTO_CT) * (a.wt * PROTO_CT));
     }
     if (a.x3) {
         if (chosen) hipLaunchKernelGGL((ar_proto_kernel<true, true>), grid, dim3(512), 0, st, a);

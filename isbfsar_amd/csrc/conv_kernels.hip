@@ -32,6 +32,21 @@ __device__ __forceinline__ float bf2f_(uint16_t h) { return __uint_as_float((uin
 __device__ __forceinline__ uint16_t f2bf_(float x) { return __builtin_bit_cast(uint16_t, (__bf16)x); }
 __device__ __forceinline__ float silu_(float x) { return x / (1.0f + __expf(-x)); }
 
+// SE gate on eight bf16 values: bf16(f32(x) * g), two elements per instruction (shift / mask unpack, v_pk_mul_f32,
+// v_cvt_pk_bf16_f32) -- 4 VALU instructions per dword
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t gate_bf16x2(uint32_t w, float g_lo, float g_hi) {
+    f32x2_t x = {__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
+    const f32x2_t g = {g_lo, g_hi};
+    x = x * g;
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bf16x2_t));
+}
+__device__ __forceinline__ uint4 gate_bf16x8(uint4 v, float4 g0, float4 g1) {
+    return make_uint4(gate_bf16x2(v.x, g0.x, g0.y), gate_bf16x2(v.y, g0.z, g0.w), gate_bf16x2(v.z, g1.x, g1.y),
+                      gate_bf16x2(v.w, g1.z, g1.w));
+}
+
 constexpr int CK = 32;            // k-tile (bf16 elements) = 64 B per row
 constexpr int ROWB = 64;          // bytes per LDS row
 
@@ -244,15 +259,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(ConvArgs p) 
         for (int i = 0; i < A_PASS; ++i) {
             uint4 v = rA[SG][i];
             if (p.gate) {
-                uint32_t w[4] = {v.x, v.y, v.z, v.w};
-                const float gg[8] = {gA[i][0].x, gA[i][0].y, gA[i][0].z, gA[i][0].w, gA[i][1].x, gA[i][1].y, gA[i][1].z, gA[i][1].w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float lo = bf2f_((uint16_t)(w[e] & 0xffff)) * gg[2 * e];
-                    const float hi = bf2f_((uint16_t)(w[e] >> 16)) * gg[2 * e + 1];
-                    w[e] = (uint32_t)f2bf_(lo) | ((uint32_t)f2bf_(hi) << 16);
-                }
-                v = make_uint4(w[0], w[1], w[2], w[3]);
+                v = gate_bf16x8(v, gA[i][0], gA[i][1]);
             }
             if ((tid >> 2) + A_ROWS * i < BM) *reinterpret_cast<uint4*>(As + swz((tid >> 2) + A_ROWS * i, chunk)) = v;
         }
@@ -579,15 +586,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_kernel(ConvArgs
                 if constexpr (GATE) {
                     const float* gs = reinterpret_cast<const float*>(lds + GATE_OFF) + g_row[i] + kt * KT + ks * 16;
                     const float4 g0 = *reinterpret_cast<const float4*>(gs), g1 = *reinterpret_cast<const float4*>(gs + 4);
-                    const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-                    uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float lo = bf2f_((uint16_t)(w[e] & 0xffff)) * gg[2 * e];
-                        const float hi = bf2f_((uint16_t)(w[e] >> 16)) * gg[2 * e + 1];
-                        w[e] = (uint32_t)f2bf_(lo) | ((uint32_t)f2bf_(hi) << 16);
-                    }
-                    v = make_uint4(w[0], w[1], w[2], w[3]);
+                    v = gate_bf16x8(v, g0, g1);
                 }
                 af[i] = __builtin_bit_cast(bf16x8, v);
             }
@@ -806,15 +805,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_dma_kernel(ConvArgs p)
                 if constexpr (GATE) {
                     const float* gs = reinterpret_cast<const float*>(lds + GATE_OFF) + g_row[i] + kt_now * CK + ks * 16;
                     const float4 g0 = *reinterpret_cast<const float4*>(gs), g1 = *reinterpret_cast<const float4*>(gs + 4);
-                    const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-                    uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float lo = bf2f_((uint16_t)(w[e] & 0xffff)) * gg[2 * e];
-                        const float hi = bf2f_((uint16_t)(w[e] >> 16)) * gg[2 * e + 1];
-                        w[e] = (uint32_t)f2bf_(lo) | ((uint32_t)f2bf_(hi) << 16);
-                    }
-                    v = make_uint4(w[0], w[1], w[2], w[3]);
+                    v = gate_bf16x8(v, g0, g1);
                 }
                 af[i] = __builtin_bit_cast(bf16x8, v);
             }

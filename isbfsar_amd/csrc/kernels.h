@@ -65,6 +65,7 @@ struct ArStatsArgs {
     int B, n, T, NT;
     int x3;
     int online;             // 1: running-max variant (bound too loose to exclude underflow)
+    int wt;                 // grid decode: windows per L2 block (set by the launcher, <= STATS_WT)
 };
 int launch_ar_stats(const ArStatsArgs& a, hipStream_t st);
 
@@ -84,6 +85,7 @@ struct ArProtoArgs {
     float* diff;            // out [B][T][128] (chosen mode)
     int B, n, L, T, NT;
     int x3;
+    int wt;                 // grid decode: window groups per L2 block (set by the launcher, <= PROTO_WT)
 };
 int launch_ar_proto(const ArProtoArgs& a, hipStream_t st);
 
