@@ -1672,9 +1672,19 @@ __device__ __forceinline__ float dot2_bf16(uint32_t x, uint32_t w, float acc) {
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, x), __builtin_bit_cast(bf16x2_t, w), acc, false);
 }
 
-template <int S>
+// sum over the 16 lanes of a DPP row (row_ror 8, 4, 2, 1), the total in every lane
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+    return v;
+}
+
+template <int S, bool FC1 = false>
 __global__ __launch_bounds__(256) void dwconv3x3_pool_kernel(DwArgs p) {
     __shared__ float red[32][129];
+    __shared__ __attribute__((aligned(16))) float pmean[FC1 ? 128 : 4];
     constexpr int NCOL = 3 * S + 3;
     const int nq = (p.OH * p.OW) >> 2;                    // pixel quads per sample
     const int PQ = nq >= 32 ? 32 : nq;                    // quad slots in the WG
@@ -1683,6 +1693,21 @@ __global__ __launch_bounds__(256) void dwconv3x3_pool_kernel(DwArgs p) {
     const int b = blockIdx.y;
     const int c = (blockIdx.x * CH + cl) * 8;
     const bool cok = c < p.C;
+    // FC1: the slab's squeeze-excite weights do not depend on anything computed here -- request them first, they
+    // arrive while the taps run (one frame = one workgroup per CU: the 80 registers cost no occupancy)
+    const int sub = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    bool fc_ok = false;
+    float4 wv[FC1 ? 20 : 1];
+    if constexpr (FC1) {
+        const int c0 = blockIdx.x * CH * 8, nch = min(CH * 8, p.C - c0);
+        fc_ok = sub * 4 < nch;
+#pragma unroll
+        for (int q = 0; q < 20; ++q) {
+            const int j = grp + 8 * q;
+            wv[q] = (fc_ok && j < p.cse) ? *reinterpret_cast<const float4*>(p.se_w1 + (size_t)j * p.C + c0 + sub * 4)
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     uint32_t wlo[9][4], whi[9][4];                        // tap weights of the even / odd channel of each pair
     float bias[8], psum[8];
     // bf16 (1, 0) and (0, 1) in registers: as a literal 0x3f800000 becomes the INLINE constant 1.0, which a packed
@@ -1759,13 +1784,38 @@ __global__ __launch_bounds__(256) void dwconv3x3_pool_kernel(DwArgs p) {
         __syncthreads();
         if ((int)threadIdx.x < CH * 8) {
             const int cc = blockIdx.x * CH * 8 + threadIdx.x;
+            float mean = 0.f;
             if (cc < p.C) {
                 float t = 0.f;
                 for (int s2 = 0; s2 < PQ; ++s2) t += red[s2][threadIdx.x];
-                p.pooled[(size_t)b * p.C + cc] = t / (float)(p.OH * p.OW);
+                mean = t / (float)(p.OH * p.OW);
+                p.pooled[(size_t)b * p.C + cc] = mean;
+            }
+            if constexpr (FC1) pmean[threadIdx.x] = mean;
+        }
+        if constexpr (FC1) {
+            // this slab's share of squeeze-excite FC1: 32 lanes per output row j hold the row's slab (requested at
+            // kernel start), multiply with the pooled means and meet in a butterfly. 8 groups x 20 rows: cse <= 160.
+            __syncthreads();
+            const float4 pv = fc_ok ? *reinterpret_cast<const float4*>(&pmean[sub * 4]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float racc[20], rup[20];
+#pragma unroll
+            for (int q = 0; q < 20; ++q)      // 16-lane sums on the vector ALU (DPP row rotations), no LDS round trips
+                racc[q] = row16_sum(fmaf(pv.w, wv[q].w, fmaf(pv.z, wv[q].z, fmaf(pv.y, wv[q].y, pv.x * wv[q].x))));
+#pragma unroll
+            for (int q = 0; q < 20; ++q) rup[q] = __shfl_xor(racc[q], 16, 64);     // the other half-row: 20 permutes in flight
+#pragma unroll
+            for (int q = 0; q < 20; ++q) {
+                const int j = grp + 8 * q;
+                if (sub == 0 && j < p.cse) p.se_part[((size_t)blockIdx.x * p.B + b) * p.cse + j] = racc[q] + rup[q];
             }
         }
     }
+}
+
+int dw_slabs(const DwArgs& a) {
+    const int nq = (a.OH * a.OW) >> 2;
+    return cdiv(a.C / 8, 256 / std::min(32, std::max(nq, 1)));
 }
 
 int launch_dwconv3x3(const DwArgs& a, hipStream_t st) {
@@ -1773,11 +1823,16 @@ int launch_dwconv3x3(const DwArgs& a, hipStream_t st) {
         set_error("dwconv3x3: unsupported shape C=%d OH=%d OW=%d", a.C, a.OH, a.OW);
         return ISB_ERR_INVALID;
     }
-    const int nq = (a.OH * a.OW) >> 2;
-    const int CH = 256 / std::min(32, nq);
-    dim3 grid(cdiv(a.C / 8, CH), a.B);
-    if (a.stride == 1) hipLaunchKernelGGL(dwconv3x3_pool_kernel<1>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(dwconv3x3_pool_kernel<2>, grid, dim3(256), 0, st, a);
+    dim3 grid(dw_slabs(a), a.B);
+    if (a.se_w1) {
+        if (!a.pooled || !a.se_part || a.cse < 1 || a.cse > 160 || a.C % 8 != 0 || (int)grid.x > SE_MAX_PARTS) {
+            set_error("dwconv3x3: the folded SE FC1 needs pooled + se_part, cse <= 160 and at most %d slabs (C=%d)", SE_MAX_PARTS, a.C);
+            return ISB_ERR_INVALID;
+        }
+        if (a.stride == 1) hipLaunchKernelGGL((dwconv3x3_pool_kernel<1, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((dwconv3x3_pool_kernel<2, true>), grid, dim3(256), 0, st, a);
+    } else if (a.stride == 1) hipLaunchKernelGGL((dwconv3x3_pool_kernel<1, false>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((dwconv3x3_pool_kernel<2, false>), grid, dim3(256), 0, st, a);
     ISB_LAUNCHED("dwconv3x3_pool", st);
     return ISB_OK;
 }
@@ -1833,22 +1888,35 @@ __global__ __launch_bounds__(256) void se_fc1_part_kernel(SeFcArgs p) {
     if (b < p.B && j < p.cse) p.part[((size_t)blockIdx.z * p.B + b) * p.cse + j] = acc;
 }
 
+// PRE (launches of a few samples: one workgroup per CU, latency is everything): the wave's W2T rows are requested
+// before the FC1 partials are even read, so the kernel makes one memory round trip instead of six
+template <bool PRE>
 __global__ __launch_bounds__(256) void se_fc2_kernel(SeFcArgs p) {
     __shared__ __attribute__((aligned(16))) float mids[160][8];          // [j][sample]
     __shared__ __attribute__((aligned(16))) float4 red[4][8][64];        // [wave][sample][lane]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int b0 = blockIdx.y * 8;
-    const int nkc = (p.C + SE_CHUNK - 1) / SE_CHUNK;
+    float4 wpre[PRE ? 40 : 1];
+    if constexpr (PRE) {
+        const int c = blockIdx.x * 256 + lane * 4;
+        const int jq = (p.cse + 3) >> 2, jb = wave * jq, je = min(p.cse, jb + jq);
+#pragma unroll
+        for (int q = 0; q < 40; ++q)
+            wpre[q] = (c < p.C && jb + q < je) ? *reinterpret_cast<const float4*>(p.w2t + (size_t)(jb + q) * p.C + c)
+                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int nkc = p.nparts > 0 ? p.nparts : (p.C + SE_CHUNK - 1) / SE_CHUNK;
     for (int i = t; i < 8 * p.cse; i += 256) {
         const int sm = i / p.cse, j = i - sm * p.cse;
         float v = 0.f;
         if (b0 + sm < p.B) {
-            float pv[15];                      // all chunk partials requested at once (one memory round trip), added in order
+            float pv[SE_MAX_PARTS];            // all partials requested at once (one memory round trip), added in order
 #pragma unroll
-            for (int kc = 0; kc < 15; ++kc) pv[kc] = kc < nkc ? p.part[((size_t)kc * p.B + b0 + sm) * p.cse + j] : 0.f;
+            for (int kc = 0; kc < SE_MAX_PARTS; ++kc) pv[kc] = kc < nkc ? p.part[((size_t)kc * p.B + b0 + sm) * p.cse + j] : 0.f;
             v = p.b1[j];
 #pragma unroll
-            for (int kc = 0; kc < 15; ++kc) v += pv[kc];
+            for (int kc = 0; kc < SE_MAX_PARTS; ++kc)
+                if (kc < nkc) v += pv[kc];
             v = v / (1.0f + expf(-v));
         }
         mids[j][sm] = v;
@@ -1861,7 +1929,25 @@ __global__ __launch_bounds__(256) void se_fc2_kernel(SeFcArgs p) {
     float4 acc[8];
 #pragma unroll
     for (int sm = 0; sm < 8; ++sm) acc[sm] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (cok) {
+    const int ns = min(8, p.B - b0);
+    if constexpr (PRE) {
+#pragma unroll
+        for (int q = 0; q < 40; ++q) {
+            if (jb + q >= je) break;
+            const float4 wv = wpre[q];
+            const float4 m0 = *reinterpret_cast<const float4*>(&mids[jb + q][0]);
+            const float4 m1 = *reinterpret_cast<const float4*>(&mids[jb + q][4]);
+            const float mm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+#pragma unroll
+            for (int sm = 0; sm < 8; ++sm) {
+                if (sm >= ns) break;           // a single frame pays for one sample, not eight
+                acc[sm].x = fmaf(mm[sm], wv.x, acc[sm].x);
+                acc[sm].y = fmaf(mm[sm], wv.y, acc[sm].y);
+                acc[sm].z = fmaf(mm[sm], wv.z, acc[sm].z);
+                acc[sm].w = fmaf(mm[sm], wv.w, acc[sm].w);
+            }
+        }
+    } else if (cok) {
 #pragma unroll 8
         for (int j = jb; j < je; ++j) {
             const float4 wv = *reinterpret_cast<const float4*>(p.w2t + (size_t)j * p.C + c);
@@ -1901,12 +1987,14 @@ __global__ __launch_bounds__(256) void se_fc2_kernel(SeFcArgs p) {
 }
 
 int launch_se_fcs(const SeFcArgs& a, hipStream_t st) {
-    if (a.cse > 160 || a.C % 4 != 0 || a.C > 15 * SE_CHUNK || !a.part) {
-        set_error("se_fcs: unsupported shape cse=%d C=%d", a.cse, a.C);
+    if (a.cse > 160 || a.C % 4 != 0 || a.C > 15 * SE_CHUNK || !a.part || a.nparts > SE_MAX_PARTS) {
+        set_error("se_fcs: unsupported shape cse=%d C=%d parts=%d", a.cse, a.C, a.nparts);
         return ISB_ERR_INVALID;
     }
-    hipLaunchKernelGGL(se_fc1_part_kernel, dim3(cdiv(a.cse, 16), cdiv(a.B, 16), cdiv(a.C, SE_CHUNK)), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(se_fc2_kernel, dim3(cdiv(a.C, 256), cdiv(a.B, 8)), dim3(256), 0, st, a);
+    if (a.nparts <= 0)
+        hipLaunchKernelGGL(se_fc1_part_kernel, dim3(cdiv(a.cse, 16), cdiv(a.B, 16), cdiv(a.C, SE_CHUNK)), dim3(256), 0, st, a);
+    if (a.B <= 8) hipLaunchKernelGGL(se_fc2_kernel<true>, dim3(cdiv(a.C, 256), 1), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(se_fc2_kernel<false>, dim3(cdiv(a.C, 256), cdiv(a.B, 8)), dim3(256), 0, st, a);
     ISB_LAUNCHED("se_fcs", st);
     return ISB_OK;
 }

@@ -131,7 +131,7 @@ int ensure_ws(Lane& L, int Bm) {
     ISB_TRY(L.bufE.alloc(B * 64 * 64 * 256 * 2));
     ISB_TRY(L.bufD.alloc(B * 32 * 32 * 384 * 2));
     ISB_TRY(L.pooled.alloc(B * 3840 * 4));
-    ISB_TRY(L.semid.alloc(B * 160 * 15 * 4));       // SE fc1 partial sums: 15 chunks of 256 channels x 160 outputs
+    ISB_TRY(L.semid.alloc(B * 160 * 32 * 4));       // SE fc1 partial sums: up to 32 channel slabs x 160 outputs
     ISB_TRY(L.gate.alloc(B * 3840 * 4));
     ISB_TRY(L.feat.alloc(B * 64 * 1280 * 4));
     ISB_TRY(L.logits.alloc(B * 64 * 288 * 4));
@@ -224,6 +224,7 @@ int run_backbone(isb_hpe* h, Lane& L, hipStream_t st, const float* crops, int B)
                 ISB_TRY(conv(h, st, b.project, L.bufE.p, B, b.out_hw, b.out_hw, 1, false, res, nullptr, Y, false));
             }
         } else {
+            int se_parts = 0;
             if (b.stride == 1 && h->fuse_front) {
                 // expand 1x1 + dw 3x3 + SE pool in one launch: the expanded tensor never leaves the chip
                 ConvArgs a{};
@@ -252,9 +253,14 @@ int run_backbone(isb_hpe* h, Lane& L, hipStream_t st, const float* crops, int B)
                 d.B = B; d.H = b.in_hw; d.W = b.in_hw; d.C = b.cexp; d.OH = b.out_hw; d.OW = b.out_hw; d.stride = b.stride;
                 d.pad = b.stride == 1 ? 1 : 0;
                 d.pooled = L.pooled.as<float>();
+                if (B == 1 && h->split_k) {        // one frame: FC1 of the squeeze-excite rides in the depthwise launch
+                    d.se_w1 = b.se_w1.as<float>(); d.se_part = L.semid.as<float>(); d.cse = b.cse;
+                    se_parts = dw_slabs(d);
+                }
                 ISB_TRY(launch_dwconv3x3(d, st));
             }
             SeFcArgs se{};
+            se.nparts = se_parts;
             se.pooled = L.pooled.as<float>(); se.w1 = b.se_w1.as<float>(); se.b1 = b.se_b1.as<float>();
             se.w2t = b.se_w2.as<float>(); se.b2 = b.se_b2.as<float>(); se.part = L.semid.as<float>();
             se.gate = L.gate.as<float>(); se.B = B; se.C = b.cexp; se.cse = b.cse;

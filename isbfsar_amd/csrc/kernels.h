@@ -157,8 +157,14 @@ struct DwArgs {
     uint16_t* out;          // bf16 [B,OH,OW,C]
     float* pooled;          // f32 [B,C] spatial mean of `out` (squeeze-excite input) or null
     int B, H, W, C, OH, OW, stride, pad;
+    // single-frame calls: the workgroup that owns a channel slab of a sample also owns its pooled means, so it writes
+    // the slab's share of the first squeeze-excite FC: se_part[slab][b][j] = sum_{c in slab} pooled[b][c] * se_w1[j][c]
+    const float* se_w1;     // [cse,C] or null
+    float* se_part;         // [dw_slabs(a)][B][cse]
+    int cse;
 };
 int launch_dwconv3x3(const DwArgs& a, hipStream_t st);
+int dw_slabs(const DwArgs& a);      // channel slabs (= grid.x) of the launch
 
 struct SeFcArgs {
     const float* pooled;    // [B,C]
@@ -169,7 +175,9 @@ struct SeFcArgs {
     float* part;            // scratch [ceil(C/256), B, cse]: fc1 partial sums per 256-channel chunk
     float* gate;            // out [B,C]
     int B, C, cse;
+    int nparts;             // 0: run fc1 over 256-channel chunks; > 0: part already holds this many slabs (DwArgs.se_part)
 };
+constexpr int SE_MAX_PARTS = 32;
 int launch_se_fcs(const SeFcArgs& a, hipStream_t st);
 
 struct StemArgs {
