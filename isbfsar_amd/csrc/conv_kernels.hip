@@ -697,7 +697,9 @@ __device__ __forceinline__ void dma16_s(const void* sbase, uint32_t voff, uint32
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sb), "s"(la) : "memory");
 }
 
-template <int TM, int TN, int WGM, int WGN, bool GATE = false>
+// GATE: 0 = none, 1 = gate rows read from p.gate, 2 = gate of the workgroup's k-range computed here from the
+// squeeze-excite FC1 partials (single-frame split-K launches: se_fc2_kernel's arithmetic, in its order)
+template <int TM, int TN, int WGM, int WGN, int GATE = 0>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_dma_kernel(ConvArgs p) {
     constexpr int NW = WGM * WGN;
     constexpr int BM = 32 * TM * WGM;
@@ -741,6 +743,23 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_dma_kernel(ConvArgs p)
         kt_first = min((int)blockIdx.z * per, nkt);
         nkt = min(per, nkt - kt_first);
     }
+    // GATE == 2: lane = 4 channels of the k-range, wave = a quarter of the FC2 inputs; the weight rows are requested
+    // before anything else so that they travel while the first tiles do
+    float4 wpre[GATE == 2 ? 40 : 1];
+    int se_jb = 0, se_je = 0;
+    bool se_cok = false;
+    if constexpr (GATE == 2) {
+        static_assert(NW == 4, "the folded FC2 splits its inputs over 4 waves");
+        const int c = kt_first * CK + lane * 4;
+        se_cok = lane * 4 < nkt * CK;
+        const int jq = (p.se_cse + 3) >> 2;
+        se_jb = wave * jq;
+        se_je = min(p.se_cse, se_jb + jq);
+#pragma unroll
+        for (int q = 0; q < 40; ++q)
+            wpre[q] = (se_cok && se_jb + q < se_je) ? *reinterpret_cast<const float4*>(p.se_w2t + (size_t)(se_jb + q) * p.Cin + c)
+                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     const unsigned char* a_base = reinterpret_cast<const unsigned char*>(p.in) + kt_first * (CK * 2);
     const unsigned char* b_base = reinterpret_cast<const unsigned char*>(p.w) + kt_first * (CK * 2);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)lds + wave * 1024;
@@ -783,7 +802,53 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_dma_kernel(ConvArgs p)
     dma(std::integral_constant<int, 0>{});      // first tile in flight while the gate rows are staged
     int g_row[TM];
     int kt_now = kt_first;
-    if constexpr (GATE) {
+    if constexpr (GATE == 2) {
+        float* gate_s = reinterpret_cast<float*>(lds + GATE_OFF);            // [256] gate of this k-range
+        float* mids = gate_s + 256;                                          // [160]
+        float4* red = reinterpret_cast<float4*>(mids + 160);                 // [4][64]
+        const int sample = m0 / (p.OH * p.OW);
+        if (tid < p.se_cse) {
+            float pv[SE_MAX_PARTS];
+#pragma unroll
+            for (int kc = 0; kc < SE_MAX_PARTS; ++kc)
+                pv[kc] = kc < p.se_nparts ? p.se_part[((size_t)kc * p.B + sample) * p.se_cse + tid] : 0.f;
+            float v = p.se_b1[tid];
+#pragma unroll
+            for (int kc = 0; kc < SE_MAX_PARTS; ++kc)
+                if (kc < p.se_nparts) v += pv[kc];
+            mids[tid] = v / (1.0f + expf(-v));
+        }
+        __syncthreads();
+        float4 ga = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < 40; ++q) {
+            if (se_jb + q >= se_je) break;
+            const float mv = mids[se_jb + q];
+            ga.x = fmaf(mv, wpre[q].x, ga.x);
+            ga.y = fmaf(mv, wpre[q].y, ga.y);
+            ga.z = fmaf(mv, wpre[q].z, ga.z);
+            ga.w = fmaf(mv, wpre[q].w, ga.w);
+        }
+        red[wave * 64 + lane] = ga;
+        __syncthreads();
+        if (wave == 0 && se_cok) {
+            float4 v = red[lane];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const float4 u = red[w * 64 + lane];
+                v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+            }
+            const float4 bias = *reinterpret_cast<const float4*>(p.se_b2 + kt_first * CK + lane * 4);
+            v.x = 1.0f / (1.0f + expf(-(v.x + bias.x)));
+            v.y = 1.0f / (1.0f + expf(-(v.y + bias.y)));
+            v.z = 1.0f / (1.0f + expf(-(v.z + bias.z)));
+            v.w = 1.0f / (1.0f + expf(-(v.w + bias.w)));
+            *reinterpret_cast<float4*>(gate_s + lane * 4) = v;
+        }
+        kt_now = 0;                                 // gate_s is indexed from the start of the k-range; published below
+#pragma unroll
+        for (int i = 0; i < TM; ++i) g_row[i] = 8 * h;
+    } else if constexpr (GATE == 1) {
         const int ohw = p.OH * p.OW;
         const int s_first = m0 / ohw;
 #pragma unroll
@@ -1615,6 +1680,29 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
         const dim3 g = conv_grid(aa, BM_, BN_);                                                                  \
         hipLaunchKernelGGL(kern, g, dim3(64 * WGM * WGN), bytes, st, aa);                                        \
     } while (0)
+        case 149: {                                          //  64 x 128, split-K, squeeze-excite FC2 folded in
+            constexpr int BM_ = 64, BN_ = 128;
+            const int nkt_ = a.Cin / CK, per_ = aa.splits > 1 ? cdiv(nkt_, aa.splits) : nkt_;
+            if (a.KH != 1 || a.stride != 1 || a.pad != 0 || (a.OH * a.OW) % BM_ != 0 || aa.splits < 2 || per_ * CK > 256 ||
+                !a.se_part || !a.se_b1 || !a.se_w2t || !a.se_b2 || a.se_cse < 1 || a.se_cse > 160 || a.se_nparts < 1 ||
+                a.se_nparts > SE_MAX_PARTS) {
+                set_error("conv_igemm: variant 149 is a split-K gated 1x1 GEMM (k-range <= 256 channels per split) with FC1 partials");
+                return ISB_ERR_INVALID;
+            }
+            const int ring = 2 * (BM_ + BN_) * ROWB + (256 + 160) * 4 + 4 * 64 * 16;
+            const int stage = BM_ * (BN_ * 2 + 16);
+            aa.grid_bias_off = ring > stage ? ring : stage;
+            const int bytes = aa.grid_bias_off + BN_ * 4;
+            auto kern = gemm1x1_dma_kernel<1, 2, 2, 2, 2>;
+            static bool attr_set = false;
+            if (!attr_set) {
+                ISB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+                attr_set = true;
+            }
+            const dim3 g = conv_grid(aa, BM_, BN_);
+            hipLaunchKernelGGL(kern, g, dim3(256), bytes, st, aa);
+            break;
+        }
         case 141: ISB_CONV_LAUNCH_G1G(1, 3, 4, 2); break;   // 128 x 192, SE gate on the A fragments
         case 142: ISB_CONV_LAUNCH_G1G(1, 2, 4, 2); break;   // 128 x 128
         case 143: ISB_CONV_LAUNCH_G1G(1, 7, 4, 1); break;   // 128 x 224

@@ -54,6 +54,7 @@ struct isb_hpe {
     isb_hpe_cfg cfg{};
     hipStream_t own_stream = nullptr;
     bool weights = false, jointmap = false;
+    bool fuse_se = true;          // single-frame split-K projections compute their SE gate in the GEMM; ISB_FUSE_SE=0 disables
     bool split_k = true;          // split-K for the projections of single-frame calls; ISB_SPLIT_K=0 disables
     bool fuse_block = true;       // Fused-MBConv blocks (3x3 expand + 1x1 project) in one launch; ISB_FUSE_BLOCK=0 disables
     int fuse_block_max_cexp = 256;   // 384 expanded channels (E tile 96 KiB) measured 10 % slower than two launches
@@ -141,7 +142,7 @@ int ensure_ws(Lane& L, int Bm) {
 }
 
 int conv(isb_hpe* h, hipStream_t st, const ConvW& cw, const void* in, int B, int H, int W, int stride, bool act,
-         const void* res, const float* gate, void* out, bool out_f32, Lane* lane = nullptr) {
+         const void* res, const float* gate, void* out, bool out_f32, Lane* lane = nullptr, const SeFcArgs* se = nullptr) {
     ConvArgs a{};
     a.in = (const uint16_t*)in; a.w = cw.w16.as<uint16_t>(); a.bias = cw.bias.as<float>();
     a.res = (const uint16_t*)res; a.gate = gate; a.out = out;
@@ -159,6 +160,20 @@ int conv(isb_hpe* h, hipStream_t st, const ConvW& cw, const void* in, int B, int
         (!gate || (a.OH * a.OW) % 64 == 0)) {
         const int s = std::min(a.Cin / 32 / 6, 16);
         if (s > 1 && (size_t)s * a.M * a.Cout * 4 <= kSplitKBytes) { a.splits = s; a.part = lane->part.as<float>(); }
+    }
+    // se: the squeeze-excite FCs that produce `gate` have not run yet. A split-K launch whose k-ranges are at most
+    // 256 channels computes each range's gate inside the GEMM (variant 149); otherwise the FC kernels run first.
+    if (se) {
+        const int nkt = a.Cin / 32;
+        if (h->fuse_se && a.splits > 1 && se->nparts > 0 && ((nkt + a.splits - 1) / a.splits) * 32 <= 256 &&
+            (a.OH * a.OW) % 64 == 0) {
+            a.se_part = se->part; a.se_b1 = se->b1; a.se_w2t = se->w2t; a.se_b2 = se->b2;
+            a.se_nparts = se->nparts; a.se_cse = se->cse;
+            a.gate = nullptr;
+            a.variant = 149;
+        } else {
+            ISB_TRY(launch_se_fcs(*se, st));
+        }
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->prof) {
@@ -264,8 +279,7 @@ int run_backbone(isb_hpe* h, Lane& L, hipStream_t st, const float* crops, int B)
             se.pooled = L.pooled.as<float>(); se.w1 = b.se_w1.as<float>(); se.b1 = b.se_b1.as<float>();
             se.w2t = b.se_w2.as<float>(); se.b2 = b.se_b2.as<float>(); se.part = L.semid.as<float>();
             se.gate = L.gate.as<float>(); se.B = B; se.C = b.cexp; se.cse = b.cse;
-            ISB_TRY(launch_se_fcs(se, st));
-            ISB_TRY(conv(h, st, b.project, L.bufD.p, B, b.out_hw, b.out_hw, 1, false, res, L.gate.as<float>(), Y, false, &L));
+            ISB_TRY(conv(h, st, b.project, L.bufD.p, B, b.out_hw, b.out_hw, 1, false, res, L.gate.as<float>(), Y, false, &L, &se));
         }
         std::swap(X, Y);
     }
@@ -335,6 +349,7 @@ extern "C" int isb_hpe_create(const isb_hpe_cfg* cfg, isb_hpe** out) {
     h->fuse_front = getenv("ISB_FUSE_FRONT") != nullptr;
     if (const char* e = getenv("ISB_FUSE_BLOCK")) h->fuse_block = atoi(e) != 0;
     if (const char* e = getenv("ISB_SPLIT_K")) h->split_k = atoi(e) != 0;
+    if (const char* e = getenv("ISB_FUSE_SE")) h->fuse_se = atoi(e) != 0;
     if (const char* e = getenv("ISB_FUSE_BLOCK_CEXP")) h->fuse_block_max_cexp = atoi(e);
     if (const char* e = getenv("ISB_HPE_LANES")) h->n_lanes = std::max(1, std::min(kMaxLanes, atoi(e)));
     ISB_HIP(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));

@@ -140,6 +140,13 @@ struct ConvArgs {
     // adds the partials in split order + bias + residual and rounds once
     int splits;
     float* part;
+    // split-K gated projection of ONE frame with the second squeeze-excite FC folded in (variant 149): each workgroup
+    // computes the gate of its own k-range (at most 256 channels) from the FC1 partials, exactly as se_fc2_kernel does
+    const float* se_part;   // [se_nparts][B][se_cse] FC1 partial sums (SeFcArgs.part / DwArgs.se_part)
+    const float* se_b1;     // [se_cse]
+    const float* se_w2t;    // [se_cse][Cin]
+    const float* se_b2;     // [Cin]
+    int se_nparts, se_cse;
     // fused Fused-MBConv block (launch_fused_mb): 3x3 expand (w, bias, act) -> bf16 -> 1x1 project (w2, bias2) + residual
     const uint16_t* w2;     // bf16 [Cout2][Cout] (BN scale folded)
     const float* bias2;     // [Cout2]

@@ -281,6 +281,28 @@ def test_two_lane_split_is_bit_identical(bbone_state, assets):
         e.close()
 
 
+def test_single_frame_fusions_are_bit_identical(bbone_state, assets, monkeypatch):
+    """The single-frame path folds the squeeze-excite FCs into its neighbours (FC1 into the depthwise launch, FC2 into
+    the split-K projection) with the summation order of the stand-alone kernels: with the FC2 fusion switched off
+    (ISB_FUSE_SE=0, read when the engine is created) the poses are the same bits."""
+    from isbfsar_amd.hpe_engine import HpeEngine
+    fr = synth.frames(3, seed=41)
+    bb = synth.bboxes(3, seed=41)
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("ISB_FUSE_SE", flag)
+        e = HpeEngine(device=0, max_batch=4)
+        try:
+            e.set_joint_map(assets[0], assets[1]["smpl+head_30"]["indices"])
+            e.load_weights(bbone_state)
+            outs.append([e.forward(fr[i:i + 1], bb[i:i + 1])[0] for i in range(3)])
+        finally:
+            e.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    assert np.isfinite(np.concatenate(outs[0])).all()
+
+
 def test_full_size_properties(bbone_state, assets):
     """BASELINE configs[1] size (256 frames per GPU): properties that need no oracle run --
     determinism, invariance under re-batching (4 x 64 through two lanes each vs 256 through two lanes),
