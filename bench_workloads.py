@@ -127,7 +127,7 @@ class HpeWorkload(_HpeBase):
         return self._hpe_roofline(steps)
 
     def cpu_baseline(self, sample):
-        n = sample or 8
+        n = sample or 128                # ~12 s on the box's 16 host cores
         self._cpu_hpe_seconds_per_frame(1)
         spf = self._cpu_hpe_seconds_per_frame(n)
         return {"value": round(1.0 / spf, 3), "unit": "frames/s", "cores": usable_cores(), "kind": "port",
@@ -189,12 +189,12 @@ class PipelineWorkload(_HpeBase):
 
     def cpu_baseline(self, sample):
         from oracle.ar_oracle import TRXOSOracle
-        n = sample or 6
+        n = sample or 96                 # ~9 s of pose oracle + ~8 s of AR oracle on 16 host cores
         self._cpu_hpe_seconds_per_frame(1)
         spf = self._cpu_hpe_seconds_per_frame(n)
         net = TRXOSOracle(self.ar_state, self.L, self.J)
         sf = net.mlp(self.ss)
-        q = synth.skeleton_windows(32, self.L, self.J, seed=9)
+        q = synth.skeleton_windows(96 if n >= 96 else 32, self.L, self.J, seed=9)
         net.forward(None, self.way, q[:2], ss_features=sf)
         t0 = time.perf_counter()
         net.forward(None, self.way, q, ss_features=sf)
@@ -295,7 +295,7 @@ class StreamWorkload(_HpeBase):
         return r
 
     def cpu_baseline(self, sample):
-        return PipelineWorkload.cpu_baseline(self, sample or 3)
+        return PipelineWorkload.cpu_baseline(self, sample or 48)
 
     def config(self, world):
         return {"workload": "BASELINE configs[4]: 1 camera feed per GPU, per-frame step = HPE (1 frame, 122 joints) + AR on the "

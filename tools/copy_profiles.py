@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Copies the evidence that tools/round_profiles.sh left under gpurun_out/ into profiles/ (tracked), named per round:
+    python tools/copy_profiles.py r01
+Counter CSVs are trimmed to dispatch / kernel / grid / workgroup / counter columns."""
+import csv
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+G, P = "gpurun_out", "profiles"
+for w, name in (("pipeline", "pipe"), ("hpe", "hpe"), ("ar", "ar"), ("stream", "stream")):
+    shutil.copy(f"{G}/bench_{w}.json", f"{P}/{tag}_bench_{name}.json")
+shutil.copy(f"{G}/prof_pipe/run_kernel_stats.csv", f"{P}/{tag}_pipeline_b256_kernel_stats.csv")
+shutil.copy(f"{G}/prof_ar/run_kernel_stats.csv", f"{P}/{tag}_ar_b1024_kernel_stats.csv")
+shutil.copy(f"{G}/traffic.json", f"{P}/{tag}_traffic.json")
+for src, dst in (("pmc_fetch", "hpe_b256_fetch_size"), ("pmc_write", "hpe_b256_write_size")):
+    with open(f"{G}/{src}/run_counter_collection.csv") as f, open(f"{P}/{tag}_{dst}_counters.csv", "w", newline="") as o:
+        w = csv.writer(o)
+        w.writerow(["Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "Counter_Name", "Counter_Value"])
+        for r in csv.DictReader(f):
+            w.writerow([r["Dispatch_Id"], r["Kernel_Name"][:80], r["Grid_Size"], r["Workgroup_Size"], r["Counter_Name"],
+                        r["Counter_Value"]])
+print("copied to", P)
