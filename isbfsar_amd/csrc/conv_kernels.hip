@@ -1070,6 +1070,146 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_dma_kernel(ConvArgs p)
 }
 
 // -------------------------------------------------------------------------------------------
+// 3x3 stride-1 convolution 32 -> 32 channels on 128-wide images (the first stage: four layers on the largest
+// activations). As an implicit GEMM it has N = 32: every k-step of the kernels above copies 16 KiB of im2col rows for
+// two MFMAs per wave -- LDS-DMA issue bound, and every input pixel crosses the L2 -> LDS path nine times. Here a
+// workgroup walks down a band of image rows, two output rows (256 pixels) per step, with the input rows it needs in
+// an LDS RING of six rows: four feed the current step, the two the next step adds are in flight meanwhile, so every
+// input pixel is copied ONCE (out-of-image pixels zero-filled by the buffer bounds check). The A fragments of all
+// nine taps are read from the ring directly -- lane r's pixel shifted by the tap is just another 64-byte LDS row --
+// and the weights (18 KiB) live in registers as 18 B fragments per lane for the whole band.
+// LDS rows are pixels (144 per image row: x = -1 .. 142, nine 1-KiB pieces); chunk slot = logical chunk ^
+// ((pixel >> 1) & 3): eight consecutive pixels hit all 32 banks for any tap shift. A step's 256 outputs are
+// consecutive NHWC pixels, so the shared epilogue (bias, SiLU, residual, 16-byte row stores) applies unchanged.
+// Sums run in the (tap, channel) order of the implicit-GEMM kernels: bit-identical results.
+// -------------------------------------------------------------------------------------------
+constexpr int HALO_ROWB = 144 * 64;                  // bytes per ring row
+constexpr int HALO_RING = 6 * HALO_ROWB;
+constexpr int HALO_LDS = HALO_RING + 256 * 64;       // + the step's output tile (residual in, result out: in place)
+__global__ __launch_bounds__(512, 2) void conv3x3_c32_rows_kernel(ConvArgs p, int band) {
+    constexpr int W_ = 128;
+    unsigned char* const lds = conv_lds_dyn;
+    unsigned char* const Cs = lds + HALO_RING;           // [256 pixels][64 B], chunk-swizzled like the ring
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int bands = p.H / band;
+    const int b = blockIdx.x / bands, ys = (blockIdx.x - b * bands) * band, ye = ys + band;
+
+    const uint32_t nbytes = (uint32_t)((size_t)p.B * p.H * W_ * 64);
+    i32x4_t rsrc, rres;
+    {
+        const uint64_t base = (uint64_t)(uintptr_t)p.in, rb = (uint64_t)(uintptr_t)p.res;
+        rsrc.x = (int)(uint32_t)base; rsrc.y = (int)(uint32_t)(base >> 32); rsrc.z = (int)nbytes; rsrc.w = 0x00020000;
+        rres.x = (int)(uint32_t)rb; rres.y = (int)(uint32_t)(rb >> 32); rres.z = (int)nbytes; rres.w = 0x00020000;
+    }
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)lds;
+    // one lane's share of a row piece: pixel hx = 16 * piece + lane / 4 (image x = hx - 1), chunk by the swizzle
+    auto load_rows = [&](int y_first, int nrows) {       // image rows y_first .. y_first + nrows - 1 -> their ring slots
+        for (int pi = wave; pi < nrows * 9; pi += 8) {
+            const int row = pi / 9, piece = pi - row * 9;
+            const int y = y_first + row;
+            const int hx = piece * 16 + (lane >> 2), x = hx - 1;
+            const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)W_;
+            const int chunk = (lane & 3) ^ ((hx >> 1) & 3);
+            const uint32_t voff = ok ? (uint32_t)((b * p.H + y) * W_ + x) * 64u + (uint32_t)chunk * 16u : 0x80000000u;
+            dma16_buf(rsrc, voff, 0u, lds_base + (uint32_t)(((y + 1) % 6) * HALO_ROWB + piece * 1024));
+        }
+    };
+    // the residual rows of a step's outputs: every wave fetches the two pieces that hold ITS 32 pixels, so the whole
+    // epilogue is wave-local (no barrier between the residual's arrival, the in-place result and the row stores)
+    auto load_res = [&](int y0) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int px = wave * 32 + k * 16 + (lane >> 2);
+            const int chunk = (lane & 3) ^ ((px >> 1) & 3);
+            const uint32_t voff = (uint32_t)((b * p.H + y0) * W_ + px) * 64u + (uint32_t)chunk * 16u;
+            dma16_buf(rres, voff, 0u, lds_base + (uint32_t)(HALO_RING + (wave * 2 + k) * 1024));
+        }
+    };
+    load_rows(ys - 1, 4);
+    const bool has_res = p.res != nullptr;               // wave-uniform
+    if (has_res) load_res(ys);
+    // weights: lane (r, h) holds output channel r, channels 8h..8h+7 of each 16-channel half of each tap
+    bf16x8 bfr[9][2];
+    float4 bias4[4];
+    {
+        const uint16_t* wrow = p.w + (size_t)r * 288 + 8 * h;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                bfr[tap][ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wrow + tap * 32 + ks * 16));
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) bias4[qq] = *reinterpret_cast<const float4*>(p.bias + 8 * qq + 4 * h);
+    }
+    const int q = wave * 32 + r;                        // output pixel of the step
+    const int oy = wave >> 2, ox = q & (W_ - 1);        // waves 0-3: first output row, 4-7: second
+    const int swq = (q >> 1) & 3;
+    uint16_t* const out16 = reinterpret_cast<uint16_t*>(p.out);
+    for (int y0 = ys; y0 < ye; y0 += 2) {
+        // the rows of this step have landed: behind them in the queue are only the previous step's two row stores
+        // and (has_res) this step's two residual pieces
+        if (y0 == ys) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (has_res) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        __syncthreads();
+        const bool more = y0 + 2 < ye;
+        if (more) load_rows(y0 + 3, 2);
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int slot = (y0 + oy + ky) % 6;        // input row y0 - 1 + oy + ky
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int hx = ox + kx;
+                const int sw = (hx >> 1) & 3;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const bf16x8 af = __builtin_bit_cast(
+                        bf16x8, *reinterpret_cast<const uint4*>(lds + slot * HALO_ROWB + hx * 64 + (((2 * ks + h) ^ sw) << 4)));
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ky * 3 + kx][ks], af, acc, 0, 0, 0);
+                }
+            }
+        }
+        // residual landed? newer than it are only the row pieces just requested (3 for waves 0-1, 2 for the others)
+        if (has_res) {
+            if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (wave < 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        }
+        // acc[e]: channel 8*(e>>2) + 4*h + (e&3) of pixel q. bias + SiLU + residual, one rounding, in place in LDS
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            unsigned char* cell = Cs + q * 64 + ((qq ^ swq) << 4) + 8 * h;
+            float v0 = acc[4 * qq] + bias4[qq].x, v1 = acc[4 * qq + 1] + bias4[qq].y, v2 = acc[4 * qq + 2] + bias4[qq].z,
+                  v3 = acc[4 * qq + 3] + bias4[qq].w;
+            if (p.act) { v0 = silu_fast(v0); v1 = silu_fast(v1); v2 = silu_fast(v2); v3 = silu_fast(v3); }
+            if (has_res) {
+                const uint2 rr = *reinterpret_cast<const uint2*>(cell);
+                v0 += bf2f_((uint16_t)(rr.x & 0xffff)); v1 += bf2f_((uint16_t)(rr.x >> 16));
+                v2 += bf2f_((uint16_t)(rr.y & 0xffff)); v3 += bf2f_((uint16_t)(rr.y >> 16));
+            }
+            uint2 pk;
+            pk.x = (uint32_t)f2bf_(v0) | ((uint32_t)f2bf_(v1) << 16);
+            pk.y = (uint32_t)f2bf_(v2) | ((uint32_t)f2bf_(v3) << 16);
+            *reinterpret_cast<uint2*>(cell) = pk;
+        }
+        // the wave's 32 pixel rows (2 KiB contiguous in NHWC) as 16-byte pieces
+        const size_t m0 = (size_t)(b * p.H + y0) * W_;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int px = wave * 32 + k * 16 + (lane >> 2), cc = lane & 3;
+            const uint4 v = *reinterpret_cast<const uint4*>(Cs + px * 64 + cc * 16);
+            *reinterpret_cast<uint4*>(out16 + (m0 + px) * 32 + ((cc ^ ((px >> 1) & 3)) << 3)) = v;
+        }
+        if (more && has_res) load_res(y0 + 2);
+    }
+}
+
+// -------------------------------------------------------------------------------------------
 // Whole Fused-MBConv block in one launch: 3x3 expand + folded BN + SiLU -> (bf16) -> 1x1 project + folded BN
 // (+ residual). The expanded tensor E (4x the block's input, the largest tensors of the network: 537 MB per layer at
 // 64x64) never leaves the chip: a workgroup owns 128 pixels x ALL expanded channels, so after the 3x3 k loop the
@@ -1437,13 +1577,19 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
             else if (a.Cout == 32) v = 59;
             else v = 132;                              // 128 x 128
         } else if (g1 && a.gate && (ohw % 128 == 0 || 128 % ohw == 0)) {
-            if (a.Cout % 320 == 0) v = 144;            // 128 x 320
+            // the 8 x 8 stages: 128-row tiles leave at most one workgroup per CU (a half-batch lane: half the CUs);
+            // 64 x 192 tiles of 4 waves measured +14 % (384 outputs) and +41 % (640 outputs) at 8192 rows
+            const long wgs128 = (long)cdiv(a.M, 128) * cdiv(a.Cout, a.Cout % 320 == 0 ? 320 : 192);
+            if (ohw % 64 == 0 && a.Cout % 64 == 0 && ((a.Cout % 192 == 0 && wgs128 <= 256) || (a.Cout % 320 == 0 && wgs128 < 256))) v = 146;
+            else if (a.Cout % 320 == 0) v = 144;       // 128 x 320
             else if (a.Cout == 224) v = 143;           // 128 x 224
             else if (a.Cout % 192 == 0) v = 141;       // 128 x 192
             else v = 142;                              // 128 x 128
         } else if (!a.gate && a.KH == 3 && a.KW == 3 && ((a.stride == 1 && a.pad == 1) || (a.stride == 2 && a.pad == 0)) &&
                    (size_t)a.B * a.H * a.W * a.Cin * 2 + (size_t)(a.W + 1) * a.Cin * 2 < 0x7ffffff0ull) {
-            if (a.Cout == 32) v = 163;                // 256 x  32   (lean 3x3, buffer-addressed A operand)
+            if (a.Cout == 32 && a.Cin == 32 && a.stride == 1 && a.W == 128 && a.H % 2 == 0 && !a.out_f32)
+                v = 171;                              // rows ring in LDS, +50 % over the implicit GEMM (bit-identical)
+            else if (a.Cout == 32) v = 163;           // 256 x  32   (lean 3x3, buffer-addressed A operand)
             else if (a.Cout % 192 == 0) v = 161;      // 128 x 192
             else v = 162;                             // 128 x 128
         } else if (!a.gate && a.zeros) {
@@ -1651,6 +1797,25 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
         const dim3 g = conv_grid(aa, 32 * TM * WGM, 32 * TN * WGN);                                              \
         hipLaunchKernelGGL((conv3x3_dma_kernel<TM, TN, WGM, WGN>), g, dim3(64 * WGM * WGN), 0, st, aa);          \
     } while (0)
+        case 171: {                                          // 3x3 32 -> 32 on 128-wide images: rows ring in LDS
+            // rows per workgroup: long bands reuse the ring (each input row is copied once), but the launch should still
+            // offer two workgroups to every CU
+            int band = 2;
+            for (int cand = 32; cand > 2; cand >>= 1)
+                if (a.H % cand == 0 && (long)a.B * (a.H / cand) >= 512) { band = cand; break; }
+            if (a.gate || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Cin != 32 || a.Cout != 32 || a.W != 128 ||
+                a.H % 2 != 0 || a.out_f32 || (size_t)a.B * a.H * a.W * 64 >= 0x7ffffff0ull) {
+                set_error("conv_igemm: variant 171 is the 3x3 stride-1 32 -> 32 convolution on 128-wide images (< 2 GiB)");
+                return ISB_ERR_INVALID;
+            }
+            static bool attr_set = false;
+            if (!attr_set) {
+                ISB_HIP(hipFuncSetAttribute((const void*)conv3x3_c32_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, HALO_LDS));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(conv3x3_c32_rows_kernel, dim3(a.B * (a.H / band)), dim3(512), HALO_LDS, st, aa, band);
+            break;
+        }
         case 161: ISB_CONV_LAUNCH_C3(1, 3, 4, 2); break;   // 128 x 192
         case 162: ISB_CONV_LAUNCH_C3(1, 2, 4, 2); break;   // 128 x 128
         case 163: ISB_CONV_LAUNCH_C3(1, 1, 8, 1); break;   // 256 x  32

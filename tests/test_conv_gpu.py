@@ -87,6 +87,34 @@ def test_conv_variants(case, variant):
     assert ms >= 0
 
 
+@pytest.mark.parametrize("B,H,act,use_res", [(1, 128, 1, True), (3, 128, 1, False), (2, 6, 0, True)])
+def test_conv_halo_c32(B, H, act, use_res):
+    """3x3 32 -> 32 on 128-wide images from an LDS halo tile (variant 171): against the torch reference and, bit for
+    bit, against the implicit-GEMM kernel (variant 163) -- same (tap, channel) summation order."""
+    rng = np.random.default_rng(1000 * B + H)
+    x = rng.normal(0, 1, (B, H, 128, 32)).astype(np.float32)
+    w = (rng.normal(0, 1, (32, 3, 3, 32)) / np.sqrt(288)).astype(np.float32)
+    scale = rng.uniform(0.8, 1.2, 32).astype(np.float32)
+    shift = rng.uniform(-0.1, 0.1, 32).astype(np.float32)
+    res = rng.normal(0, 1, (B, H, 128, 32)).astype(np.float32) if use_res else None
+    r16 = None if res is None else f32_to_bf16(res)
+    out, _ = conv_debug(f32_to_bf16(x), w, scale, shift, 3, 1, act, r16, None, variant=171)
+    old, _ = conv_debug(f32_to_bf16(x), w, scale, shift, 3, 1, act, r16, None, variant=163)
+    assert np.array_equal(out, old)
+    xb = torch.from_numpy(bf16_to_f32(f32_to_bf16(x))).permute(0, 3, 1, 2)
+    wf = (torch.from_numpy(w) * torch.from_numpy(scale).view(-1, 1, 1, 1)).bfloat16().float().permute(0, 3, 1, 2)
+    y = F.conv2d(xb, wf, padding=1) + torch.from_numpy(shift).view(1, -1, 1, 1)
+    if act:
+        y = y * torch.sigmoid(y)
+    y = y.permute(0, 2, 3, 1)
+    if res is not None:
+        y = y + torch.from_numpy(bf16_to_f32(r16))
+    ref = y.bfloat16().float().numpy()
+    got = bf16_to_f32(out)
+    tol = 2.0 ** -7 * np.maximum(1.0, np.abs(ref))
+    assert np.all(np.abs(got - ref) <= tol), float(np.abs(got - ref).max())
+
+
 SPLITK_CASES = [
     # B, H, Cin, Cout, act, res, gate, splits, tile variant
     (1, 8, 2304, 384, 0, True, True, 12, 147),     # stage-6 projection of one frame
