@@ -166,6 +166,11 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     W = pick_workload(args.workload)(args, rank, world, local)
+    # set-up, not measurement: the first calls allocate the per-lane activation workspaces and load the code objects
+    # (and, for N > 1, establish the RCCL rings); the W warm-up steps the caller asked for follow
+    for _ in range(2):
+        W.step()
+    torch.cuda.synchronize()
 
     def barrier():
         if world > 1:
