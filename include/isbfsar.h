@@ -164,6 +164,13 @@ int isb_hpe_select_person_host(isb_hpe* h, const float* h_boxes, const float* h_
  *                                                              head logits f32 [B,8,8,288] (may be NULL)
  *   post        : hpe.py:109-169                     head logits + bbox -> joints, valid,
  *                                                    optional pred f64 [B,32,5] = pred2d(x,y), pred3d(x,y,z) */
+/* Test-time augmentation as far as the reference executes it (hpe.py:88-100, MetrabsTRTConfig.num_aug, params.py:36):
+ * each box yields n_aug parameter sets, new_K[k][:2,:2] *= scales[k] and homo_inv[k] = rotflip[k] @ homo_inv, and
+ * n_aug crops. The tables are what misc.py:312-327 (get_augmentations) returns: rotflip f64 [n_aug,3,3], scales f64
+ * [n_aug]; n_aug = 0 switches it off. With augmentation on, isb_hpe_crop_params_host / isb_hpe_warp_host return
+ * B x n_aug items ([B][n_aug] order) and the full forward is refused (ISB_ERR_STATE): the reference's decode reshapes
+ * the head output to ONE sample (hpe.py:108), so nothing downstream of the crops is defined there. */
+int isb_hpe_set_augmentations(isb_hpe* h, int32_t n_aug, const double* h_rotflip, const double* h_scales);
 int isb_hpe_crop_params_host(isb_hpe* h, const int32_t* h_bbox, int32_t B, float* h_H, double* h_newK, double* h_R);
 int isb_hpe_warp_host(isb_hpe* h, const uint8_t* h_frames, const int32_t* h_bbox, int32_t B, float* h_crops);
 int isb_hpe_backbone_host(isb_hpe* h, const float* h_crops, int32_t B, float* h_features, float* h_logits);

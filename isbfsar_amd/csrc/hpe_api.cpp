@@ -69,6 +69,9 @@ struct isb_hpe {
     DevBuf head_w, head_b;
     DevBuf expand, indices;
     bool has_indices = false;
+    // test-time augmentation tables (hpe.py:88-93); n_aug = 0: off
+    int n_aug = 0;
+    DevBuf aug_rotflip, aug_scale;
     // workspace
     DevBuf zeros;
     Lane lanes[kMaxLanes];
@@ -314,14 +317,18 @@ int run_crop_params(isb_hpe* h, Lane& L, hipStream_t st, const int32_t* d_bbox, 
     CropParamArgs a{};
     a.bbox = d_bbox;
     for (int i = 0; i < 9; ++i) a.K[i] = h->K[i];
-    a.H = L.H.as<float>(); a.newK = L.newK.as<double>(); a.R = L.R.as<double>(); a.B = B;
+    a.H = L.H.as<float>(); a.newK = L.newK.as<double>(); a.R = L.R.as<double>();
+    a.n_aug = h->n_aug; a.aug_rotflip = h->aug_rotflip.as<double>(); a.aug_scale = h->aug_scale.as<double>();
+    a.B = B * std::max(h->n_aug, 1);        // B boxes -> B x n_aug parameter sets
     return launch_crop_params(a, st);
 }
 
 int run_warp(isb_hpe* h, Lane& L, hipStream_t st, const uint8_t* d_frames, int B) {
     WarpArgs a{};
     a.frames = d_frames; a.H = L.H.as<float>(); a.crops = L.crops.as<float>();
-    a.B = B; a.FH = h->cfg.height; a.FW = h->cfg.width;
+    a.n_aug = std::max(h->n_aug, 1);
+    a.B = B * a.n_aug;                      // B frames -> B x n_aug crops
+    a.FH = h->cfg.height; a.FW = h->cfg.width;
     return launch_warp(a, st);
 }
 
@@ -490,11 +497,29 @@ extern "C" int isb_hpe_set_joint_map(isb_hpe* h, const float* expand, const int3
     });
 }
 
+extern "C" int isb_hpe_set_augmentations(isb_hpe* h, int32_t n_aug, const double* rotflip, const double* scales) {
+    return isb::guard([&]() -> int {
+    ISB_REQUIRE(h, ISB_ERR_INVALID, "null handle");
+    ISB_REQUIRE(n_aug >= 0 && n_aug <= 64, ISB_ERR_INVALID, "n_aug %d outside [0,64]", n_aug);
+    ISB_REQUIRE(n_aug == 0 || (rotflip && scales), ISB_ERR_INVALID, "augmentation tables missing");
+    ISB_HIP(hipSetDevice(h->cfg.device));
+    if (n_aug > 0) {
+        ISB_TRY(upload(h->aug_rotflip, rotflip, (size_t)n_aug * 72));
+        ISB_TRY(upload(h->aug_scale, scales, (size_t)n_aug * 8));
+    }
+    h->n_aug = n_aug;
+    return ISB_OK;
+    });
+}
+
 extern "C" int isb_hpe_forward(isb_hpe* h, const uint8_t* d_frames, const int32_t* d_bbox, int32_t B, float* d_joints,
                                uint8_t* d_valid, void* stream) {
     return isb::guard([&]() -> int {
     ISB_REQUIRE(h && d_frames && d_bbox && d_joints && d_valid, ISB_ERR_INVALID, "null argument");
     ISB_REQUIRE(B >= 1, ISB_ERR_INVALID, "batch %d < 1", B);
+    ISB_REQUIRE(h->n_aug == 0, ISB_ERR_STATE,
+                "test-time augmentation is on: the reference defines it up to the augmented crops only (hpe.py:88-100; its "
+                "decode reshapes to one sample, hpe.py:108) -- use the crop_params / warp / backbone stages");
     ISB_REQUIRE(h->weights && h->jointmap, ISB_ERR_STATE, "isb_hpe_forward needs weights and a joint map");
     ISB_HIP(hipSetDevice(h->cfg.device));
     hipStream_t st = (hipStream_t)stream;   // NULL = the HIP null stream (torch's default stream)
@@ -540,6 +565,7 @@ extern "C" int isb_hpe_forward_host(isb_hpe* h, const uint8_t* frames, const int
     return isb::guard([&]() -> int {
     ISB_REQUIRE(h && frames && bbox && joints && valid, ISB_ERR_INVALID, "null argument");
     ISB_REQUIRE(B >= 1, ISB_ERR_INVALID, "batch %d < 1", B);
+    ISB_REQUIRE(h->n_aug == 0, ISB_ERR_STATE, "test-time augmentation is on: the reference defines it up to the augmented crops only (hpe.py:88-100)");
     ISB_REQUIRE(h->weights && h->jointmap, ISB_ERR_STATE, "isb_hpe_forward_host needs weights and a joint map");
     ISB_HIP(hipSetDevice(h->cfg.device));
     hipStream_t st = h->own_stream;
@@ -566,15 +592,16 @@ extern "C" int isb_hpe_crop_params_host(isb_hpe* h, const int32_t* bbox, int32_t
     ISB_HIP(hipSetDevice(h->cfg.device));
     hipStream_t st = h->own_stream;
     Lane& L = h->lanes[0];
-    ISB_TRY(ensure_ws(L, std::min<int>(B, h->cfg.max_batch)));
-    ISB_REQUIRE(B <= L.ws_B, ISB_ERR_INVALID, "B %d exceeds max_batch %d", B, h->cfg.max_batch);
+    const int n = B * std::max(h->n_aug, 1);           // parameter sets: [B][n_aug]
+    ISB_REQUIRE(n <= h->cfg.max_batch, ISB_ERR_INVALID, "B x n_aug = %d exceeds max_batch %d", n, h->cfg.max_batch);
+    ISB_TRY(ensure_ws(L, n));
     DevBuf db;
     ISB_TRY(upload(db, bbox, (size_t)B * 16));
     ISB_TRY(run_crop_params(h, L, st, db.as<int32_t>(), B));
     ISB_HIP(hipStreamSynchronize(st));
-    ISB_HIP(hipMemcpy(H, L.H.p, (size_t)B * 36, hipMemcpyDeviceToHost));
-    ISB_HIP(hipMemcpy(newK, L.newK.p, (size_t)B * 72, hipMemcpyDeviceToHost));
-    ISB_HIP(hipMemcpy(R, L.R.p, (size_t)B * 72, hipMemcpyDeviceToHost));
+    ISB_HIP(hipMemcpy(H, L.H.p, (size_t)n * 36, hipMemcpyDeviceToHost));
+    ISB_HIP(hipMemcpy(newK, L.newK.p, (size_t)n * 72, hipMemcpyDeviceToHost));
+    ISB_HIP(hipMemcpy(R, L.R.p, (size_t)n * 72, hipMemcpyDeviceToHost));
     return ISB_OK;
     });
 }
@@ -585,8 +612,9 @@ extern "C" int isb_hpe_warp_host(isb_hpe* h, const uint8_t* frames, const int32_
     ISB_HIP(hipSetDevice(h->cfg.device));
     hipStream_t st = h->own_stream;
     Lane& L = h->lanes[0];
-    ISB_TRY(ensure_ws(L, std::min<int>(B, h->cfg.max_batch)));
-    ISB_REQUIRE(B <= L.ws_B, ISB_ERR_INVALID, "B %d exceeds max_batch %d", B, h->cfg.max_batch);
+    const int n = B * std::max(h->n_aug, 1);           // crops: [B][n_aug]
+    ISB_REQUIRE(n <= h->cfg.max_batch, ISB_ERR_INVALID, "B x n_aug = %d exceeds max_batch %d", n, h->cfg.max_batch);
+    ISB_TRY(ensure_ws(L, n));
     const size_t fsz = (size_t)h->cfg.height * h->cfg.width * 3;
     DevBuf df, db;
     ISB_TRY(upload(df, frames, fsz * B));
@@ -594,7 +622,7 @@ extern "C" int isb_hpe_warp_host(isb_hpe* h, const uint8_t* frames, const int32_
     ISB_TRY(run_crop_params(h, L, st, db.as<int32_t>(), B));
     ISB_TRY(run_warp(h, L, st, df.as<uint8_t>(), B));
     ISB_HIP(hipStreamSynchronize(st));
-    ISB_HIP(hipMemcpy(crops, L.crops.p, (size_t)B * 256 * 256 * 3 * 4, hipMemcpyDeviceToHost));
+    ISB_HIP(hipMemcpy(crops, L.crops.p, (size_t)n * 256 * 256 * 3 * 4, hipMemcpyDeviceToHost));
     return ISB_OK;
     });
 }
@@ -622,6 +650,7 @@ extern "C" int isb_hpe_post_host(isb_hpe* h, const float* logits, const int32_t*
     return isb::guard([&]() -> int {
     ISB_REQUIRE(h && logits && bbox && joints && valid && B >= 1, ISB_ERR_INVALID, "bad argument");
     ISB_REQUIRE(h->jointmap, ISB_ERR_STATE, "isb_hpe_post_host before isb_hpe_set_joint_map");
+    ISB_REQUIRE(h->n_aug == 0, ISB_ERR_STATE, "test-time augmentation is on: the reference's decode takes one sample (hpe.py:108)");
     ISB_HIP(hipSetDevice(h->cfg.device));
     hipStream_t st = h->own_stream;
     Lane& L = h->lanes[0];

@@ -33,9 +33,10 @@ __device__ __forceinline__ void mat3_inv(const double* m, double* o) {
 __global__ void crop_params_kernel(CropParamArgs p) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= p.B) return;
-    const bool nobox = p.bbox[4 * b] < 0;               // select_person found nobody: keep the math finite
-    const double x1 = nobox ? 0 : p.bbox[4 * b + 0], x2 = nobox ? 1 : p.bbox[4 * b + 1];
-    const double y1 = nobox ? 0 : p.bbox[4 * b + 2], y2 = nobox ? 1 : p.bbox[4 * b + 3];
+    const int box = p.n_aug > 0 ? b / p.n_aug : b, aug = p.n_aug > 0 ? b - box * p.n_aug : 0;
+    const bool nobox = p.bbox[4 * box] < 0;             // select_person found nobody: keep the math finite
+    const double x1 = nobox ? 0 : p.bbox[4 * box + 0], x2 = nobox ? 1 : p.bbox[4 * box + 1];
+    const double y1 = nobox ? 0 : p.bbox[4 * box + 2], y2 = nobox ? 1 : p.bbox[4 * box + 3];
     const double* K = p.K;
     // numpy inverts the float32 K in float32 (one correctly rounded division per entry)
     const float fx = (float)K[0], fy = (float)K[4], cx = (float)K[2], cy = (float)K[5];
@@ -59,9 +60,9 @@ __global__ void crop_params_kernel(CropParamArgs p) {
     if (xn == 0.0) { x[0] = z[2]; x[1] = 0.0; x[2] = -z[0]; xn = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]); }
     x[0] /= xn; x[1] /= xn; x[2] /= xn;
     const double y[3] = {z[1] * x[2] - z[2] * x[1], z[2] * x[0] - z[0] * x[2], z[0] * x[1] - z[1] * x[0]};
-    const double R[9] = {x[0], x[1], x[2], y[0], y[1], y[2], z[0], z[1], z[2]};
+    const double R0[9] = {x[0], x[1], x[2], y[0], y[1], y[2], z[0], z[1], z[2]};
     double KR[9];
-    mat3_mul(K, R, KR);
+    mat3_mul(K, R0, KR);
     double pr[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -74,7 +75,16 @@ __global__ void crop_params_kernel(CropParamArgs p) {
     const double vs = sqrt((pr[0][0] - pr[2][0]) * (pr[0][0] - pr[2][0]) + (pr[0][1] - pr[2][1]) * (pr[0][1] - pr[2][1]));
     const double hs = sqrt((pr[1][0] - pr[3][0]) * (pr[1][0] - pr[3][0]) + (pr[1][1] - pr[3][1]) * (pr[1][1] - pr[3][1]));
     const double scale = 256.0 / fmax(vs, hs);
-    const double nK[9] = {K[0] * scale, K[1] * scale, 128.0, K[3] * scale, K[4] * scale, 128.0, 0.0, 0.0, 1.0};
+    double nK[9] = {K[0] * scale, K[1] * scale, 128.0, K[3] * scale, K[4] * scale, 128.0, 0.0, 0.0, 1.0};
+    double R[9];
+    if (p.n_aug > 0) {                                  // hpe.py:88-93
+        const double s = p.aug_scale[aug];
+        nK[0] *= s; nK[1] *= s; nK[3] *= s; nK[4] *= s;
+        mat3_mul(p.aug_rotflip + 9 * aug, R0, R);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) R[i] = R0[i];
+    }
     double M[9], Mi[9], H[9];
     mat3_mul(nK, R, M);
     mat3_inv(M, Mi);
@@ -98,6 +108,7 @@ int launch_crop_params(const CropParamArgs& a, hipStream_t st) {
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void warp_kernel(WarpArgs p) {
     const int b = blockIdx.y;
+    const int fb = p.n_aug > 1 ? b / p.n_aug : b;        // source frame
     const int pix = blockIdx.x * 256 + threadIdx.x;      // 0..65535
     const int y = pix >> 8, x = pix & 255;
     const float* H = p.H + 9 * b;
@@ -114,7 +125,7 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs p) {
     const int xi = finite ? (int)xs : -1, yi = finite ? (int)ys : -1;
     float o0 = 0.f, o1 = 0.f, o2 = 0.f;
     if (xi >= 0 && xi < p.FW && yi >= 0 && yi < p.FH) {
-        const uint8_t* s = p.frames + (((size_t)b * p.FH + yi) * p.FW + xi) * 3;
+        const uint8_t* s = p.frames + (((size_t)fb * p.FH + yi) * p.FW + xi) * 3;
         o0 = (float)((double)s[0] / 255.0);                // hpe.py:100 (int / 255.0 in f64, cast to f32)
         o1 = (float)((double)s[1] / 255.0);
         o2 = (float)((double)s[2] / 255.0);

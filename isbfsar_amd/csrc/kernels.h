@@ -204,7 +204,11 @@ struct CropParamArgs {
     float* H;               // out [B,9]  f32 homography, hpe.py:96-97
     double* newK;           // out [B,9]
     double* R;              // out [B,9]
-    int B;
+    int B;                  // outputs = boxes x max(n_aug, 1); output i uses box i / n_aug and augmentation i % n_aug
+    // test-time augmentation (hpe.py:88-93): new_K[k][:2,:2] *= scale[k]; homo_inv[k] = rotflip[k] @ homo_inv
+    int n_aug;              // 0 = off
+    const double* aug_rotflip;   // [n_aug,9]
+    const double* aug_scale;     // [n_aug]
 };
 int launch_crop_params(const CropParamArgs& a, hipStream_t st);
 
@@ -213,6 +217,7 @@ struct WarpArgs {
     const float* H;         // [B,9]
     float* crops;           // out [B,256,256,3] f32 in [0,1]
     int B, FH, FW;
+    int n_aug;              // > 1: crop i is cut from frame i / n_aug (test-time augmentation)
 };
 int launch_warp(const WarpArgs& a, hipStream_t st);
 

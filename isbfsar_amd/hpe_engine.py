@@ -84,13 +84,27 @@ class HpeEngine:
         return joints, valid
 
     # -- stage-level hooks ----------------------------------------------------------------
+    def set_augmentations(self, num_aug: int):
+        """Test-time augmentation (MetrabsTRTConfig.num_aug, hpe.py:88-93): crop_params / warp then return num_aug
+        items per box, [B * num_aug, ...] in (box, augmentation) order. 0 switches it off."""
+        self.num_aug = int(num_aug)
+        if self.num_aug <= 0:
+            self.num_aug = 0
+            _lib.check(_lib.lib().isb_hpe_set_augmentations(self._h, 0, None, None), "isb_hpe_set_augmentations")
+            return None
+        flip, rotflip, gammas, scales = get_augmentations(self.num_aug)
+        rf = np.ascontiguousarray(rotflip, dtype=np.float64)
+        sc = np.ascontiguousarray(scales, dtype=np.float64)
+        _lib.check(_lib.lib().isb_hpe_set_augmentations(self._h, self.num_aug, _ptr(rf), _ptr(sc)), "isb_hpe_set_augmentations")
+        return flip, rotflip, gammas, scales
+
     def crop_params(self, bboxes):
         bb = np.ascontiguousarray(bboxes, dtype=np.int32)
-        B = bb.shape[0]
+        B = bb.shape[0] * max(getattr(self, "num_aug", 0), 1)
         H = np.empty((B, 3, 3), np.float32)
         newK = np.empty((B, 3, 3), np.float64)
         R = np.empty((B, 3, 3), np.float64)
-        _lib.check(_lib.lib().isb_hpe_crop_params_host(self._h, _ptr(bb), B, _ptr(H), _ptr(newK), _ptr(R)),
+        _lib.check(_lib.lib().isb_hpe_crop_params_host(self._h, _ptr(bb), bb.shape[0], _ptr(H), _ptr(newK), _ptr(R)),
                    "isb_hpe_crop_params_host")
         return H, newK, R
 
@@ -98,7 +112,7 @@ class HpeEngine:
         f = np.ascontiguousarray(frames, dtype=np.uint8)
         bb = np.ascontiguousarray(bboxes, dtype=np.int32)
         B = f.shape[0]
-        crops = np.empty((B, 256, 256, 3), np.float32)
+        crops = np.empty((B * max(getattr(self, "num_aug", 0), 1), 256, 256, 3), np.float32)
         _lib.check(_lib.lib().isb_hpe_warp_host(self._h, _ptr(f), _ptr(bb), B, _ptr(crops)), "isb_hpe_warp_host")
         return crops
 
@@ -221,6 +235,26 @@ def expand_dw_debug(x_bf16, w1, scale1, shift1, dww, dwscale, dwshift, iters=1, 
                                               _ptr(f(dwscale)), _ptr(f(dwshift)), B, HW, Cin, Cexp, iters, _ptr(out), _ptr(pooled),
                                               C.byref(ms)), "isb_debug_expand_dw")
     return out, pooled, ms.value
+
+
+def get_augmentations(num_aug: int, rot_aug_linspace_noend: bool = True):
+    """Host-side mirror of the reference's test-time augmentation tables (modules/hpe/utils/misc.py:312-327): returns
+    (should_flip bool[n], rotflip f64[n,3,3], gammas[n], scales[n]). Rotations about the optical axis spread over
+    +-25 degrees (the end point left out by default), zoom 0.8..1.0 then 1.0..1.1, every other augmentation around the
+    middle one mirrored in x. Same numpy calls, hence the same dtypes and roundings, as the reference's."""
+    gammas = np.linspace(0.6, 1.0, num_aug)
+    half_range = np.float32(np.deg2rad(25))
+    n_angles = num_aug + 1 if rot_aug_linspace_noend else num_aug
+    angles = np.linspace(-half_range, half_range, n_angles)[:num_aug]
+    scales = np.concatenate([np.linspace(0.8, 1.0, (num_aug + 1) // 2)[:-1],
+                             np.linspace(1.0, 1.1, num_aug - num_aug // 2)], axis=0)
+    should_flip = (np.arange(num_aug) - num_aug // 2) % 2 != 0
+    mirror_x = np.array([[-1, 0, 0], [0, 1, 0], [0, 0, 1]], dtype=np.float32)
+    maybe_mirror = np.where(should_flip[:, None, None], mirror_x, np.eye(3))
+    a = -angles
+    s, c, z, o = np.sin(a), np.cos(a), np.zeros_like(a), np.ones_like(a)
+    rot = np.stack([np.stack([c, -s, z], axis=-1), np.stack([s, c, z], axis=-1), np.stack([z, z, o], axis=-1)], axis=-2)
+    return should_flip, maybe_mirror @ rot, gammas, scales
 
 
 def pose_windows(joints, seq_len: int):

@@ -244,6 +244,68 @@ def gen_all(out_dir: str):
     print("hpe goldens written")
 
 
+def gen_tta(out_dir: str, num_aug: int = 5):
+    """G9: test-time augmentation as far as the reference executes it. estimate() is run with num_aug = 5 (n_test = 5,
+    ImageTransformer(5, 480, 640)); the FakeRunner records the H matrices and the warped crops it is handed
+    (hpe.py:88-100). What follows in estimate() reshapes the head output to one sample (hpe.py:108) and is not defined
+    for five crops: whatever it does with the fake one-sample logits is ignored here."""
+    import torch
+    spec = importlib.util.spec_from_file_location(
+        "ref_img_tf5", os.path.join(REF, "modules/hpe/setup/6_create_image_transformation_onnx.py"))
+    mod = importlib.util.module_from_spec(spec)
+    orig = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        spec.loader.exec_module(mod)
+        tf5 = mod.ImageTransformer(num_aug, 480, 640)
+    finally:
+        torch.Tensor.cuda = orig
+    FakeRunner.state["tf"] = tf5
+    est = reference_estimator("smpl+head_30")
+    est.num_aug = num_aug
+    est.n_test = num_aug
+    from modules.hpe.utils.misc import get_augmentations as ref_aug, homography as ref_homography
+    flip, rotflip, gammas, scales = ref_aug(num_aug)
+    flat = {"num_aug": num_aug, "aug_should_flip": flip, "aug_rotflip": rotflip, "aug_gammas": gammas, "aug_scales": scales,
+            "aug_rotflip_dtype": str(rotflip.dtype), "aug_scales_dtype": str(scales.dtype)}
+    boxes = [BBOXES[2], BBOXES[3], BBOXES[0]]
+    for i, bbox in enumerate(boxes):
+        frame = np.random.default_rng(100 + i).integers(0, 256, (480, 640, 3), dtype=np.uint8)
+        st = FakeRunner.state
+        st["bbox"] = bbox
+        st["head_logits"] = head_logits_case(i, "gauss")
+        st.pop("H", None)
+        try:
+            est.estimate(frame)
+            after = "returned"
+        except Exception as e:                      # the one-sample decode / reconstruction of five crops
+            after = f"{type(e).__name__}: {e}"
+        H = np.asarray(st["H"], np.float32).reshape(num_aug, 3, 3)
+        wi = st["warp_int"].astype(np.uint8)        # [5,256,256,3]
+        # the same quantities through the reference's functions (hpe.py:85-96 spelled out)
+        new_K, homo_inv = ref_homography(*bbox, est.K, 256)
+        nk = np.tile(new_K, (num_aug, 1, 1))
+        for k in range(num_aug):
+            nk[k, :2, :2] *= scales[k]
+        hi = rotflip @ np.tile(homo_inv[0], (num_aug, 1, 1))
+        H2 = (est.K @ np.linalg.inv(nk @ hi)).astype(np.float32)
+        assert np.array_equal(H, H2), "estimate() and the spelled-out lines disagree"
+        flat.update({f"t{i}_bbox": np.array(bbox, np.int32), f"t{i}_frame_seed": 100 + i, f"t{i}_H": H, f"t{i}_new_K": nk,
+                     f"t{i}_homo_inv": hi, f"t{i}_after_warp": after,
+                     f"t{i}_warp_digest": np.array([digest(wi[k]) for k in range(num_aug)]),
+                     f"t{i}_warp_patch": wi[:, 96:160:2, 96:160:2].copy(),
+                     f"t{i}_warp_nonzero": np.array([int((wi[k] != 0).any(axis=-1).sum()) for k in range(num_aug)]),
+                     f"t{i}_bbone_in_digest": digest(np.asarray(st["bbone_in"], np.float32))})
+        print(f"tta case {i}: bbox={bbox} H[0,0]={H[0, 0]} after warp: {after[:80]}")
+    flat["n_cases"] = len(boxes)
+    np.savez_compressed(os.path.join(out_dir, "hpe_tta.npz"), **flat)
+    print("tta goldens written")
+
+
 if __name__ == "__main__":
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
-    gen_all(os.path.join(ROOT, "tests", "golden"))
+    if len(sys.argv) > 1 and sys.argv[1] == "tta":
+        gen_tta(os.path.join(ROOT, "tests", "golden"))
+    else:
+        gen_all(os.path.join(ROOT, "tests", "golden"))
+        gen_tta(os.path.join(ROOT, "tests", "golden"))

@@ -79,6 +79,54 @@ def test_warp_bit_exact_vs_reference(eng, g):
         np.testing.assert_array_equal(u8[0, :32, :32], g[f"c{i}_warp_patch"])
 
 
+def test_tta_crop_params_and_warp_match_reference(golden_dir):
+    """num_aug = 5 (hpe.py:88-100): five parameter sets and five crops per box, against what the reference's own
+    estimate() computed (tests/golden/hpe_tta.npz) and, for a batch of boxes, against the oracle; the full forward is
+    refused because the reference defines nothing past the crops."""
+    from isbfsar_amd.hpe_engine import HpeEngine
+    from oracle import hpe_oracle as ho
+    t = np.load(os.path.join(golden_dir, "hpe_tta.npz"))
+    n = int(t["num_aug"])
+    e = HpeEngine(device=0, max_batch=32)
+    try:
+        e.set_augmentations(n)
+        for i in range(int(t["n_cases"])):
+            bb = t[f"t{i}_bbox"][None]
+            H, newK, R = e.crop_params(bb)
+            assert H.shape == (n, 3, 3)
+            np.testing.assert_allclose(H, t[f"t{i}_H"], rtol=2e-7, atol=1e-9)
+            np.testing.assert_allclose(newK, t[f"t{i}_new_K"], rtol=1e-13, atol=1e-9)
+            np.testing.assert_allclose(R, t[f"t{i}_homo_inv"], rtol=0, atol=1e-12)
+            frame = np.random.default_rng(int(t[f"t{i}_frame_seed"])).integers(0, 256, (480, 640, 3), dtype=np.uint8)
+            crops = e.warp(frame[None], bb)
+            assert crops.shape == (n, 256, 256, 3)
+            u8 = np.rint(crops * 255.0).astype(np.uint8)
+            if np.array_equal(H, t[f"t{i}_H"]):            # same f32 matrices -> the same pixels, bit for bit
+                assert _digest(crops) == str(t[f"t{i}_bbone_in_digest"])
+                for k in range(n):
+                    assert _digest(u8[k]) == str(t[f"t{i}_warp_digest"][k])
+            np.testing.assert_array_equal(u8[:, 96:160:2, 96:160:2], t[f"t{i}_warp_patch"])
+        # a batch of boxes: (box, augmentation) order, each against the oracle
+        fr = synth.frames(4, seed=77)
+        bb = synth.bboxes(4, seed=77)
+        H, newK, R = e.crop_params(bb)
+        crops = e.warp(fr, bb)
+        n_diff = 0
+        for b in range(4):
+            nk, hi, h = ho.crop_params_aug(bb[b], _K(), n)
+            np.testing.assert_allclose(H[b * n:(b + 1) * n], h, rtol=2e-7, atol=1e-9)
+            np.testing.assert_allclose(R[b * n:(b + 1) * n], hi, rtol=0, atol=1e-12)
+            for k in range(n):
+                n_diff += int((crops[b * n + k] != ho.warp(fr[b], H[b * n + k])).any(axis=-1).sum())
+        assert n_diff == 0                                 # the warp of the engine's own H matrices is exact
+        with pytest.raises(Exception, match="augmentation"):
+            e.forward(fr, bb)
+        e.set_augmentations(0)
+        assert e.crop_params(bb)[0].shape == (4, 3, 3)
+    finally:
+        e.close()
+
+
 def test_warp_batch_vs_oracle(eng):
     from oracle import hpe_oracle as ho
     fr = synth.frames(8, seed=40)

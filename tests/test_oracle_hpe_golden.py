@@ -57,6 +57,36 @@ def test_warp_bit_exact(g):
         np.testing.assert_array_equal(u8[112:144, 112:144], g[f"c{i}_warp_center"])
 
 
+def test_tta_tables_and_crops(golden_dir):
+    """Test-time augmentation (hpe.py:88-100, misc.py:312-327) as far as the reference executes it: the tables of
+    get_augmentations, per-augmentation new_K / homo_inv / H and the five warped crops the reference's own
+    estimate() produced with num_aug = 5 (tests/golden/hpe_tta.npz, oracle/gen_golden_hpe.py::gen_tta). The oracle
+    restatement AND the product's host-side mirror of the tables are pinned to them."""
+    from isbfsar_amd.hpe_engine import get_augmentations as product_aug
+    t = np.load(os.path.join(golden_dir, "hpe_tta.npz"))
+    n = int(t["num_aug"])
+    for fn in (ho.get_augmentations, product_aug):
+        flip, rotflip, gammas, scales = fn(n)
+        np.testing.assert_array_equal(flip, t["aug_should_flip"])
+        np.testing.assert_array_equal(rotflip, t["aug_rotflip"])
+        np.testing.assert_array_equal(gammas, t["aug_gammas"])
+        np.testing.assert_array_equal(scales, t["aug_scales"])
+        assert str(rotflip.dtype) == str(t["aug_rotflip_dtype"])
+    for i in range(int(t["n_cases"])):
+        new_K, homo_inv, H = ho.crop_params_aug(t[f"t{i}_bbox"], K, n)
+        np.testing.assert_array_equal(H, t[f"t{i}_H"])
+        np.testing.assert_allclose(new_K, t[f"t{i}_new_K"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(homo_inv, t[f"t{i}_homo_inv"], rtol=0, atol=1e-12)
+        frame = np.random.default_rng(int(t[f"t{i}_frame_seed"])).integers(0, 256, (480, 640, 3), dtype=np.uint8)
+        crops = np.stack([ho.warp(frame, H[k]) for k in range(n)])
+        assert _digest(crops) == str(t[f"t{i}_bbone_in_digest"])               # what the backbone engine was handed
+        u8 = np.rint(crops * 255.0).astype(np.uint8)
+        for k in range(n):
+            assert _digest(u8[k]) == str(t[f"t{i}_warp_digest"][k])
+        np.testing.assert_array_equal(u8[:, 96:160:2, 96:160:2], t[f"t{i}_warp_patch"])
+        assert "Error" in str(t[f"t{i}_after_warp"])       # the reference itself cannot go past the crops (hpe.py:108)
+
+
 def test_postprocess_matches_estimate(g, assets):
     W, st = assets
     n_valid = 0
