@@ -29,9 +29,7 @@ class HumanPoseEstimator:
         self.yolo_thresh = model_config.yolo_thresh
         self.nms_thresh = model_config.nms_thresh
         self.num_aug = model_config.num_aug
-        if self.num_aug > 0:
-            raise NotImplementedError("test-time augmentation (num_aug>0, hpe.py:88-93) is a 'next' row (SURVEY.md 8f)")
-        self.n_test = 1
+        self.n_test = 1 if self.num_aug < 1 else self.num_aug     # hpe.py:25
 
         # Intrinsics and K matrix of RealSense (hpe.py:28-33)
         self.K = np.zeros((3, 3), np.float32)
@@ -62,6 +60,10 @@ class HumanPoseEstimator:
                 w = effnetv2.make_state(getattr(model_config, "weights_seed", 0))
             self.engine.load_weights(w)
             self.engine.set_joint_map(self.expand_joints, indices)
+            if self.num_aug > 0:
+                # hpe.py:88-100: n_test crops per frame (engine.crop_params / engine.warp). estimate() then raises like
+                # the reference's does -- its decode takes one sample (hpe.py:108) -- with the library's explanation
+                self.engine.set_augmentations(self.num_aug)
 
     def _bbox(self, frame):
         if self.detector is not None:                     # hpe.py:59-73, post-processing on the GPU

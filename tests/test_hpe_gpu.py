@@ -418,3 +418,12 @@ def test_human_pose_estimator_dropin(bbone_state, assets):
     assert r2 is not None and r2["bbox"] == (269, 459, 280, 455)
     nodet = HumanPoseEstimator(cfg, RealSenseIntrinsics(), detector=lambda f: (boxes[3:4], confs[3:4]))
     assert nodet.estimate(frame) is None
+    # num_aug > 0 (params.py:36 disables it): the constructor succeeds like the reference's, the augmented crops are
+    # available stage by stage, and estimate() raises like the reference's (hpe.py:108) -- with an explanation
+    cfg.num_aug = 5
+    cfg.max_batch = 8
+    tta = HumanPoseEstimator(cfg, RealSenseIntrinsics())
+    assert tta.n_test == 5
+    assert tta.engine.warp(frame[None], np.array([cfg.fixed_bbox], np.int32)).shape == (5, 256, 256, 3)
+    with pytest.raises(Exception, match="augmentation"):
+        tta.estimate(frame)
