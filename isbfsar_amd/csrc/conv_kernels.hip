@@ -132,7 +132,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
                     else bs = *reinterpret_cast<const float4*>(p.bias + n);
                     v0 += bs.x; v1 += bs.y; v2 += bs.z; v3 += bs.w;
                     if (p.act) { v0 = silu_fast(v0); v1 = silu_fast(v1); v2 = silu_fast(v2); v3 = silu_fast(v3); }
-                    if (p.res && mok) {       // (requesting all residual pieces up front measured 5 % slower: registers)
+                    if (p.res && mok) {       // (requesting all residual pieces up front measured 5-7 % slower, twice)
                         const uint2 rr = *reinterpret_cast<const uint2*>(p.res + (size_t)m * p.Cout + n);
                         v0 += bf2f_((uint16_t)(rr.x & 0xffff)); v1 += bf2f_((uint16_t)(rr.x >> 16));
                         v2 += bf2f_((uint16_t)(rr.y & 0xffff)); v3 += bf2f_((uint16_t)(rr.y >> 16));

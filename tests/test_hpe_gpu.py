@@ -377,6 +377,39 @@ def test_full_size_properties(bbone_state, assets):
         e.close()
 
 
+def test_hpe_error_behaviour(bbone_state, assets):
+    """The boundary's error contract: every failure is a negative return code + isb_last_error text,
+    surfaced by the Python layer as IsbError; nothing is computed on a half-configured handle."""
+    from isbfsar_amd import _lib
+    from isbfsar_amd.hpe_engine import HpeEngine
+    e = HpeEngine(device=0, max_batch=4)
+    try:
+        fr = synth.frames(2, seed=1)
+        bb = synth.bboxes(2, seed=1)
+        with pytest.raises(_lib.IsbError, match="weights"):
+            e.forward(fr, bb)
+        bad = dict(bbone_state)
+        bad.pop(next(k for k in bad if k.endswith(".w")))
+        with pytest.raises(_lib.IsbError, match="missing"):
+            e.load_weights(bad)
+        with pytest.raises(_lib.IsbError):
+            e.load_weights(b"not a blob at all")
+        e.load_weights(bbone_state)
+        with pytest.raises(_lib.IsbError, match="joint map"):
+            e.forward(fr, bb)
+        with pytest.raises(_lib.IsbError, match="outside"):
+            e.set_joint_map(assets[0], [0, 1, 200])
+        e.set_joint_map(assets[0], None)
+        with pytest.raises(_lib.IsbError, match="max_batch"):
+            e.crop_params(synth.bboxes(5, seed=2))             # stage hooks run one micro-batch
+        j, v = e.forward(synth.frames(5, seed=2), synth.bboxes(5, seed=2))      # the full stage micro-batches (4 + 1)
+        assert j.shape == (5, 122, 3) and np.isfinite(j).all()
+        with pytest.raises(ValueError):
+            e.forward(fr[:, :100], bb)                         # wrong frame size is caught before the library
+    finally:
+        e.close()
+
+
 def test_pose_windows_kernel():
     import torch
     from isbfsar_amd.hpe_engine import pose_windows
