@@ -25,6 +25,7 @@ struct isb_ar {
     DevBuf s_feat, s_proj, KcF, KcF_lo, VtF, VtF_lo, ub;
     // per-chunk workspace
     int ws_B = 0;
+    DevBuf VqF;
     DevBuf win, h1, qfeat, proj, KqF, KqF_lo, lse2, part, diff, y1, f1, logits_tmp;
     DevBuf chosen;
     int chosen_cap = 0;
@@ -48,6 +49,7 @@ int ensure_ws(isb_ar* h, int Bc) {
     ISB_TRY(h->qfeat.alloc(B * L * 256 * 4));
     ISB_TRY(h->proj.alloc(B * L * 512 * 4));
     ISB_TRY(h->KqF.alloc(B * h->NT * 4096 * 2));
+    ISB_TRY(h->VqF.alloc(B * h->NT * 16 * 64 * 16));       // f32 V of the query tuples, 16 KiB per 32-tuple tile
     if (h->x3) ISB_TRY(h->KqF_lo.alloc(B * h->NT * 4096 * 2));
     ISB_TRY(h->lse2.alloc(B * nmax * h->Tp * 4));
     ISB_TRY(h->part.alloc(B * nmax * h->NT * 4));
@@ -312,6 +314,7 @@ extern "C" int isb_ar_infer(isb_ar* h, const float* d_windows, int32_t B, float*
         ta.gamma = h->gamma.as<float>(); ta.beta = h->beta.as<float>();
         ta.tup = h->tup.as<int16_t>();
         ta.KF = h->KqF.as<uint16_t>(); ta.KF_lo = h->x3 ? h->KqF_lo.as<uint16_t>() : nullptr;
+        ta.VqF = h->VqF.as<float>();
         ta.kscale = h->kscale;
         ta.n_items = Bc; ta.L = L; ta.T = T; ta.NT = NT;
         ISB_TRY(launch_ar_tuples(ta, st));
@@ -335,6 +338,7 @@ extern "C" int isb_ar_infer(isb_ar* h, const float* d_windows, int32_t B, float*
         pa.VtF = h->VtF.as<uint16_t>(); pa.VtF_lo = h->x3 ? h->VtF_lo.as<uint16_t>() : nullptr;
         pa.lse2 = h->lse2.as<float>();
         pa.proj = h->proj.as<float>(); pa.bv = h->bv.as<float>(); pa.tup = h->tup.as<int16_t>();
+        pa.VqF = h->VqF.as<float>();
         pa.chosen = nullptr; pa.part = h->part.as<float>(); pa.diff = nullptr;
         pa.B = Bc; pa.n = n; pa.L = L; pa.T = T; pa.NT = NT; pa.x3 = h->x3;
         ISB_TRY(launch_ar_proto(pa, st));

@@ -134,6 +134,26 @@ __global__ __launch_bounds__(512) void ar_tuples_k_kernel(ArTupleArgs p) {
         const float used = p.KF_lo ? yh + bf2f(lo[e]) : yh;
         nrm += used * used;
     }
+    if (p.VqF) {
+        // query side: V of the tuple in f32, (Av[f0] + Bv[f1]) + bv as ar_proto's epilogue used to rebuild it for every
+        // class, written once in the order that epilogue reads: features d0..d0+3 belong to lane half 0, d0+4..d0+7 to
+        // half 1 of piece (dt = ks / 2, q = 2 (ks % 2) + h)
+        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+        if (valid) {
+            const int f0 = p.tup[2 * t], f1 = p.tup[2 * t + 1];
+            const float* a = p.proj + (size_t)(item * p.L + f0) * 512 + 256 + d0;
+            const float* b = p.proj + (size_t)(item * p.L + f1) * 512 + 384 + d0;
+            const float4 a0 = *reinterpret_cast<const float4*>(a), a1 = *reinterpret_cast<const float4*>(a + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(b), b1 = *reinterpret_cast<const float4*>(b + 4);
+            const float4 c0 = *reinterpret_cast<const float4*>(p.bv + d0), c1 = *reinterpret_cast<const float4*>(p.bv + d0 + 4);
+            v0 = make_float4(a0.x + b0.x + c0.x, a0.y + b0.y + c0.y, a0.z + b0.z + c0.z, a0.w + b0.w + c0.w);
+            v1 = make_float4(a1.x + b1.x + c1.x, a1.y + b1.y + c1.y, a1.z + b1.z + c1.z, a1.w + b1.w + c1.w);
+        }
+        const int piece = (ks >> 1) * 4 + 2 * (ks & 1) + h;
+        float* dst = p.VqF + ((((size_t)item * p.NT + it) * 16 + piece) * 64 + r) * 4;
+        *reinterpret_cast<float4*>(dst) = v0;
+        *reinterpret_cast<float4*>(dst + 32 * 4) = v1;
+    }
     const size_t off = ((((size_t)item * p.NT + it) * 8 + ks) * 64 + lane) * 8;
     uint4 o;
     o.x = hi[0] | ((uint32_t)hi[1] << 16); o.y = hi[2] | ((uint32_t)hi[3] << 16);
@@ -549,24 +569,22 @@ __global__ __launch_bounds__(512, 2) void ar_proto_kernel(ArProtoArgs p) {
     const bool ivalid = i < p.T;
     float ss = 0.f;
     if (ivalid) {
-        const int f0 = p.tup[2 * i], f1 = p.tup[2 * i + 1];
-        const float* av = p.proj + (size_t)(b * p.L + f0) * 512 + 256 + 4 * h;
-        const float* bvp = p.proj + (size_t)(b * p.L + f1) * 512 + 384 + 4 * h;
-        const float* bias = p.bv + 4 * h;
+        // Vq of the lane's tuple comes from the fragment image ar_tuples wrote: 16 fully coalesced 1-KiB wave loads.
+        // (Rebuilding it here from the per-frame projections -- 48 loads per lane, every lane another 512-byte row --
+        // kept the CU's address unit busier than the matrix cores: the kernel was bound by its epilogue.)
+        const float* vq = p.VqF + (((size_t)b * p.NT + it) * 16 * 64 + lane) * 4;
         float* dout = CHOSEN ? p.diff + ((size_t)b * p.T + i) * 128 + 4 * h : nullptr;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int d = 32 * dt + 8 * q;
-                const float4 x = *reinterpret_cast<const float4*>(av + d);
-                const float4 y = *reinterpret_cast<const float4*>(bvp + d);
-                const float4 z = *reinterpret_cast<const float4*>(bias + d);
+                const float4 x = *reinterpret_cast<const float4*>(vq + (dt * 4 + q) * 256);
                 float4 df;
-                df.x = (x.x + y.x + z.x) - pacc[dt][4 * q + 0];
-                df.y = (x.y + y.y + z.y) - pacc[dt][4 * q + 1];
-                df.z = (x.z + y.z + z.z) - pacc[dt][4 * q + 2];
-                df.w = (x.w + y.w + z.w) - pacc[dt][4 * q + 3];
+                df.x = x.x - pacc[dt][4 * q + 0];
+                df.y = x.y - pacc[dt][4 * q + 1];
+                df.z = x.z - pacc[dt][4 * q + 2];
+                df.w = x.w - pacc[dt][4 * q + 3];
                 if (CHOSEN) *reinterpret_cast<float4*>(dout + d) = df;
                 ss += df.x * df.x + df.y * df.y + df.z * df.z + df.w * df.w;
             }

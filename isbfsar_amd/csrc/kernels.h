@@ -49,6 +49,8 @@ struct ArTupleArgs {
     uint16_t* VtF;          // out (support only) or null
     uint16_t* VtF_lo;       // out or null
     float* ub;              // out (support only): [n_items][Tp] = |kc_j| * qnorm_bound, or null
+    float* VqF;             // out (query only) or null: f32 V of every tuple in ar_proto's epilogue order,
+                            // [item][it][piece = 4 dt + q][lane = 32 h + r][4] = V[32 it + r][32 dt + 8 q + 4 h ..+4]
     float kscale;           // folded into K before rounding (query: log2(e)/sqrt(128); support: 1)
     float qnorm_bound;      // upper bound of |kq'| (support side only)
     int n_items, L, T, NT;
@@ -78,6 +80,7 @@ struct ArProtoArgs {
     const uint16_t* VtF_lo;
     const float* lse2;      // [B][n][Tp]
     const float* proj;      // [B*L,512] query projections (Av at +256, Bv at +384)
+    const float* VqF;       // query V in epilogue order (ArTupleArgs.VqF)
     const float* bv;        // [128]
     const int16_t* tup;     // [Tp][2]
     const int32_t* chosen;  // null: all classes -> part; else only class chosen[b] -> diff
