@@ -71,6 +71,15 @@ __device__ __forceinline__ void wait_tiles_in_flight(int tiles, int per_tile) { 
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// sum over the 16 lanes of a DPP row (row_ror 8, 4, 2, 1), the total in every lane
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+    return v;
+}
+
 // row of accumulator register r inside a 32x32 tile for lane-half h
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -337,6 +346,22 @@ __global__ __launch_bounds__(512, 2) void ar_stats_kernel(ArStatsArgs p) {
     }
     if (!active) return;
     // combine the 32 lanes (i within the tile) of each half-wave
+    if constexpr (!ONLINE) {
+        // plain sums: 16-lane row sums on the vector ALU (DPP rotations), then ONE cross-row exchange per value with all
+        // sixteen in flight. (As a 5-step xor butterfly per value, each step an LDS-crossbar permute that is waited
+        // for, these 80 serial round trips cost about as much as the kernel's whole tile loop.)
+        float rs[16], other[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) rs[i] = row16_sum(lsum[i]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) other[i] = __shfl_xor(rs[i], 16, 64);
+        if (r == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                p.lse2[((size_t)b * p.n + c) * Tp + jt * 32 + acc_row(i, h)] = ubr[i] + log2f(rs[i] + other[i]);
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         float l = lsum[i], m = ONLINE ? mrun[i] : ubr[i];
