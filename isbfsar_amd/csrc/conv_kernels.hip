@@ -1222,7 +1222,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c32_rows_kernel(ConvArgs p, in
 // WGM: 32-pixel blocks per workgroup (4 -> 128 pixels, 8 waves; 2 -> 64 pixels, 4 waves: two workgroups per CU
 // when the E tile of 384 channels would otherwise fill the LDS); Cexp = 64 * TN; WPR = projected channels rounded up
 // to 64 / 96 / 128 (rows of the projection-weight buffers)
-template <int WGM, int TN, int WPR>
+// HALO (stride 1, 64 input channels, 64-wide maps: the body blocks of stage 2): what bounds the k loop is the operand
+// bytes per k-step (tools/kstep_probe.py) and a third of them are im2col rows of A. The tile's 128 pixels are two image
+// rows; their input HALO (4 rows x 66 pixels x 128 B = 33 KiB, out-of-image pixels zero-filled by the buffer bounds
+// check) is copied to LDS once and the A fragments of the 18 k-steps are read from it -- a tap shift is just another
+// 128-byte LDS row, chunk slot = chunk ^ (pixel & 7) keeps eight consecutive pixels on 32 different banks. The k loop
+// then streams only the weights: 16 instead of 24 KiB per k-step. Same (tap, channel) order: bit-identical.
+template <int WGM, int TN, int WPR, bool HALO = false>
 __global__ __launch_bounds__(128 * WGM) void fused_mb_kernel(ConvArgs p) {
     constexpr int WGN = 2, NW = WGM * WGN;
     constexpr int TN2 = (WPR / 32 + 1) / 2;                  // 32-channel tiles of the projection per wave
@@ -1235,7 +1241,10 @@ __global__ __launch_bounds__(128 * WGM) void fused_mb_kernel(ConvArgs p) {
     constexpr int WP_ROWS = WPR, WP_BUF = WP_ROWS * ROWB;    // projection weights of one k-block (rows past Cout2 unused)
     constexpr int W2_PW = (WP_ROWS / 16 + NW - 1) / NW;
     constexpr int STAGE2 = BM * (64 * TN2 * 2 + 16);         // epilogue staging of the output tile
-    constexpr int REG_A0 = 2 * BUF > E_BYTES ? 2 * BUF : E_BYTES;
+    constexpr int HW_ = 64, HWD = HW_ + 2, HALO_BYTES = 4 * HWD * 128;     // HALO: 264 pixel rows of 128 B = 33 pieces
+    constexpr int BBUF = BN * ROWB;                                         // HALO: one k-step of weights
+    constexpr int KREG = HALO ? HALO_BYTES + 2 * BBUF : 2 * BUF;
+    constexpr int REG_A0 = KREG > E_BYTES ? KREG : E_BYTES;
     constexpr int REG_A = REG_A0 > STAGE2 ? REG_A0 : STAGE2;
     constexpr int WP_OFF = REG_A, BIAS1_OFF = WP_OFF + 2 * WP_BUF, BIAS2_OFF = BIAS1_OFF + BN * 4;
     __shared__ __attribute__((aligned(16))) unsigned char lds[BIAS2_OFF + 128 * 4];
@@ -1300,13 +1309,31 @@ __global__ __launch_bounds__(128 * WGM) void fused_mb_kernel(ConvArgs p) {
     if (wave == 1 && lane < 32) dma16_s(p.bias2, (uint32_t)min(lane * 4, p.Cout2 - 4) * 4, ldsA + BIAS2_OFF);
     int tap = 0, c0 = 0;
     uint32_t tap_soff = 0;
+    constexpr int B_LDS0 = HALO ? HALO_BYTES : BM * ROWB;     // weights of buffer 0; buffer 1 follows B_STRIDE later
+    constexpr int B_STRIDE = HALO ? BBUF : BUF;
+    if constexpr (HALO) {
+        // the halo, once: piece i = 8 pixel rows; lane = (pixel row i * 8 + lane / 8, chunk slot lane & 7)
+        const int b = m0 / ohw, y0 = (m0 - b * ohw) / HW_;
+        for (int i = wave; i < HALO_BYTES / 1024; i += NW) {
+            const int hp = i * 8 + (lane >> 3);
+            const int hy = hp / HWD, hx = hp - hy * HWD;
+            const int y = y0 - 1 + hy, x = hx - 1;
+            const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)HW_;
+            const uint32_t chunk = (uint32_t)((lane & 7) ^ (hp & 7));
+            // relative to the shifted base (in - (W + 1) pixels): pixel (y, x) sits at ((b H + y + 1) W + x + 1) pixels
+            const uint32_t voff = ok ? (uint32_t)((b * p.H + y + 1) * HW_ + x + 1) * 128u + chunk * 16u : 0x80000000u;
+            dma16_buf(rsrc, voff, 0u, ldsA + i * 1024);
+        }
+    }
     auto dma = [&](auto bufc) {
         constexpr int buf = decltype(bufc)::value;
-        const uint32_t soff = tap_soff + (uint32_t)c0 * 2u;
-        dma16_buf(rsrc, ((a_mask >> tap) & 1u) ? a_voff : 0x80000000u, soff, lds0 + buf * BUF);
+        if constexpr (!HALO) {
+            const uint32_t soff = tap_soff + (uint32_t)c0 * 2u;
+            dma16_buf(rsrc, ((a_mask >> tap) & 1u) ? a_voff : 0x80000000u, soff, lds0 + buf * BUF);
+        }
 #pragma unroll
         for (int s = 0; s < B_PW; ++s)
-            if (wave + NW * s < B_INST) dma16_s(b_base, b_voff[s], lds0 + (buf * BUF + BM * ROWB + NW * s * 1024));
+            if (wave + NW * s < B_INST) dma16_s(b_base, b_voff[s], lds0 + (B_LDS0 + buf * B_STRIDE + NW * s * 1024));
         b_base += CK * 2;
         c0 += CK;
         if (c0 == p.Cin) {
@@ -1325,19 +1352,33 @@ __global__ __launch_bounds__(128 * WGM) void fused_mb_kernel(ConvArgs p) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         a_sw[ks] = swz(wm * 32 + r, 2 * ks + h);
-        b_sw[ks] = BM * ROWB + swz(wn * TN * 32 + r, 2 * ks + h);
+        b_sw[ks] = B_LDS0 + swz(wn * TN * 32 + r, 2 * ks + h);
     }
+    // HALO: window origin of the lane's pixel in the halo; k-step kt = (tap kt / 2, channel half kt % 2 = buffer)
+    const int hq = wm * 32 + r;
+    const int hp0 = (hq / HW_) * HWD + (hq % HW_);
+    int h_tap = 0, h_off = 0;                                 // tap index and its pixel offset ky * 66 + kx
     auto compute = [&](auto bufc) {
         constexpr int buf = decltype(bufc)::value;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const bf16x8 af = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + a_sw[ks] + buf * BUF));
+            bf16x8 af;
+            if constexpr (HALO) {
+                const int hp = hp0 + h_off;
+                af = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + hp * 128 + (((4 * buf + 2 * ks + h) ^ (hp & 7)) << 4)));
+            } else {
+                af = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + a_sw[ks] + buf * BUF));
+            }
             bf16x8 bfr[TN];
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + b_sw[ks] + (buf * BUF + j * 2048)));
+                bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + b_sw[ks] + (buf * B_STRIDE + j * 2048)));
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af, acc[j], 0, 0, 0);
+        }
+        if constexpr (HALO && buf == 1) {                     // both halves of the tap done
+            ++h_tap;
+            h_off += (h_tap % 3 == 0) ? HWD - 2 : 1;
         }
     };
     auto publish = [&]() {
@@ -1463,6 +1504,11 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t st) {
     return launch_splitk_reduce(b, st);
 }
 
+static bool fused_mb_halo() {       // ISB_FMB_HALO=0: im2col A operand (A/B switch)
+    static const bool on = [] { const char* e = getenv("ISB_FMB_HALO"); return !e || atoi(e) != 0; }();
+    return on;
+}
+
 int launch_fused_mb(const ConvArgs& a, hipStream_t st) {
     const bool same1 = a.stride == 1 && a.pad == 1, same2 = a.stride == 2 && a.pad == 0;
     if (a.gate || a.KH != 3 || a.KW != 3 || !(same1 || same2) || a.Cin % 32 != 0 || a.K != 9 * a.Cin || !a.w2 || !a.bias2 ||
@@ -1479,7 +1525,9 @@ int launch_fused_mb(const ConvArgs& a, hipStream_t st) {
     if (a.Cout == 128) {
         if (wpr == 64) ISB_FMB(4, 2, 64); else if (wpr == 96) ISB_FMB(4, 2, 96); else ISB_FMB(4, 2, 128);
     } else if (a.Cout == 256) {
-        if (wpr == 64) ISB_FMB(4, 4, 64); else if (wpr == 96) ISB_FMB(4, 4, 96); else ISB_FMB(4, 4, 128);
+        if (wpr == 64 && same1 && a.Cin == 64 && a.W == 64 && a.H % 2 == 0 && fused_mb_halo())
+            hipLaunchKernelGGL((fused_mb_kernel<4, 4, 64, true>), dim3(cdiv(a.M, 128)), dim3(512), 0, st, aa);
+        else if (wpr == 64) ISB_FMB(4, 4, 64); else if (wpr == 96) ISB_FMB(4, 4, 96); else ISB_FMB(4, 4, 128);
     } else {                                                 // 384 expanded channels: 64-pixel tiles, two workgroups per CU
         if (wpr == 64) ISB_FMB(2, 6, 64); else if (wpr == 96) ISB_FMB(2, 6, 96); else ISB_FMB(2, 6, 128);
     }

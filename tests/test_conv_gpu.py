@@ -207,6 +207,8 @@ def test_depthwise_pool(B, H, C, stride):
 
 @pytest.mark.parametrize("B,H,Cin,Cexp,Cout2,stride,use_res", [
     (2, 32, 64, 256, 64, 1, True),      # stage 2 body block
+    (2, 64, 64, 256, 64, 1, True),      # stage 2 body block at its real 64 x 64 size: halo-tile A operand
+    (1, 64, 64, 256, 64, 1, False),
     (3, 16, 32, 128, 64, 2, False),     # stage 2 first block (stride 2), ragged M (192 rows)
     (2, 16, 96, 384, 96, 1, True),      # stage 3 body block (wide projection path)
     (1, 32, 64, 256, 96, 2, False),     # stage 3 first block
