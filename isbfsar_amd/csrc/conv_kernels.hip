@@ -922,7 +922,11 @@ __device__ __forceinline__ void dma16_buf(i32x4_t rsrc, uint32_t voff, uint32_t 
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(voff), "s"(rsrc), "s"(la), "s"(so) : "memory");
 }
 
-template <int TM, int TN, int WGM, int WGN>
+// HALO (stride 1, 96 input channels, 32-wide maps, 128-pixel tiles = four image rows: the body blocks of stage 3): the
+// A fragments come from the tile's input halo in LDS (6 rows x 34 pixels, 256-byte pixel rows of which 192 B are used,
+// chunk slot = chunk ^ (pixel & 7)), copied once, like fused_mb_kernel<.., HALO>; the k loop streams only the weights
+// (12 instead of 20 KiB per k-step). Same (tap, channel) order: bit-identical.
+template <int TM, int TN, int WGM, int WGN, bool HALO = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_dma_kernel(ConvArgs p) {
     constexpr int NW = WGM * WGN;
     constexpr int BM = 32 * TM * WGM;
@@ -931,7 +935,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_dma_kernel(ConvArgs p)
     constexpr int A_PW = (A_INST + NW - 1) / NW, B_PW = (B_INST + NW - 1) / NW;
     constexpr int BUF = (BM + BN) * ROWB;
     constexpr int CROW = BN * 2 + 16;
-    constexpr int LDS_BYTES = (2 * BUF > BM * CROW || BM * CROW > 65536) ? 2 * BUF : BM * CROW;
+    constexpr int HW_ = 32, HWD = HW_ + 2, HALO_BYTES = 6 * HWD * 256;       // HALO: 204 pixel rows of 256 B = 51 pieces
+    constexpr int BBUF = BN * ROWB;
+    constexpr int KREG = HALO ? HALO_BYTES + 2 * BBUF : 2 * BUF;
+    constexpr int LDS_BYTES = (KREG > BM * CROW || BM * CROW > 65536) ? KREG : BM * CROW;
+    constexpr int B_LDS0 = HALO ? HALO_BYTES : BM * ROWB, B_STRIDE = HALO ? BBUF : BUF;
+    static_assert(!HALO || (BM == 128 && TM == 1), "the halo path walks 128-pixel tiles, one 32-pixel block per wave row");
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES + BN * 4];
     constexpr int bias_off = LDS_BYTES;
 
@@ -993,18 +1002,35 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_dma_kernel(ConvArgs p)
     // scalar k-step state: tap index, channel offset inside the tap, byte offset of the tap's pixel
     int tap = 0, c0 = 0;
     uint32_t tap_soff = 0;
+    if constexpr (HALO) {
+        // the halo, once: piece i = 4 pixel rows of 256 B; lane = (pixel row i * 4 + lane / 16, chunk slot lane & 15)
+        const int b = m0 / ohw, y0 = (m0 - b * ohw) / HW_;
+        const uint32_t ldsA = (uint32_t)(uintptr_t)(lds_ptr_t)lds;
+        for (int i = wave; i < HALO_BYTES / 1024; i += NW) {
+            const int hp = i * 4 + (lane >> 4);
+            const int hy = hp / HWD, hx = hp - hy * HWD;
+            const int y = y0 - 1 + hy, x = hx - 1;
+            const int chunk = (lane & 15) ^ (hp & 7);
+            const bool ok = chunk < 12 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)HW_;
+            // relative to the shifted base (in - (W + 1) pixels): pixel (y, x) sits at ((b H + y + 1) W + x + 1) pixels
+            const uint32_t voff = ok ? (uint32_t)((b * p.H + y + 1) * HW_ + x + 1) * 192u + (uint32_t)chunk * 16u : 0x80000000u;
+            dma16_buf(rsrc, voff, 0u, ldsA + i * 1024);
+        }
+    }
     auto dma = [&](auto bufc) {
         constexpr int buf = decltype(bufc)::value;
         const uint32_t soff = tap_soff + (uint32_t)c0 * 2u;
+        if constexpr (!HALO) {
 #pragma unroll
-        for (int s = 0; s < A_PW; ++s)
-            if (wave + NW * s < A_INST) {
-                const uint32_t vo = ((a_mask[s] >> tap) & 1u) ? a_voff[s] : 0x80000000u;   // + soff cannot wrap back in range
-                dma16_buf(rsrc, vo, soff, lds0 + (buf * BUF + NW * s * 1024));
-            }
+            for (int s = 0; s < A_PW; ++s)
+                if (wave + NW * s < A_INST) {
+                    const uint32_t vo = ((a_mask[s] >> tap) & 1u) ? a_voff[s] : 0x80000000u;   // + soff cannot wrap back in range
+                    dma16_buf(rsrc, vo, soff, lds0 + (buf * BUF + NW * s * 1024));
+                }
+        }
 #pragma unroll
         for (int s = 0; s < B_PW; ++s)
-            if (wave + NW * s < B_INST) dma16_s(b_base, b_voff[s], lds0 + (buf * BUF + BM * ROWB + NW * s * 1024));
+            if (wave + NW * s < B_INST) dma16_s(b_base, b_voff[s], lds0 + (B_LDS0 + buf * B_STRIDE + NW * s * 1024));
         b_base += CK * 2;
         c0 += CK;
         if (c0 == p.Cin) {                      // next tap: one pixel to the right, or back two and down a row
@@ -1025,24 +1051,40 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_dma_kernel(ConvArgs p)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         a_sw[ks] = swz(wm * TM * 32 + r, 2 * ks + h);
-        b_sw[ks] = BM * ROWB + swz(wn * TN * 32 + r, 2 * ks + h);
+        b_sw[ks] = B_LDS0 + swz(wn * TN * 32 + r, 2 * ks + h);
     }
+    // HALO: window origin of the lane's pixel in the halo; k-step = (tap, 32-channel block 0..2 of the 96)
+    const int hq = wm * 32 + r;
+    const int hp0 = (hq / HW_) * HWD + (hq % HW_);
+    int h_tap = 0, h_off = 0, h_cb = 0;
     auto compute = [&](auto bufc) {
         constexpr int buf = decltype(bufc)::value;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 af[TM], bfr[TN];
+            if constexpr (HALO) {
+                const int hp = hp0 + h_off;
+                af[0] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + hp * 256 + (((4 * h_cb + 2 * ks + h) ^ (hp & 7)) << 4)));
+            } else {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + a_sw[ks] + (buf * BUF + i * 2048)));
+                for (int i = 0; i < TM; ++i)
+                    af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + a_sw[ks] + (buf * BUF + i * 2048)));
+            }
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + b_sw[ks] + (buf * BUF + j * 2048)));
+                bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + b_sw[ks] + (buf * B_STRIDE + j * 2048)));
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        if constexpr (HALO) {
+            if (++h_cb == 3) {                                // the tap's 96 channels done
+                h_cb = 0;
+                ++h_tap;
+                h_off += (h_tap % 3 == 0) ? HWD - 2 : 1;
+            }
         }
     };
     auto publish = [&]() {
@@ -1592,6 +1634,11 @@ static dim3 conv_grid(ConvArgs& a, int BM, int BN) {
     return dim3(8 * ((a.grid_m + 7) / 8) * a.grid_n, 1, z);
 }
 
+static bool conv3_halo() {          // ISB_C3_HALO=0: im2col A operand (A/B switch)
+    static const bool on = [] { const char* e = getenv("ISB_C3_HALO"); return !e || atoi(e) != 0; }();
+    return on;
+}
+
 static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
     ConvArgs aa = a;
     aa.grid_mode = conv_grid_mode();
@@ -1638,6 +1685,8 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
             if (a.Cout == 32 && a.Cin == 32 && a.stride == 1 && a.W == 128 && a.H % 2 == 0 && !a.out_f32)
                 v = 171;                              // rows ring in LDS, +50 % over the implicit GEMM (bit-identical)
             else if (a.Cout == 32) v = 163;           // 256 x  32   (lean 3x3, buffer-addressed A operand)
+            else if (a.Cout % 192 == 0 && a.stride == 1 && a.Cin == 96 && a.W == 32 && a.H % 4 == 0 && conv3_halo())
+                v = 167;                              // 128 x 192, halo-tile A operand
             else if (a.Cout % 192 == 0) v = 161;      // 128 x 192
             else v = 162;                             // 128 x 128
         } else if (!a.gate && a.zeros) {
@@ -1862,6 +1911,16 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
                 attr_set = true;
             }
             hipLaunchKernelGGL(conv3x3_c32_rows_kernel, dim3(a.B * (a.H / band)), dim3(512), HALO_LDS, st, aa, band);
+            break;
+        }
+        case 167: {                                          // 128 x 192, A operand from an LDS halo (96 channels, 32-wide maps)
+            if (a.gate || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Cin != 96 || a.W != 32 || a.H % 4 != 0 ||
+                (a.H * a.W) % 128 != 0 || (size_t)a.B * a.H * a.W * a.Cin * 2 + (size_t)(a.W + 1) * a.Cin * 2 >= 0x7ffffff0ull) {
+                set_error("conv_igemm: variant 167 is the 3x3 stride-1 convolution of 96 channels on 32-wide maps");
+                return ISB_ERR_INVALID;
+            }
+            const dim3 g = conv_grid(aa, 128, 192);
+            hipLaunchKernelGGL((conv3x3_dma_kernel<1, 3, 4, 2, true>), g, dim3(512), 0, st, aa);
             break;
         }
         case 161: ISB_CONV_LAUNCH_C3(1, 3, 4, 2); break;   // 128 x 192

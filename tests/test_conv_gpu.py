@@ -115,6 +115,24 @@ def test_conv_halo_c32(B, H, act, use_res):
     assert np.all(np.abs(got - ref) <= tol), float(np.abs(got - ref).max())
 
 
+@pytest.mark.parametrize("B,Cout,act", [(2, 384, 1), (3, 192, 0)])
+def test_conv3x3_halo_c96(B, Cout, act):
+    """3x3 96 -> Cout on 32 x 32 maps with the A operand read from an LDS halo tile (variant 167): bit for bit the
+    implicit-GEMM kernel (variant 161), and the torch reference."""
+    rng = np.random.default_rng(B * 100 + Cout)
+    x = rng.normal(0, 1, (B, 32, 32, 96)).astype(np.float32)
+    w = (rng.normal(0, 1, (Cout, 3, 3, 96)) / np.sqrt(864)).astype(np.float32)
+    scale = rng.uniform(0.8, 1.2, Cout).astype(np.float32)
+    shift = rng.uniform(-0.1, 0.1, Cout).astype(np.float32)
+    out, _ = conv_debug(f32_to_bf16(x), w, scale, shift, 3, 1, act, None, None, variant=167)
+    old, _ = conv_debug(f32_to_bf16(x), w, scale, shift, 3, 1, act, None, None, variant=161)
+    assert np.array_equal(out, old)
+    ref = _ref(x, w, scale, shift, 3, 1, act, None, None)
+    got = bf16_to_f32(out)
+    tol = 2.0 ** -7 * np.maximum(1.0, np.abs(ref))
+    assert np.all(np.abs(got - ref) <= tol), float(np.abs(got - ref).max())
+
+
 SPLITK_CASES = [
     # B, H, Cin, Cout, act, res, gate, splits, tile variant
     (1, 8, 2304, 384, 0, True, True, 12, 147),     # stage-6 projection of one frame
