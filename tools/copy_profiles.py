@@ -12,6 +12,7 @@ for w, name in (("pipeline", "pipe"), ("hpe", "hpe"), ("ar", "ar"), ("stream", "
     shutil.copy(f"{G}/bench_{w}.json", f"{P}/{tag}_bench_{name}.json")
 shutil.copy(f"{G}/prof_pipe/run_kernel_stats.csv", f"{P}/{tag}_pipeline_b256_kernel_stats.csv")
 shutil.copy(f"{G}/prof_ar/run_kernel_stats.csv", f"{P}/{tag}_ar_b1024_kernel_stats.csv")
+shutil.copy(f"{G}/prof_hpe1/run_kernel_stats.csv", f"{P}/{tag}_hpe_b256_onelane_kernel_stats.csv")
 shutil.copy(f"{G}/traffic.json", f"{P}/{tag}_traffic.json")
 for src, dst in (("pmc_fetch", "hpe_b256_fetch_size"), ("pmc_write", "hpe_b256_write_size")):
     with open(f"{G}/{src}/run_counter_collection.csv") as f, open(f"{P}/{tag}_{dst}_counters.csv", "w", newline="") as o:

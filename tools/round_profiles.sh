@@ -11,6 +11,9 @@ for w in pipeline hpe ar stream; do
 done
 echo "== kernel stats (pipeline)"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_pipe -o run -- python3 bench.py --workload pipeline --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/prof_pipe.log 2>&1
+echo "== kernel stats (hpe, one lane: every convolution launch is a 256-frame launch, as in bench.py's roofline pass)"
+ISB_HPE_LANES=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_hpe1 -o run -- python3 bench.py --workload hpe --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/prof_hpe1.log 2>&1
+python3 tools/family_avg.py gpurun_out/prof_hpe1/run_kernel_stats.csv gpurun_out/bench_hpe.json
 echo "== kernel stats (ar)"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_ar -o run -- python3 bench.py --workload ar --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/prof_ar.log 2>&1
 echo "== PMC traffic"
