@@ -167,8 +167,10 @@ def main():
 
     W = pick_workload(args.workload)(args, rank, world, local)
     # set-up, not measurement: the first calls allocate the per-lane activation workspaces and load the code objects
-    # (and, for N > 1, establish the RCCL rings); the W warm-up steps the caller asked for follow
-    for _ in range(2):
+    # (and, for N > 1, establish the RCCL rings), and a fraction of a second of load brings the clocks to their sustained
+    # state (a 100-step run averages 19.9 ms per step, the first steps after start-up 21); the W warm-up steps the
+    # caller asked for follow
+    for _ in range(8 if args.workload in ("auto", "pipeline", "hpe", "ar") else 2):
         W.step()
     torch.cuda.synchronize()
 
