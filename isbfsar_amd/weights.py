@@ -99,10 +99,16 @@ def ar_state_shapes(seq_len: int, n_joints: int, d_in: int = 256, d_out: int = 1
     return s
 
 
-def make_ar_state(seq_len: int, n_joints: int, seed: int = 0, gain: float = 1.0) -> "OrderedDict[str, np.ndarray]":
+def make_ar_state(seq_len: int, n_joints: int, seed: int = 0, gain: float = 1.0, disc_gain: float = 1.0,
+                  norm_gain: float = 1.0) -> "OrderedDict[str, np.ndarray]":
     """Deterministic TRXOS (skeleton) weights: U(-g/sqrt(fan_in), g/sqrt(fan_in)) like
     torch's Linear default; LayerNorm gamma in [0.8,1.2], beta in [-0.1,0.1] so that the
-    affine part of ``norm_k`` (model.py:46) is exercised."""
+    affine part of ``norm_k`` (model.py:46) is exercised.
+
+    ``disc_gain`` multiplies the four Discriminator weight matrices (model.py:186-191): with the default
+    initialisation the open-set score sits in 0.50-0.51 whatever the input, with 6 it spans (0.05, 0.95) over
+    the synthetic windows, so a wrong ``diff`` shows. ``norm_gain`` multiplies ``norm_k.weight`` (a trained
+    LayerNorm gain: sharper tuple attention, model.py:46,101-109)."""
     out: "OrderedDict[str, np.ndarray]" = OrderedDict()
     shapes = ar_state_shapes(seq_len, n_joints)
     for name, shape in shapes.items():
@@ -116,6 +122,12 @@ def make_ar_state(seq_len: int, n_joints: int, seed: int = 0, gain: float = 1.0)
             fan_in = wshape[-1]
             b = gain / np.sqrt(float(fan_in))
             out[name] = uniform(name, shape, -b, b, seed)
+    if disc_gain != 1.0:
+        for name in ("discriminator.dimensionality_reduction.weight", "discriminator.fc1.weight",
+                     "discriminator.fc2.weight", "discriminator.fc3.weight"):
+            out[name] = (out[name] * np.float32(disc_gain)).astype(np.float32)
+    if norm_gain != 1.0:
+        out["transformers.0.norm_k.weight"] = (out["transformers.0.norm_k.weight"] * np.float32(norm_gain)).astype(np.float32)
     return out
 
 
@@ -179,10 +191,11 @@ def state_from_torch(state_dict: Mapping[str, "object"], keys: Iterable[str] | N
     out = {}
     for k, v in state_dict.items():
         k2 = k.replace(".module", "")
-        if k2.startswith("features_extractor.") and not k2.startswith("features_extractor.sk."):
-            k2 = "features_extractor.sk." + k2[len("features_extractor."):]
+        # the RGB branch is not on the skeleton path: drop it BEFORE the rename below would hide its prefix
         if k2.startswith("post_resnet.") or k2.startswith("features_extractor.rgb."):
             continue
+        if k2.startswith("features_extractor.") and not k2.startswith("features_extractor.sk."):
+            k2 = "features_extractor.sk." + k2[len("features_extractor."):]
         if keys is not None and k2 not in keys:
             continue
         out[k2] = np.asarray(v.detach().cpu().numpy() if hasattr(v, "detach") else v, dtype=np.float32)

@@ -6,8 +6,12 @@ TensorRT engine (``bbone1.engine``: reference utils/params.py:29, modules/hpe/hp
 4_create_heads_onnx.py:13,19; model name 'efficientnetv2-l', include_top=False:
 2_extract_bbone_heads.py:27,46-47). The arithmetic lives in isarandi/metrabs (un-vendored, no pinned
 version) + downloaded weights, so there is NO reference output to pin against: this file restates
-the public efficientnetv2-l block table (isbfsar_amd/effnetv2.py) and the HIP backbone is compared
-with it on synthetic weights. What IS pinned is the shape contract.
+the PUBLIC efficientnetv2-l definition from its published block strings (``V2_L_BLOCKS`` below, parsed here --
+nothing is imported from the product package) and the HIP backbone is compared with it on synthetic
+weights. What IS pinned: the shape contract, and three known answers of the public model that
+tests/test_oracle_effnetv2.py asserts on this file's own table: 117,746,848 parameters without the
+classifier top (117,234,272 trainable: the figures Keras prints for EfficientNetV2L(include_top=False)),
+15.99 GMAC per 256x256 crop and the output shape [B,8,8,1280].
 
 Two numeric modes:
   * ``mode="f32"``   plain fp32 everywhere;
@@ -19,13 +23,112 @@ Only tests/, smoke() and bench.py's cpu_baseline leg may import this file.
 """
 from __future__ import annotations
 
-from typing import Dict, Mapping, Optional
+import re
+from dataclasses import dataclass
+from typing import Dict, List, Mapping, Optional
 
 import numpy as np
 import torch
 import torch.nn.functional as F
 
-from isbfsar_amd import effnetv2 as arch
+# the published efficientnetv2-l architecture strings: r = repeats, k = kernel, s = stride of the first repeat,
+# e = expansion ratio, i / o = input / output filters, c1 = Fused-MBConv, se = squeeze-excite ratio of the block INPUT
+V2_L_BLOCKS = (
+    "r4_k3_s1_e1_i32_o32_c1",
+    "r7_k3_s2_e4_i32_o64_c1",
+    "r7_k3_s2_e4_i64_o96_c1",
+    "r10_k3_s2_e4_i96_o192_se0.25",
+    "r19_k3_s1_e6_i192_o224_se0.25",
+    "r25_k3_s2_e6_i224_o384_se0.25",
+    "r7_k3_s1_e6_i384_o640_se0.25",
+)
+STEM_FILTERS = 32          # = input filters of the first block
+HEAD_FILTERS = 1280        # feature_size of the public config
+BN_EPS = 1e-3
+
+
+@dataclass
+class OBlock:
+    idx: int
+    kind: str          # "fused" | "mb"
+    cin: int
+    cout: int
+    cexp: int
+    stride: int
+    cse: int           # squeeze width, 0 = no SE
+    residual: bool
+    in_hw: int
+    out_hw: int
+
+
+def parse_block_string(s: str) -> dict:
+    """'r10_k3_s2_e4_i96_o192_se0.25' -> dict(r=10, k=3, s=2, e=4, i=96, o=192, se=0.25, c=0)"""
+    out = {"se": 0.0, "c": 0}
+    for op in s.split("_"):
+        m = re.match(r"^([a-z]+)([0-9.]+)$", op)
+        if not m:
+            raise ValueError(f"bad block option {op!r} in {s!r}")
+        key, val = m.group(1), m.group(2)
+        out[key] = float(val) if key == "se" else int(val)
+    for need in ("r", "k", "s", "e", "i", "o"):
+        if need not in out:
+            raise ValueError(f"{s!r}: option {need!r} missing")
+    return out
+
+
+def oracle_blocks(in_hw: int = 128, strings=V2_L_BLOCKS) -> List[OBlock]:
+    """Expand the block strings the way the public model builder does: the first repeat of a stage takes the stage's
+    input filters and stride, later repeats run output->output at stride 1; squeeze width = max(1, int(block_in * se));
+    identity skip when stride 1 and in == out."""
+    out: List[OBlock] = []
+    hw, idx = in_hw, 0
+    for s in strings:
+        a = parse_block_string(s)
+        assert a["k"] == 3, "efficientnetv2-l uses 3x3 kernels only"
+        for rep in range(a["r"]):
+            cin = a["i"] if rep == 0 else a["o"]
+            stride = a["s"] if rep == 0 else 1
+            ohw = hw // stride
+            out.append(OBlock(idx, "fused" if a["c"] == 1 else "mb", cin, a["o"], cin * a["e"], stride,
+                              max(1, int(cin * a["se"])) if a["se"] > 0 else 0, stride == 1 and cin == a["o"], hw, ohw))
+            hw, idx = ohw, idx + 1
+    return out
+
+
+def count_parameters(blocks: Optional[List[OBlock]] = None) -> Dict[str, int]:
+    """Parameters of the public model without its classifier top: convolution kernels (no bias), BatchNorm
+    gamma/beta (trainable) + moving mean/variance, squeeze-excite kernels and biases."""
+    blocks = oracle_blocks() if blocks is None else blocks
+    w = STEM_FILTERS * 27
+    bn = STEM_FILTERS
+    for b in blocks:
+        if b.kind == "fused":
+            if b.cexp == b.cin:
+                w += b.cout * 9 * b.cin
+                bn += b.cout
+            else:
+                w += b.cexp * 9 * b.cin + b.cout * b.cexp
+                bn += b.cexp + b.cout
+        else:
+            w += b.cexp * b.cin + 9 * b.cexp + b.cout * b.cexp + (b.cse * b.cexp + b.cse) + (b.cexp * b.cse + b.cexp)
+            bn += 2 * b.cexp + b.cout
+    w += HEAD_FILTERS * blocks[-1].cout
+    bn += HEAD_FILTERS
+    return {"trainable": w + 2 * bn, "total": w + 4 * bn}
+
+
+def count_macs(blocks: Optional[List[OBlock]] = None, crop: int = 256, n_head_logits: int = 288) -> int:
+    """Multiply-accumulates for one crop: stem + blocks + 1x1 head conv + the MetrABS Linear(1280, 288) pose head."""
+    blocks = oracle_blocks(crop // 2) if blocks is None else blocks
+    m = (crop // 2) ** 2 * 27 * STEM_FILTERS
+    for b in blocks:
+        o = b.out_hw * b.out_hw
+        if b.kind == "fused":
+            m += o * 9 * b.cin * b.cexp + (o * b.cexp * b.cout if b.cexp != b.cin else 0)
+        else:
+            m += b.in_hw * b.in_hw * b.cin * b.cexp + o * 9 * b.cexp + o * b.cexp * b.cout + 2 * b.cexp * b.cse
+    o = blocks[-1].out_hw ** 2
+    return m + o * blocks[-1].cout * HEAD_FILTERS + o * HEAD_FILTERS * n_head_logits
 
 
 def _r(x: torch.Tensor, mode: str) -> torch.Tensor:
@@ -40,7 +143,7 @@ class EffNetV2LOracle:
     def __init__(self, state: Mapping[str, np.ndarray], mode: str = "bf16"):
         assert mode in ("f32", "bf16")
         self.mode = mode
-        self.blocks = arch.blocks()
+        self.blocks = oracle_blocks()
         self.w: Dict[str, torch.Tensor] = {}
         for k, v in state.items():
             self.w[k] = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))

@@ -79,10 +79,12 @@ def reference_trxos(seq_len: int, n_joints: int, way: int, state):
     return net
 
 
-def gen_ar(tag: str, L: int, J: int, way: int, B: int, seed: int, keep_intermediates: bool):
+def gen_ar(tag: str, L: int, J: int, way: int, B: int, seed: int, keep_intermediates: bool, **state_kw):
     import torch
 
-    state = weights.make_ar_state(L, J, seed=seed)
+    # state_kw: disc_gain / norm_gain (weights.make_ar_state) -- the "sharp" fixtures, whose open-set score spans
+    # (0.05, 0.95) and whose LayerNorm gain is that of a trained model
+    state = weights.make_ar_state(L, J, seed=seed, **state_kw)
     net = reference_trxos(L, J, way, state)
     ss = synth.skeleton_windows(way, L, J, seed=seed + 100)
     q = synth.skeleton_windows(B, L, J, seed=seed + 200)
@@ -112,6 +114,7 @@ def gen_ar(tag: str, L: int, J: int, way: int, B: int, seed: int, keep_intermedi
                     outs["proto0_c0"] = o["prototypes"][0].numpy()[0, 0]
     rec = dict(
         L=L, J=J, way=way, B=B, seed=seed,
+        disc_gain=np.float64(state_kw.get("disc_gain", 1.0)), norm_gain=np.float64(state_kw.get("norm_gain", 1.0)),
         ss_digest=digest(ss), q_digest=digest(q),
         logits=np.stack(outs["logits"]), is_true=np.stack(outs["is_true"]),
         qfeat0=outs["qfeat"], support_features_c0=sf[0], support_features_digest=digest(sf),
@@ -158,6 +161,11 @@ def main():
         gen_ar("ref_16_30_5", 16, 30, 5, B=3, seed=0, keep_intermediates=True)
         gen_ar("bl_30_122_60", 30, 122, 60, B=2, seed=1, keep_intermediates=False)
         gen_ar_stream("ref_16_30_5", 16, 30, 5, n_frames=20, seed=0)
+        # BASELINE configs[4]: 120-class support set (one window is enough: the reference takes 0.3 s per window here)
+        gen_ar("bl_30_122_120", 30, 122, 120, B=1, seed=1, keep_intermediates=False)
+        # resolving power: discriminator weights x6 (is_true spans 0.0-1.0 instead of 0.50-0.51) and LayerNorm gain x3
+        gen_ar("sharp_16_30_5", 16, 30, 5, B=8, seed=2, keep_intermediates=False, disc_gain=6.0, norm_gain=3.0)
+        gen_ar("sharp_30_122_60", 30, 122, 60, B=4, seed=2, keep_intermediates=False, disc_gain=6.0, norm_gain=3.0)
     if "hpe" in which:
         try:
             from gen_golden_hpe import gen_all

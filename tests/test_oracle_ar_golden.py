@@ -18,19 +18,28 @@ def _load(golden_dir, name):
     return np.load(os.path.join(golden_dir, name))
 
 
-@pytest.mark.parametrize("name", ["ar_ref_16_30_5.npz", "ar_bl_30_122_60.npz"])
+def _state_kw(g):
+    """the weight-generator switches a fixture was made with (oracle/gen_golden.py: the "sharp" fixtures)"""
+    return {k: float(g[k]) for k in ("disc_gain", "norm_gain") if k in g.files}
+
+
+@pytest.mark.parametrize("name", ["ar_ref_16_30_5.npz", "ar_bl_30_122_60.npz", "ar_bl_30_122_120.npz",
+                                  "ar_sharp_16_30_5.npz", "ar_sharp_30_122_60.npz"])
 def test_trxos_oracle_matches_reference(golden_dir, name):
     g = _load(golden_dir, name)
     L, J, way, B, seed = (int(g[k]) for k in ("L", "J", "way", "B", "seed"))
-    state = weights.make_ar_state(L, J, seed=seed)
+    state = weights.make_ar_state(L, J, seed=seed, **_state_kw(g))
     ss = synth.skeleton_windows(way, L, J, seed=seed + 100)
     q = synth.skeleton_windows(B, L, J, seed=seed + 200)
     # the synthetic generator must reproduce the inputs the reference saw
     assert _digest(ss) == str(g["ss_digest"]) and _digest(q) == str(g["q_digest"])
     net = TRXOSOracle(state, L, J)
     out = net.forward(ss, way, q)
-    np.testing.assert_allclose(out["logits"], g["logits"], rtol=0, atol=2e-5)
-    np.testing.assert_allclose(out["is_true"], g["is_true"], rtol=0, atol=2e-6)
+    sharp = "sharp" in name        # LayerNorm gain x3: logits up to -14; discriminator x6: f32 noise amplified 6^4 times
+    np.testing.assert_allclose(out["logits"], g["logits"], rtol=0, atol=2e-4 if sharp else 2e-5)
+    np.testing.assert_allclose(out["is_true"], g["is_true"], rtol=0, atol=1e-4 if sharp else 2e-6)
+    if sharp:                      # the point of these fixtures: the open-set score moves
+        assert g["is_true"].min() < 0.1 and g["is_true"].max() > 0.9
     np.testing.assert_allclose(out["query_features"][0], g["qfeat0"], rtol=0, atol=2e-6)
     np.testing.assert_allclose(out["support_features"][0], g["support_features_c0"], rtol=0, atol=2e-6)
     assert abs(float(out["support_features"].astype(np.float64).sum()) - float(g["support_features_sum"])) < 1e-2
