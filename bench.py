@@ -3,8 +3,10 @@
 
     python bench.py --gpus N --steps K --warmup W [--workload pipeline|hpe|ar]
 
-One process per GPU (the driver launches N>1 through torch.distributed.run; RANK / LOCAL_RANK /
-WORLD_SIZE / MASTER_* come from the environment, backend "nccl" = RCCL).  A step is one pass
+One process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment when launched through
+torch.distributed.run, backend "nccl" = RCCL). Started plainly with --gpus N > 1, this process does not touch the
+GPU: it starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD, forwards its output and
+exits with its return code; a WORLD_SIZE that disagrees with --gpus is an error (exit 2), never a silent N=1 run.  A step is one pass
 of the hot path over one batch of synthetic input already resident in HBM.  Units shard
 across ranks with no data-path collective (weak scaling: per-GPU batch fixed); the only
 collective is the all-gather of per-window results, inside the timed region for N>1.
@@ -38,8 +40,28 @@ def parse():
     ap.add_argument("--way", type=int, default=60)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=0)
+    ap.add_argument("--cpu-sample", type=int, default=0, help="items per CPU-baseline iteration (0 = the workload's default)")
+    ap.add_argument("--cpu-iters", type=int, default=10, help="timed CPU-baseline iterations (median reported; BASELINE.md 4)")
     return ap.parse_args()
+
+
+def self_launch(args) -> int:
+    """--gpus N > 1 without a torchrun environment: run the N ranks as a child torch.distributed.run job.
+    Nothing in THIS process has touched the GPU (a process that has must never exec another program on this pool, and
+    needs not: the child is an ordinary subprocess whose stdout -- the one JSON line of its rank 0 -- is ours)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:                     # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env["ISB_BENCH_CHILD"] = "1"
+    print(f"bench.py: launching {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
 
 
 # --------------------------------------------------------------------------------------------
@@ -104,22 +126,24 @@ class ArWorkload:
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                 "avg_launch_ms": round(ms / max(launches, 1), 4), "launches": int(launches)}
 
-    def cpu_baseline(self, sample):
+    def cpu_baseline(self, sample, iters=10):
         from oracle.ar_oracle import TRXOSOracle
         import torch
-        n = sample or 128
-        from bench_workloads import usable_cores
+        from bench_workloads import ar_parity, median_time, usable_cores
+        n = sample or 16
         cores = usable_cores()
         torch.set_num_threads(cores)
         net = TRXOSOracle(self.state, self.L, self.J)
         sf = net.mlp(self.ss)
-        net.forward(None, self.way, self.q_host[:2], ss_features=sf)   # warm-up
-        t0 = time.perf_counter()
-        net.forward(None, self.way, self.q_host[:n], ss_features=sf)
-        dt = time.perf_counter() - t0
-        return {"value": round(n / dt, 3), "unit": "windows/s", "cores": cores, "kind": "port",
-                "sample": f"{n} windows of {self.L}x{self.J} joints vs {self.way} classes, numpy oracle "
-                          f"(support features cached), {dt:.1f} s"}
+        q = self.q_host[:n]
+        ref = {}
+        med, total = median_time(lambda: ref.update(net.forward(None, self.way, q, ss_features=sf)), warm=1, iters=iters)
+        # the parity half of the metric: the GPU's answers for the SAME windows against what was just timed
+        logits, is_true, embed = self.eng.infer(q, want_embed=True)
+        self.parity = ar_parity(logits, is_true, embed, ref)
+        return {"value": round(n / med, 3), "unit": "windows/s", "cores": cores, "kind": "port",
+                "sample": f"median of {iters} passes over {n} windows of {self.L}x{self.J} joints vs {self.way} classes, numpy "
+                          f"oracle (support features cached), {total:.1f} s of CPU work"}
 
     def config(self, world):
         return {"workload": "BASELINE configs[2]: AR embed + tuple cross-attention match + open-set score, "
@@ -142,13 +166,15 @@ def main():
     args = parse()
     import torch
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))             # before ANY GPU call in this process
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        # launched without torchrun: re-launching is the driver's job; run the N=1 case
-        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE=1; run under torch.distributed.run", file=sys.stderr)
-        args.gpus = 1
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run as {args.gpus} GPUs",
+              file=sys.stderr)
+        raise SystemExit(2)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
     # rehearsal of the N > 1 code path on a ONE-GPU box: ISB_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
@@ -200,7 +226,14 @@ def main():
     barrier()
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = W.cpu_baseline(args.cpu_sample)
+        cpu = W.cpu_baseline(args.cpu_sample, max(1, args.cpu_iters))
+    devices = [f"cuda:{local}"]
+    if world > 1:
+        import torch.distributed as dist
+        world = dist.get_world_size()                    # what the process group says, not what the flags said
+        gathered = [None] * world
+        dist.all_gather_object(gathered, f"rank{rank}=cuda:{torch.cuda.current_device()}")
+        devices = gathered
 
     if rank == 0:
         units = W.units_per_step() * world * args.steps
@@ -210,6 +243,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": W.precision if hasattr(W, "precision") else "bf16", "data": "synthetic",
             "config": W.config(world), "roofline": roof, "cpu_baseline": cpu,
+            # error half of BASELINE.json's metric ("...; open-set score L2 vs ref"): GPU outputs against the CPU oracle
+            # on the cpu_baseline sample (same inputs); null when the CPU leg is skipped (N > 1, --no-cpu-baseline)
+            "parity": getattr(W, "parity", None),
+            "world_size": world, "devices": devices,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -36,6 +36,40 @@ def usable_cores() -> int:
     return max(1, n)
 
 
+def median_time(fn, warm: int = 3, iters: int = 10):
+    """BASELINE.md 4 protocol: `warm` untimed passes, then the MEDIAN wall time of `iters` timed ones.
+    Returns (median seconds per pass, total seconds spent)."""
+    t_all = time.perf_counter()
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), time.perf_counter() - t_all
+
+
+def _softmax(x):
+    e = np.exp(x - x.max(axis=-1, keepdims=True))
+    return e / e.sum(axis=-1, keepdims=True)
+
+
+def ar_parity(logits, is_true, embed, ref) -> dict:
+    """GPU outputs vs the oracle's for the same windows: max-abs of logits / class probabilities / embedding, max-abs
+    and L2 (root of the summed squares over the sample) of the open-set score."""
+    logits, is_true = np.asarray(logits, np.float64), np.asarray(is_true, np.float64).reshape(-1)
+    rt = np.asarray(ref["is_true"], np.float64).reshape(-1)
+    out = {"n_windows": int(logits.shape[0]),
+           "logits_maxabs": float(np.abs(logits - ref["logits"]).max()),
+           "probs_maxabs": float(np.abs(_softmax(logits) - _softmax(np.asarray(ref["logits"], np.float64))).max()),
+           "is_true_maxabs": float(np.abs(is_true - rt).max()),
+           "is_true_l2": float(np.sqrt(((is_true - rt) ** 2).sum()))}
+    if embed is not None:
+        out["embed_maxabs"] = float(np.abs(np.asarray(embed, np.float64) - ref["query_features"]).max())
+    return out
+
+
 def igemm_macs_per_crop() -> int:
     """MACs executed by conv_igemm_kernel per crop (all 3x3/1x1 convs except the f32 stem)."""
     m = 0
@@ -90,7 +124,9 @@ class _HpeBase:
                 "avg_launch_ms": round(ms / max(launches, 1), 5), "launches": int(launches),
                 "flops_per_step": flops / steps}
 
-    def _cpu_hpe_seconds_per_frame(self, n):
+    def _cpu_hpe(self, n, iters):
+        """The fp32 pose oracle on the first n frames of this rank's batch: (median seconds per frame, total seconds,
+        parity of the GPU's poses for the same frames against the poses the timed oracle produced)."""
         from oracle import hpe_oracle as ho
         from oracle.effnetv2_oracle import EffNetV2LOracle
         import torch
@@ -98,14 +134,28 @@ class _HpeBase:
         K = ho.intrinsics_matrix(384.025146484375, 384.025146484375, 319.09661865234375, 237.75723266601562)
         net = EffNetV2LOracle(self.bb_state, "f32")
         W = np.load(os.path.join(_ASSETS, "32_to_122.npy"))
-        t0 = time.perf_counter()
-        for i in range(n):
-            j = i % len(self.frames_host)
-            nk, r, H = ho.crop_params(self.bbox_host[j], K)
-            crop = ho.warp(self.frames_host[j], H[0])
-            lg = net.head(net.backbone(crop[None]))
-            ho.postprocess(lg, nk, r, W, None)
-        return (time.perf_counter() - t0) / n
+        n = min(n, len(self.frames_host))
+        poses = [None] * n
+
+        def one_pass():
+            for j in range(n):
+                nk, r, H = ho.crop_params(self.bbox_host[j], K)
+                crop = ho.warp(self.frames_host[j], H[0])
+                lg = net.head(net.backbone(crop[None]))
+                poses[j] = ho.postprocess(lg, nk, r, W, None)
+
+        med, total = median_time(one_pass, warm=1, iters=iters)
+        joints, valid = self.hpe.forward(self.frames_host[:n], self.bbox_host[:n])
+        ok = [j for j in range(n) if poses[j] is not None and valid[j]]
+        par = {"n_frames": n, "valid_agree": bool(all((poses[j] is not None) == bool(valid[j]) for j in range(n)))}
+        if ok:
+            ref = np.stack([poses[j] for j in ok])
+            g = joints[ok].astype(np.float64)
+            # root-centred pose = what the AR stage consumes (main.py:103); absolute = what estimate() returns
+            par["joints_rootcentred_maxabs"] = float(np.abs((g - g[:, :1]) - (ref - ref[:, :1])).max())
+            par["joints_maxabs"] = float(np.abs(g - ref).max())
+            par["joints_l2_per_frame"] = float(np.sqrt(((g - ref) ** 2).sum(axis=(1, 2))).max())
+        return med / n, total, par
 
 
 class HpeWorkload(_HpeBase):
@@ -126,12 +176,12 @@ class HpeWorkload(_HpeBase):
     def roofline(self, steps):
         return self._hpe_roofline(steps)
 
-    def cpu_baseline(self, sample):
-        n = sample or 128                # ~12 s on the box's 16 host cores
-        self._cpu_hpe_seconds_per_frame(1)
-        spf = self._cpu_hpe_seconds_per_frame(n)
+    def cpu_baseline(self, sample, iters=10):
+        n = sample or 8                  # HPE batch 8; ~0.8 s per pass on the box's 16 host cores
+        spf, total, self.parity = self._cpu_hpe(n, iters)
         return {"value": round(1.0 / spf, 3), "unit": "frames/s", "cores": usable_cores(), "kind": "port",
-                "sample": f"{n} frames through the fp32 CPU oracle (numpy geometry + torch-CPU EfficientNetV2-L), {spf * n:.1f} s"}
+                "sample": f"median of {iters} passes over {n} frames through the fp32 CPU oracle (numpy geometry + torch-CPU "
+                          f"EfficientNetV2-L), {total:.1f} s of CPU work"}
 
     def config(self, world):
         return {"workload": f"BASELINE configs[1]: B={self.B} synthetic 640x480 frames/GPU, HPE only "
@@ -201,21 +251,23 @@ class PipelineWorkload(_HpeBase):
     def roofline(self, steps):
         return self._hpe_roofline(steps)
 
-    def cpu_baseline(self, sample):
+    def cpu_baseline(self, sample, iters=10):
         from oracle.ar_oracle import TRXOSOracle
-        n = sample or 96                 # ~9 s of pose oracle + ~8 s of AR oracle on 16 host cores
-        self._cpu_hpe_seconds_per_frame(1)
-        spf = self._cpu_hpe_seconds_per_frame(n)
+        n = sample or 8                  # per pass: 8 frames (~0.8 s) and 8 windows (~0.7 s) on 16 host cores
+        spf, t_hpe, par = self._cpu_hpe(n, iters)
         net = TRXOSOracle(self.ar_state, self.L, self.J)
         sf = net.mlp(self.ss)
-        q = synth.skeleton_windows(96 if n >= 96 else 32, self.L, self.J, seed=9)
-        net.forward(None, self.way, q[:2], ss_features=sf)
-        t0 = time.perf_counter()
-        net.forward(None, self.way, q, ss_features=sf)
-        spw = (time.perf_counter() - t0) / len(q)
+        q = synth.skeleton_windows(n, self.L, self.J, seed=9)
+        ref = {}
+        med, t_ar = median_time(lambda: ref.update(net.forward(None, self.way, q, ss_features=sf)), warm=1, iters=iters)
+        spw = med / len(q)
+        logits, is_true, embed = self.ar.infer(q, want_embed=True)
+        par.update(ar_parity(logits, is_true, embed, ref))
+        self.parity = par
         return {"value": round(1.0 / (spf + spw), 3), "unit": "pipelines/s", "cores": usable_cores(), "kind": "port",
-                "sample": f"{n} frames through the fp32 pose oracle ({spf * 1e3:.0f} ms/frame) + {len(q)} windows through "
-                          f"the AR oracle ({spw * 1e3:.0f} ms/window); pipelines/s = 1/(sum)"}
+                "sample": f"median of {iters} passes: {n} frames through the fp32 pose oracle ({spf * 1e3:.0f} ms/frame) + "
+                          f"{len(q)} windows through the AR oracle ({spw * 1e3:.0f} ms/window); pipelines/s = 1/(sum); "
+                          f"{t_hpe + t_ar:.1f} s of CPU work"}
 
     def config(self, world):
         return {"workload": f"BASELINE configs[3] per-GPU shard: {self.B} synthetic 640x480 frames/GPU "
@@ -309,8 +361,8 @@ class StreamWorkload(_HpeBase):
         r.update(extra)
         return r
 
-    def cpu_baseline(self, sample):
-        return PipelineWorkload.cpu_baseline(self, sample or 48)
+    def cpu_baseline(self, sample, iters=10):
+        return PipelineWorkload.cpu_baseline(self, sample or 4, iters)
 
     def config(self, world):
         return {"workload": "BASELINE configs[4]: 1 camera feed per GPU, per-frame step = HPE (1 frame, 122 joints) + AR on the "

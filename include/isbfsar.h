@@ -18,6 +18,11 @@
  *     PyTorch's default stream is).  Calls are asynchronous on that stream unless documented
  *     otherwise; the *_host variants run on a private stream and synchronise before returning.
  *   - a handle is bound to one device and is not thread safe: one handle per process / rank.
+ *   - ONE STREAM PER HANDLE AT A TIME: a handle owns one set of activation / tuple workspaces, ordered only by
+ *     the stream a call is issued on. Calls on the same handle from two streams race on those buffers; to move a
+ *     handle to another stream, make the new stream wait on the old one's work first (event or synchronise).
+ *     Different handles are independent and may run on different streams concurrently. isb_hpe_forward forks
+ *     internally onto private lane streams and joins back into `stream` before it returns to the caller's order.
  */
 #ifndef ISBFSAR_H
 #define ISBFSAR_H
@@ -119,7 +124,9 @@ typedef struct isb_hpe_cfg {
     float fx, fy, ppx, ppy;   /* RealSenseIntrinsics (utils/params.py:40-47) -> K, hpe.py:28-33 */
     int32_t width, height;    /* frame size (640 x 480) */
     int32_t device;           /* HIP device ordinal */
-    int32_t max_batch;        /* frames per internal micro-batch (activation workspace); 0 = 64 */
+    int32_t max_batch;        /* frames per internal micro-batch (activation workspace); 0 = 64; clamped to 1024: the
+                               * convolution kernels address a tensor with 32-bit byte offsets and the largest activation
+                               * is 2 MiB per frame. Any B is accepted by isb_hpe_forward (it micro-batches). */
     int32_t n_out_joints;     /* informational: joints per pose after selection (30 / 122) */
     int32_t reserved;
 } isb_hpe_cfg;
@@ -219,6 +226,7 @@ int isb_debug_dwconv(int32_t device, const uint16_t* h_x, const float* h_w, cons
  * flatten to 3J and cut sliding windows of L consecutive frames per camera.
  *   d_joints  [n_cam, n_frames, J, 3] f32
  *   d_windows [n_cam * (n_frames - L + 1), L, 3J] f32   (camera-major, oldest frame first)
+ * No handle: the launch goes to the device that owns d_joints (hipPointerGetAttributes).
  * ---------------------------------------------------------------------------------------- */
 int isb_pose_windows(const float* d_joints, int32_t n_cam, int32_t n_frames, int32_t J, int32_t L,
                      float* d_windows, void* stream);

@@ -44,6 +44,7 @@ constexpr int kDiscMaxSplits = 32;
 int ensure_ws(isb_ar* h, int Bc) {
     if (Bc <= h->ws_B) return ISB_OK;
     const size_t B = Bc, L = h->L, nmax = h->cfg.way_max;
+    h->ws_B = 0;                  // failure-atomic: published again only after every allocation succeeded
     ISB_TRY(h->win.alloc(B * L * h->D3 * 4));
     ISB_TRY(h->h1.alloc(B * L * h->H * 4));
     ISB_TRY(h->qfeat.alloc(B * L * 256 * 4));
@@ -234,6 +235,8 @@ extern "C" int isb_ar_set_support(isb_ar* h, const float* poses, const float* fe
     ISB_REQUIRE(n >= 1 && n <= h->cfg.way_max, ISB_ERR_INVALID, "support size %d outside [1,%d]", n, h->cfg.way_max);
     ISB_HIP(hipSetDevice(h->cfg.device));
     hipStream_t st = h->own_stream;
+    h->support = false;           // failure-atomic: the caches below are being replaced; isb_ar_infer refuses the handle
+    h->n = 0;                     // until this call has succeeded
     const size_t rows = (size_t)n * h->L;
     ISB_TRY(h->s_feat.alloc(rows * 256 * 4));
     ISB_TRY(h->s_proj.alloc(rows * 512 * 4));

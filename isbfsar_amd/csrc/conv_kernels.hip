@@ -443,8 +443,9 @@ __device__ __forceinline__ void dma16_at(const void* gsrc, uint32_t lds_addr) { 
 }
 __device__ __forceinline__ void dma16(const void* gsrc, unsigned char* ldst) {
     const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_ptr_t)ldst);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(la) : "memory");   // m0 is reserved: the compiler
-    // writes it immediately before each of its own uses and keeps nothing live in it
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(la) : "memory");   // m0 is RESERVED on amdgcn:
+    // the compiler writes it immediately before each of its own uses and keeps nothing live in it across statements, so
+    // no clobber is declared (naming a reserved register in the clobber list is itself diagnosed as undefined behaviour)
 }
 
 

@@ -30,6 +30,7 @@ struct BlockW {
 struct StageDef { bool fused; int repeats, expand, stride, cin, cout; bool se; };
 constexpr int kMinSplit = 64;     // a batch this large is run as concurrent parts (>= 32 frames each)
 constexpr int kMaxLanes = 4;
+constexpr int kMaxMicroBatch = 1024;   // frames per micro-batch: keeps every activation tensor <= 2 GiB (32-bit byte offsets)
 const StageDef kStages[] = {
     {true, 4, 1, 1, 32, 32, false},   {true, 7, 4, 2, 32, 64, false},   {true, 7, 4, 2, 64, 96, false},
     {false, 10, 4, 2, 96, 192, true}, {false, 19, 6, 1, 192, 224, true}, {false, 25, 6, 2, 224, 384, true},
@@ -123,9 +124,20 @@ int upload_conv(const std::map<std::string, BlobTensor>& m, const std::string& p
     return ISB_OK;
 }
 
+// free functions (no handle): make the device that owns `dptr` current, like every handle-taking entry point does
+int set_device_of(const void* dptr) {
+    hipPointerAttribute_t at{};
+    ISB_HIP(hipPointerGetAttributes(&at, dptr));
+    ISB_REQUIRE(at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged, ISB_ERR_INVALID,
+                "pointer %p is not device memory", dptr);
+    ISB_HIP(hipSetDevice(at.device));
+    return ISB_OK;
+}
+
 int ensure_ws(Lane& L, int Bm) {
     if (Bm <= L.ws_B) return ISB_OK;
     const size_t B = Bm;
+    L.ws_B = 0;                   // failure-atomic: a failed allocation below leaves a lane that re-allocates on the next call
     ISB_TRY(L.H.alloc(B * 9 * 4));
     ISB_TRY(L.newK.alloc(B * 9 * 8));
     ISB_TRY(L.R.alloc(B * 9 * 8));
@@ -348,6 +360,9 @@ extern "C" int isb_hpe_create(const isb_hpe_cfg* cfg, isb_hpe** out) {
     ISB_REQUIRE(h, ISB_ERR_NOMEM, "out of host memory");
     h->cfg = *cfg;
     if (h->cfg.max_batch <= 0) h->cfg.max_batch = 64;
+    // per-lane micro-batch limit (isbfsar.h): the convolution kernels address a tensor with 32-bit byte offsets and the
+    // largest activation is 2 MiB per frame (64x64x256 bf16) -> 1024 frames = 2 GiB. Larger batches are micro-batched.
+    h->cfg.max_batch = std::min(h->cfg.max_batch, kMaxMicroBatch);
     // K as float32 values (hpe.py:28-33)
     h->K[0] = (double)cfg->fx; h->K[2] = (double)cfg->ppx; h->K[4] = (double)cfg->fy; h->K[5] = (double)cfg->ppy; h->K[8] = 1.0;
     ISB_HIP(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
@@ -707,6 +722,7 @@ extern "C" int isb_pose_windows(const float* d_joints, int32_t n_cam, int32_t n_
     ISB_REQUIRE(d_joints && d_windows, ISB_ERR_INVALID, "null argument");
     ISB_REQUIRE(n_cam >= 1 && J >= 1 && L >= 1 && n_frames >= L, ISB_ERR_INVALID,
                 "bad shape n_cam=%d n_frames=%d J=%d L=%d", n_cam, n_frames, J, L);
+    ISB_TRY(set_device_of(d_joints));         // no handle here: launch on the device that owns the buffers
     return launch_pose_windows(d_joints, n_cam, n_frames, J, L, d_windows, (hipStream_t)stream);
     });
 }

@@ -15,7 +15,8 @@ table below is the PUBLIC efficientnetv2-l configuration ("parity unpinned", SUR
     BN eps 1e-3 (folded to per-channel scale/shift), TF "SAME" padding (stride 2: pad bottom/right
     only), SE squeeze = max(1, int(block_in * 0.25)), residual when stride 1 and in == out.
 
-The same table exists in C++ (csrc/backbone.cpp) -- tests compare both through the blob names.
+The same table exists in C++ (csrc/hpe_api.cpp, kStages) -- isb_hpe_load_weights checks every blob tensor's
+shape against it, and tests/test_oracle_effnetv2.py checks this table against the published block strings.
 
 Blob tensor names (all f32; conv weights are [cout, kh, kw, cin], i.e. K-contiguous rows):
     bbone.stem.{w,scale,shift}
@@ -129,23 +130,39 @@ def tensor_shapes() -> "OrderedDict[str, Tuple[int, ...]]":
     return s
 
 
-def make_state(seed: int = 0) -> "OrderedDict[str, np.ndarray]":
+def make_state(seed: int = 0, profile: str = "default", head_gain: float = 4.0) -> "OrderedDict[str, np.ndarray]":
     """Deterministic synthetic weights that keep activations O(1) through all 79 blocks:
     activated convs get He-style gain, projections (no activation, added to the residual)
-    a small gain, folded-BN scale in [0.8,1.2] and shift in [-0.1,0.1]."""
+    a small gain, folded-BN scale in [0.8,1.2] and shift in [-0.1,0.1].
+
+    profile "default": every projection has gain 0.35. The six stage transitions (no identity skip) then shrink
+        the input-dependent part of the activations by 0.35 each while the BN shifts keep feeding O(0.1) in: the final
+        features barely depend on the frame (frame-to-frame difference 0.3 % of their magnitude) and the pose heatmaps
+        are flat. Fine for throughput, weak as a parity input.
+    profile "signal": projections of the transition blocks have gain 1.0, those of the residual blocks 0.1, shifts in
+        [-0.02, 0.02]: the activations keep a standard deviation of 1-3.5 through all stages, the final features
+        (std 1.1, max 10) differ between frames by as much as their own magnitude and the heatmaps are PEAKED (the
+        regime of a trained MetrABS). The parity tests of the pose stage use this profile."""
+    if profile not in ("default", "signal"):
+        raise ValueError(f"unknown weight profile {profile!r}")
+    sig = profile == "signal"
+    bl = {b.idx: b for b in blocks()}
     out: "OrderedDict[str, np.ndarray]" = OrderedDict()
     for name, shape in tensor_shapes().items():
         leaf = name.split(".")[-1]
         if leaf == "scale":
             out[name] = uniform(name, shape, 0.8, 1.2, seed)
         elif leaf in ("shift", "b1", "b2", "bias"):
-            out[name] = uniform(name, shape, -0.1, 0.1, seed)
+            sh = 0.02 if sig else 0.1
+            out[name] = uniform(name, shape, -sh, sh, seed)
         else:
             fan_in = int(np.prod(shape[1:]))
             if ".project." in name:
                 gain = 0.35
+                if sig:
+                    gain = 0.1 if bl[int(name.split(".")[1][1:])].residual else 1.0
             elif name == "head.weight":
-                gain = 4.0                 # spread the pose-head logits so heatmaps are not flat
+                gain = head_gain           # spread the pose-head logits so heatmaps are not flat
             elif ".se.w2" in name:
                 gain = 1.0
             else:

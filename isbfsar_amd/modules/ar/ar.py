@@ -34,6 +34,19 @@ def _to_tensor(x):
         return np.array(x, dtype=np.float32, copy=True)
 
 
+def _fingerprint(x):
+    if x is None:
+        return None
+    a = np.ascontiguousarray(_to_numpy(x))
+    try:
+        import xxhash
+        h = xxhash.xxh3_64_intdigest(a.data)
+    except ImportError:  # pragma: no cover
+        import zlib
+        h = zlib.crc32(a.data)
+    return (a.shape, h)
+
+
 def _load_state(args):
     w = getattr(args, "weights", None)
     if w is not None:
@@ -70,7 +83,11 @@ class ActionRecognizer:
 
     # ------------------------------------------------------------------------------------
     def _signature(self):
-        return tuple((k, id(v.get("poses")), id(v.get("features"))) for k, v in self.support_set.items())
+        """Content fingerprint of the support set (class order, names, and the bytes of every poses / features array):
+        what is on the device is keyed on WHAT the set holds, not on object identity -- in-place edits of
+        ``support_set[c]["poses"]``, a replaced dict (main.py:323) and recycled object ids are all seen.
+        xxh3 runs at >10 GB/s: ~20 us for the reference's 5 x [16,90] set, ~0.5 ms for 120 x [30,366]."""
+        return tuple((k, _fingerprint(v.get("poses")), _fingerprint(v.get("features"))) for k, v in self.support_set.items())
 
     def _sync_support(self):
         """(Re)install the device-side support cache when ``support_set`` changed (train/remove/

@@ -4,6 +4,7 @@ which needs a GPU), one all-gather of packed records, and the result must be BIT
 unsharded computation (no cross-rank arithmetic)."""
 import os
 import socket
+import sys
 
 import numpy as np
 import pytest
@@ -86,3 +87,28 @@ def test_sharded_equals_unsharded_gloo():
     ref_eq = np.concatenate([pack_records(*_compute(q[a:b])).numpy()
                              for a, b in (shard_range(6, r, world) for r in range(world))])
     assert np.array_equal(full_eq, ref_eq)
+
+
+def test_bench_refuses_a_world_size_that_disagrees_with_gpus():
+    """bench.py must never report an N-GPU line from a run with another world size (round-1 behaviour: a silent N=1)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 2 and "refusing" in r.stderr and "{" not in r.stdout
+
+
+def test_bench_self_launch_starts_a_child_job():
+    """Without a torchrun environment `--gpus 2` starts `python -m torch.distributed.run --nproc-per-node 2 bench.py ...`
+    as a CHILD process and returns its exit code. No GPU here: the ranks stop at "needs a GPU" and the launcher must
+    hand that failure through (non-zero), not print a line."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert "launching 2 ranks" in r.stderr and "--nproc-per-node=2" in r.stderr
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and "needs a GPU" in r.stderr and '"metric"' not in r.stdout

@@ -1,0 +1,237 @@
+"""GPU correctness of the two BASELINE configs that chain the stages (BASELINE.json configs[3] and configs[4]):
+
+  configs[3]  frames -> isb_hpe_forward (122 joints) -> isb_pose_windows -> isb_ar_infer (way 60), the per-GPU shard of the
+              full pipeline exactly as bench.py's `pipeline` workload runs it, against the oracle chain;
+  configs[4]  the streaming step (1 frame + 1 sliding window, 120-class support set) eager vs the oracle chain, and its
+              hipGraph replay against the eager step, bit for bit.
+
+Tolerances are the north star's 1e-3 on 3D joints (root-centred: what the AR stage consumes, main.py:103), embedding,
+class probabilities and open-set score. Stage hand-off: the AR oracle is fed the GPU's windows (so the comparison is
+of the AR stage on identical inputs) AND, end to end, the oracle's own windows."""
+import os
+
+import numpy as np
+import pytest
+
+from isbfsar_amd import effnetv2, synth, weights
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+L, J = 30, 122
+
+
+def _softmax(x):
+    e = np.exp(x - x.max(axis=-1, keepdims=True))
+    return e / e.sum(axis=-1, keepdims=True)
+
+
+def _K():
+    from oracle import hpe_oracle as ho
+    return ho.intrinsics_matrix(384.025146484375, 384.025146484375, 319.09661865234375, 237.75723266601562)
+
+
+@pytest.fixture(scope="module")
+def expand():
+    return np.load(os.path.join(ROOT, "isbfsar_amd", "assets", "32_to_122.npy"))
+
+
+@pytest.fixture(scope="module")
+def bb_state():
+    return effnetv2.make_state(0)
+
+
+def _oracle_poses(bb_state, expand, frames, boxes):
+    from oracle import hpe_oracle as ho
+    from oracle.effnetv2_oracle import EffNetV2LOracle
+    net = EffNetV2LOracle(bb_state, "bf16")
+    out = []
+    for f, b in zip(frames, boxes):
+        nk, r, H = ho.crop_params(b, _K())
+        pose = ho.postprocess(net.head(net.backbone(ho.warp(f, H[0])[None])), nk, r, expand, None)
+        assert pose is not None
+        out.append(pose)
+    return np.stack(out)                                  # [n,122,3] f64
+
+
+def test_config3_full_pipeline_vs_oracle_chain(bb_state, expand):
+    """8 cameras x (29 + 3) frames = 256 frames (one GPU's shard of configs[3]) -> 122-joint poses -> 30-deep windows
+    (3 per camera) -> AR vs 60 classes. The oracle chain runs for two of the cameras (64 frames, 6 windows)."""
+    import torch
+    from isbfsar_amd.engine import ArEngine
+    from isbfsar_amd.hpe_engine import HpeEngine, pose_windows
+    from oracle.ar_oracle import TRXOSOracle
+    n_cam, n_fr, way = 8, L - 1 + 3, 60
+    B = n_cam * n_fr
+    frames = synth.frames(B, seed=6000)
+    boxes = synth.bboxes(B, seed=6000)
+    hpe = HpeEngine(device=0, max_batch=256)
+    ar_state = weights.make_ar_state(L, J, seed=1)
+    ss = synth.skeleton_windows(way, L, J, seed=101)
+    ar = ArEngine(L, J, way, device=0, precision="bf16", max_batch=64)
+    try:
+        hpe.load_weights(bb_state)
+        hpe.set_joint_map(expand, None)
+        ar.load_weights(ar_state)
+        ar.set_support(poses=ss)
+        joints, valid = hpe.forward(torch.from_numpy(frames).cuda(), torch.from_numpy(boxes).cuda())   # camera-major
+        assert bool(valid.all().item())
+        windows = pose_windows(joints.view(n_cam, n_fr, J, 3), L)            # [n_cam*3, L, 3J]
+        logits, is_true, embed = ar.infer(windows, want_embed=True)
+        torch.cuda.synchronize()
+        joints, windows = joints.cpu().numpy().reshape(n_cam, n_fr, J, 3), windows.cpu().numpy()
+        logits, is_true, embed = logits.cpu().numpy(), is_true.cpu().numpy(), embed.cpu().numpy()
+    finally:
+        hpe.close()
+        ar.close()
+    assert windows.shape == (n_cam * 3, L, 3 * J) and logits.shape == (n_cam * 3, way)
+    net = TRXOSOracle(ar_state, L, J)
+    sf = net.mlp(ss)
+    # (i) the match stage on the GPU's own windows, every camera: same inputs -> 1e-3 on everything
+    ref = net.forward(None, way, windows, ss_features=sf)
+    np.testing.assert_allclose(embed, ref["query_features"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(_softmax(logits), _softmax(ref["logits"]), rtol=0, atol=1e-3)
+    np.testing.assert_allclose(is_true, ref["is_true"][:, 0], rtol=0, atol=1e-3)
+    # (ii) end to end for cameras 0 and 5: oracle poses -> oracle windows -> oracle match
+    for cam in (0, 5):
+        sl = slice(cam * n_fr, (cam + 1) * n_fr)
+        poses = _oracle_poses(bb_state, expand, frames[sl], boxes[sl])
+        rc_ref = poses - poses[:, :1]
+        rc_gpu = joints[cam] - joints[cam][:, :1]
+        e_pose = float(np.abs(rc_gpu - rc_ref).max())
+        win_ref = np.stack([rc_ref[k:k + L].reshape(L, 3 * J) for k in range(3)]).astype(np.float32)   # main.py:103-105, ar.py:42-50
+        np.testing.assert_allclose(windows[cam * 3:cam * 3 + 3], win_ref, rtol=0, atol=1e-3)
+        r2 = net.forward(None, way, win_ref, ss_features=sf)
+        e_emb = float(np.abs(embed[cam * 3:cam * 3 + 3] - r2["query_features"]).max())
+        e_prob = float(np.abs(_softmax(logits[cam * 3:cam * 3 + 3]) - _softmax(r2["logits"])).max())
+        e_true = float(np.abs(is_true[cam * 3:cam * 3 + 3] - r2["is_true"][:, 0]).max())
+        print(f"configs[3] camera {cam}: |d pose_rc|={e_pose:.2e} |d embed|={e_emb:.2e} |d prob|={e_prob:.2e} |d is_true|={e_true:.2e}")
+        assert e_pose < 1e-3 and e_emb < 1e-3 and e_prob < 1e-3 and e_true < 1e-3
+
+
+class _StreamStep:
+    """bench_workloads.StreamWorkload's step, restated for the test: one frame -> pose -> ring of the last 30 poses ->
+    one window -> match against 120 classes; every buffer is allocated up front so that the step can be captured."""
+
+    def __init__(self, bb_state, expand, way=120):
+        import torch
+        from isbfsar_amd.engine import ArEngine
+        from isbfsar_amd.hpe_engine import HpeEngine
+        self.torch = torch
+        self.way = way
+        self.hpe = HpeEngine(device=0, max_batch=1)
+        self.hpe.load_weights(bb_state)
+        self.hpe.set_joint_map(expand, None)
+        self.ar_state = weights.make_ar_state(L, J, seed=1)
+        self.ss = synth.skeleton_windows(way, L, J, seed=101)
+        self.ar = ArEngine(L, J, way, device=0, precision="bf16", max_batch=1)
+        self.ar.load_weights(self.ar_state)
+        self.ar.set_support(poses=self.ss)
+        self.hist = synth.skeleton_windows(1, L, J, seed=777).reshape(1, L, J, 3)
+        self.ring = torch.from_numpy(self.hist).cuda().contiguous()
+        self.frame = torch.zeros((1, 480, 640, 3), dtype=torch.uint8, device="cuda")
+        self.bbox = torch.zeros((1, 4), dtype=torch.int32, device="cuda")
+        self.out = None
+
+    def step(self):
+        from isbfsar_amd.hpe_engine import pose_windows
+        joints, valid = self.hpe.forward(self.frame, self.bbox)
+        self.ring.copy_(self.torch.cat([self.ring[:, 1:], joints.view(1, 1, J, 3)], dim=1))
+        windows = pose_windows(self.ring, L)
+        logits, is_true, embed = self.ar.infer(windows, want_embed=True)
+        self.out = (joints, valid, logits, is_true, embed)
+
+    def feed(self, frame, box):
+        self.frame.copy_(self.torch.from_numpy(frame[None]).cuda())
+        self.bbox.copy_(self.torch.from_numpy(box[None]).cuda())
+
+    def result(self):
+        self.torch.cuda.synchronize()
+        return [t.cpu().numpy().copy() for t in self.out]
+
+    def close(self):
+        self.hpe.close()
+        self.ar.close()
+
+
+def test_config4_streaming_step_eager_vs_oracle_and_hipgraph_replay(bb_state, expand):
+    """configs[4]: per-frame step against a 120-class support set. (a) eager steps vs the oracle chain (pose of the new
+    frame, window, probabilities, open-set score); (b) the step captured in ONE hipGraph and replayed on new frames
+    gives the eager step's outputs bit for bit."""
+    import torch
+    from oracle.ar_oracle import TRXOSOracle
+    n_steps = 4
+    frames = synth.frames(n_steps, seed=8100)
+    boxes = synth.bboxes(n_steps, seed=8100)
+    eager = _StreamStep(bb_state, expand)
+    graph = _StreamStep(bb_state, expand)
+    try:
+        # --- eager reference run
+        e_out = []
+        for t in range(n_steps):
+            eager.feed(frames[t], boxes[t])
+            eager.step()
+            e_out.append(eager.result())
+        # --- capture one step (after a warm-up that allocates every workspace), then replay it on the same frames
+        graph.feed(frames[0], boxes[0])
+        graph.step()
+        torch.cuda.synchronize()
+        graph.ring.copy_(torch.from_numpy(graph.hist).cuda())          # rewind the ring to the start state
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            graph.feed(frames[0], boxes[0])
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=s):
+                graph.step()
+        torch.cuda.synchronize()
+        graph.ring.copy_(torch.from_numpy(graph.hist).cuda())          # capture does not execute: start state again
+        for t in range(n_steps):
+            graph.feed(frames[t], boxes[t])
+            torch.cuda.synchronize()
+            g.replay()
+            r = graph.result()
+            for a, b, what in zip(r, e_out[t], ("joints", "valid", "logits", "is_true", "embed")):
+                assert np.array_equal(a, b), f"hipGraph replay differs from the eager step in {what} at step {t}"
+        # --- eager vs the oracle chain
+        net = TRXOSOracle(eager.ar_state, L, J)
+        sf = net.mlp(eager.ss)
+        ring = eager.hist[0].astype(np.float64)                         # [L,J,3]
+        for t in range(n_steps):
+            joints, valid, logits, is_true, embed = e_out[t]
+            assert valid[0] == 1 and logits.shape == (1, 120)
+            pose = _oracle_poses(bb_state, expand, frames[t:t + 1], boxes[t:t + 1])[0]
+            e_pose = float(np.abs((joints[0] - joints[0][0]) - (pose - pose[0])).max())
+            ring = np.concatenate([ring[1:], pose[None]])
+            win = (ring - ring[:, :1]).reshape(1, L, 3 * J).astype(np.float32)
+            ref = net.forward(None, 120, win, ss_features=sf)
+            e_emb = float(np.abs(embed - ref["query_features"]).max())
+            e_prob = float(np.abs(_softmax(logits) - _softmax(ref["logits"])).max())
+            e_true = float(np.abs(is_true - ref["is_true"][:, 0]).max())
+            print(f"configs[4] step {t}: |d pose_rc|={e_pose:.2e} |d embed|={e_emb:.2e} |d prob|={e_prob:.2e} |d is_true|={e_true:.2e}")
+            assert e_pose < 1e-3 and e_emb < 1e-3 and e_prob < 1e-3 and e_true < 1e-3
+    finally:
+        eager.close()
+        graph.close()
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment must start two ranks by itself (as a child
+    torch.distributed.run job) and report n_gpus 2. Rehearsed on this one-GPU box with both ranks on cuda:0 over gloo
+    (ISB_BENCH_ONE_DEVICE / ISB_BENCH_BACKEND are test switches; the driver's 8-GPU runs use RCCL)."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(ISB_BENCH_ONE_DEVICE="1", ISB_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--workload", "ar", "--batch", "64"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["world_size"] == 2 and len(line["devices"]) == 2
+    assert line["value"] > 0 and line["cpu_baseline"] is None and line["parity"] is None
+    # a WORLD_SIZE that disagrees with --gpus is refused, never reported as the requested size
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                        env=env2, capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 2 and "refusing" in r2.stderr
