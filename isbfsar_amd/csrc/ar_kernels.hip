@@ -245,7 +245,8 @@ __global__ __launch_bounds__(512, 2) void ar_stats_kernel(ArStatsArgs p) {
     // 1-D grid decoded per XCD (workgroup id % 8 = XCD) into blocks of STATS_WT windows x STATS_ST slot groups, slot
     // groups fastest: the block's Kq tiles (0.9 MiB) and class K fragments (1 MiB) are reused out of that XCD's L2
     const int id = blockIdx.x, xcd = id & 7, sl = id >> 3;
-    const int nsg = (p.n * p.NT + 7) >> 3;                          // groups of 8 (class, j-tile) slots
+    const int ncls = p.chosen ? 1 : p.n;                            // chosen mode: one class per window, chosen[b]
+    const int nsg = (ncls * p.NT + 7) >> 3;                         // groups of 8 (class, j-tile) slots
     const int nsb = (nsg + STATS_ST - 1) / STATS_ST;
     const int blk = sl / (p.wt * STATS_ST), within = sl - blk * (p.wt * STATS_ST);
     const int wbi = blk / nsb, sb = blk - wbi * nsb;
@@ -253,8 +254,9 @@ __global__ __launch_bounds__(512, 2) void ar_stats_kernel(ArStatsArgs p) {
     const int b = ((wbi * p.wt + within / STATS_ST) << 3) + xcd;
     if (sg >= nsg || b >= p.B) return;
     const int slot = sg * 8 + wave;
-    const bool active = slot < p.n * p.NT;
-    const int c = active ? slot / p.NT : 0, jt = active ? slot % p.NT : 0;
+    const bool active = slot < ncls * p.NT;
+    const int cidx = active ? slot / p.NT : 0, jt = active ? slot % p.NT : 0;     // class index inside lse2
+    const int c = p.chosen ? p.chosen[b] : cidx;                                   // class whose K fragments are read
     const int Tp = p.NT * 32;
 
     bf16x8 a_hi[8], a_lo[8];
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(512, 2) void ar_stats_kernel(ArStatsArgs p) {
         if (r == 0) {
 #pragma unroll
             for (int i = 0; i < 16; ++i)
-                p.lse2[((size_t)b * p.n + c) * Tp + jt * 32 + acc_row(i, h)] = ubr[i] + log2f(rs[i] + other[i]);
+                p.lse2[((size_t)b * ncls + cidx) * Tp + jt * 32 + acc_row(i, h)] = ubr[i] + log2f(rs[i] + other[i]);
         }
         return;
     }
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(512, 2) void ar_stats_kernel(ArStatsArgs p) {
                 l += lo;
             }
         }
-        if (r == 0) p.lse2[((size_t)b * p.n + c) * Tp + jt * 32 + acc_row(i, h)] = m + log2f(l);
+        if (r == 0) p.lse2[((size_t)b * ncls + cidx) * Tp + jt * 32 + acc_row(i, h)] = m + log2f(l);
     }
 }
 
@@ -385,7 +387,8 @@ int launch_ar_stats(const ArStatsArgs& a0, hipStream_t st) {
     ArStatsArgs a = a0;
     const bool online = a.online != 0;
     a.wt = std::min(STATS_WT, cdiv(a.B, 8));      // a few windows (the live loop): no grid padding to a full L2 block
-    dim3 grid(8 * cdiv(cdiv(a.B, 8), a.wt) * cdiv(cdiv(a.n * a.NT, 8), STATS_ST) * (a.wt * STATS_ST));
+    const int ncls = a.chosen ? 1 : a.n;
+    dim3 grid(8 * cdiv(cdiv(a.B, 8), a.wt) * cdiv(cdiv(ncls * a.NT, 8), STATS_ST) * (a.wt * STATS_ST));
     if (a.x3) {
         if (online) hipLaunchKernelGGL((ar_stats_kernel<true, true>), grid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((ar_stats_kernel<true, false>), grid, dim3(512), 0, st, a);
@@ -455,7 +458,7 @@ __global__ __launch_bounds__(512, 2) void ar_proto_kernel(ArProtoArgs p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) pacc[dt][i] = 0.f;
 
-    const float* lse_row = p.lse2 + ((size_t)b * p.n + c) * Tp + 4 * h;
+    const float* lse_row = p.lse2 + (p.lse_per_window ? (size_t)b : (size_t)b * p.n + c) * Tp + 4 * h;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) { ISB_PIN(q_hi[ks]); if (X3) ISB_PIN(q_lo[ks]); }
 

@@ -19,6 +19,7 @@
 // BN*2+16 B: conflict-free 8-byte writes) and leaves as full 16-byte pieces.
 #include <algorithm>
 #include <type_traits>
+#include <utility>
 
 #include "isb_common.h"
 #include "kernels.h"
@@ -909,6 +910,196 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_dma_kernel(ConvArgs p)
 }
 
 // -------------------------------------------------------------------------------------------
+// Weights-stationary 1x1 GEMM for the MBConv expand convolutions with a SHORT K (Cin = 96 / 192 / 224 / 384: 3 - 12
+// k-steps). What the tile kernels above pay for on these layers is not arithmetic: a 128 x 192 tile has 42 MFMAs per
+// wave (K = 224), and around them a prologue (first-tile latency), 20 KiB of operand DMA + 64 KiB of LDS fragment reads
+// per k-step (three quarters of both are WEIGHTS, re-fetched by every M tile), a barrier per k-step, and an epilogue of
+// ~1600 vector-issue cycles per wave (SiLU: two quarter-rate transcendentals per element) during which the matrix pipes
+// idle. Measured (round 2, 224 -> 1344 at 256 frames): 75 us = 529 TFLOP/s, 21 % of peak.
+// Here ONE persistent workgroup of 6 waves per CU owns a slice of 192 output channels for its whole life:
+//   * wave w keeps the weights of its 32 channels for ALL of K in registers as MFMA A-operand fragments (K / 4 VGPRs):
+//     the weights never touch LDS -- no weight DMA, no weight fragment reads, no weight re-fetch per tile;
+//   * the activations arrive as whole 96-row M tiles (96 x K bf16, 18 - 72 KiB) in two LDS buffers by LDS-DMA: tile j + 1
+//     travels while tile j is consumed, so there is no prologue per tile and ONE barrier per tile (A is re-read
+//     Cout / 192 times in all, out of the XCD's L2: neighbouring workgroup ids walk the same tile sequence);
+//   * between two barriers a wave runs its 6 NK MFMAs back to back (6 ds_read_b128 per k-step) and its epilogue (bias,
+//     SiLU, one bf16 rounding, wave-local staging of a 32 x 32 block, 16-byte stores) with no synchronisation at all;
+//   * the two waves that share a SIMD (w and w + 4: waves go to the SIMDs in the order 0, 2, 1, 3, 0, 2) run these two
+//     phases in OPPOSITE order -- waves 0-3 multiply tile j and then finish it, waves 4-5 first finish tile j - 1 and then
+//     multiply tile j -- so one wave's vector work (the SiLU epilogue) runs beside the other's matrix work on the same
+//     SIMD. (In-kernel s_memtime stamps of the first, per-k-step-barrier form: k loop 4900 cycles, epilogue 2650, and
+//     1850 more at the next barrier waiting for the slowest epilogue: every wave of the CU sat in the same phase.)
+// LDS-DMA completion is tracked with a counted s_waitcnt vmcnt: per tile a wave issues its NK pieces of the NEXT tile and
+// then, in either phase order, 6 stores; when the next tile is needed exactly those 6 stores are younger: vmcnt(6).
+// Stores are never masked (rows past M are clamped onto row M - 1, whose values they repeat) and waves 4-5 issue six
+// dummy pieces where the stores of the tile "before the first" would sit, so the count is exact from the first tile on.
+// Sums run in the k order of gemm1x1_dma_kernel and bias / SiLU / rounding are the same code: bit-identical results.
+// -------------------------------------------------------------------------------------------
+constexpr int WS_BM = 96, WS_BN = 192, WS_NW = 6;
+constexpr int WS_CHUNK = WS_BM * ROWB;                   // 6 KiB: 96 rows x 32 channels
+constexpr int WS_NS = 6;                                 // global stores per wave and tile (3 row blocks x 2)
+constexpr int WS_SROW = 80;                              // staging row: 64 B + 16 (8-byte writes spread over the banks)
+constexpr int WS_STAGE = 32 * WS_SROW;
+constexpr int ws_lds_bytes(int nk) { return 2 * nk * WS_CHUNK + WS_NW * WS_STAGE + 1024; }
+
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int NK, bool ACT, bool STAMPS = false>
+__global__ __launch_bounds__(64 * WS_NW, 2) void gemm1x1_wsreg_kernel(ConvArgs p) {
+    constexpr int K = 32 * NK;
+    constexpr int TILE = NK * WS_CHUNK;                  // one M tile, chunk (k-step) major
+    constexpr int STAGE_OFF = 2 * TILE, DUMP_OFF = STAGE_OFF + WS_NW * WS_STAGE;
+    unsigned char* const lds = conv_lds_dyn;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    // workgroup -> (sequence of M tiles, slice of 192 channels). Workgroup ids go round-robin over the XCDs, so id % 8
+    // names an XCD; in XCD-major order consecutive workgroups are the slices of one sequence: they read the same
+    // activation rows at the same time, out of that XCD's L2 (placement is for speed only)
+    const int nsl = p.grid_n, Q = p.grid_m;              // slices; tile sequences
+    const int g = blockIdx.x, idx = (g & 7) * (gridDim.x >> 3) + (g >> 3);
+    const int q = idx / nsl, slice = idx - q * nsl;
+    const int n_mt = (p.M + WS_BM - 1) / WS_BM;
+    if (q >= Q || q >= n_mt) return;
+    const int nw0 = slice * WS_BN + 32 * wave;
+    const bool late = wave >= 4;                         // the SIMD partners of waves 0 and 1: epilogue first, then multiply
+
+    // the wave's weights, all of K, as A-operand fragments: lane (r, h) holds channel nw0 + r, k = 16 ks + 8 h .. + 7
+    bf16x8 bfr[2 * NK];
+    {
+        const uint16_t* wrow = p.w + (size_t)(nw0 + r) * K + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 2 * NK; ++ks) bfr[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wrow + 16 * ks));
+    }
+    float4 bias4[4];
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) bias4[qq] = *reinterpret_cast<const float4*>(p.bias + nw0 + 8 * qq + 4 * h);
+    // the compiler's own waits for these ordinary loads must happen HERE, before any asm DMA is in flight (it does not
+    // see them in its vmcnt model)
+#pragma unroll
+    for (int ks = 0; ks < 2 * NK; ++ks) asm volatile("" ::"v"(bfr[ks]));
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) asm volatile("" ::"v"(bias4[qq].x), "v"(bias4[qq].y), "v"(bias4[qq].z), "v"(bias4[qq].w));
+
+    // activation pieces: wave w fills rows 16 w .. 16 w + 15 of every chunk; lane -> (row, swizzled 16-byte chunk)
+    const int rowl = 16 * wave + (lane >> 2);
+    const uint32_t lchunk = (uint32_t)(((lane & 3) ^ ((rowl >> 2) & 3)) * 16);
+    const uint32_t lds_a = (uint32_t)(uintptr_t)(lds_ptr_t)lds;
+    const uint32_t lds0 = lds_a + wave * 1024;
+    const unsigned char* a_bytes = reinterpret_cast<const unsigned char*>(p.in);
+    auto issue_tile = [&](int tile, int buf) {  // the wave's NK pieces of an M tile (past the last tile: row M - 1, never used)
+        const uint32_t voff = (uint32_t)min(tile * WS_BM + rowl, p.M - 1) * (uint32_t)(K * 2) + lchunk;
+#pragma unroll
+        for (int s = 0; s < NK; ++s) dma16_s(a_bytes + s * 64, voff, lds0 + (buf * TILE + s * WS_CHUNK));
+    };
+    unsigned char* const stage = lds + STAGE_OFF + wave * WS_STAGE;
+    uint16_t* const out16 = reinterpret_cast<uint16_t*>(p.out);
+    const int a_sw0 = swz(r, h), a_sw1 = swz(r, 2 + h);
+    f32x16 acc[3];
+
+    auto multiply = [&](int buf) {              // acc = tile (in LDS buffer buf) x the wave's weights
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+        const unsigned char* At = lds + buf * TILE;
+#pragma unroll
+        for (int s = 0; s < NK; ++s) {
+            bf16x8 af[2][3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                af[0][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(At + s * WS_CHUNK + a_sw0 + i * 2048));
+                af[1][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(At + s * WS_CHUNK + a_sw1 + i * 2048));
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[2 * s + ks], af[ks][i], acc[i], 0, 0, 0);
+        }
+    };
+    // epilogue, wave-local. acc[i][e]: pixel 32 i + r of the tile, channel nw0 + 8 (e >> 2) + 4 h + (e & 3)
+    auto finish = [&](int tile) {
+        const int m0 = tile * WS_BM;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                float v0 = acc[i][4 * qq] + bias4[qq].x, v1 = acc[i][4 * qq + 1] + bias4[qq].y;
+                float v2 = acc[i][4 * qq + 2] + bias4[qq].z, v3 = acc[i][4 * qq + 3] + bias4[qq].w;
+                if constexpr (ACT) { v0 = silu_fast(v0); v1 = silu_fast(v1); v2 = silu_fast(v2); v3 = silu_fast(v3); }
+                uint2 pk;           // two v_cvt_pk_bf16_f32 (the same round-to-nearest-even as the scalar casts elsewhere)
+                pk.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{v0, v1}, bf16x2_t));
+                pk.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{v2, v3}, bf16x2_t));
+                *reinterpret_cast<uint2*>(stage + r * WS_SROW + qq * 16 + h * 8) = pk;
+            }
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const int row = 16 * k2 + (lane >> 2), cc = lane & 3;
+                const uint4 v = *reinterpret_cast<const uint4*>(stage + row * WS_SROW + cc * 16);
+                const int m = min(m0 + 32 * i + row, p.M - 1);         // rows past M repeat row M - 1: same bytes, same address
+                *reinterpret_cast<uint4*>(out16 + (size_t)m * p.Cout + nw0 + cc * 8) = v;
+            }
+        }
+    };
+    // probe bit 1: waves 0 and 4 of the first 64 workgroups stamp s_memtime into the dump KiB for tiles 1..4:
+    // 8 slots per tile and wave: 0 tile landed, 1 barrier passed, 2 first phase done, 3 second phase done
+    const bool stamp_wg = STAMPS && (wave == 0 || wave == 4) && g < 64;
+    int tile_no = 0;
+    auto stamp = [&](int slot) {
+        if constexpr (!STAMPS) return;
+        if (stamp_wg && tile_no >= 1 && tile_no <= 4) {
+            const uint64_t tnow = __builtin_amdgcn_s_memtime();
+            if (lane == 0) *reinterpret_cast<uint64_t*>(lds + DUMP_OFF + (((tile_no - 1) * 2 + (wave >> 2)) * 8 + slot) * 8) = tnow;
+        }
+    };
+
+    // tuning probes: static priority for one half, or a raised priority while a wave is in its vector phase
+    if ((p.probe & 4) && late) __builtin_amdgcn_s_setprio(1);
+    if ((p.probe & 8) && !late) __builtin_amdgcn_s_setprio(1);
+    const bool dyn_prio = (p.probe & 16) != 0;
+    issue_tile(q, 0);
+    if (late) {                                 // queue entries where the stores of the tile before the first would sit
+#pragma unroll
+        for (int i = 0; i < WS_NS; ++i) dma16_s(p.bias, (uint32_t)(lane & 7) * 16u, lds_a + DUMP_OFF);
+    }
+    int buf = 0;
+    for (int t = q; t < n_mt; t += Q, buf ^= 1, ++tile_no) {
+        if (t == q && !late) wait_vm<0>();      // first tile of waves 0-3: nothing younger than its pieces
+        else wait_vm<WS_NS>();                  // the six stores (or dummies) issued after the tile's pieces may still fly
+        stamp(0);
+        __builtin_amdgcn_s_barrier();           // everybody's pieces have landed; everybody is done with the other buffer
+        stamp(1);
+        issue_tile(t + Q, buf ^ 1);
+        if (!late) {
+            multiply(buf);
+            stamp(2);
+            if (dyn_prio) __builtin_amdgcn_s_setprio(2);
+            finish(t);
+            if (dyn_prio) __builtin_amdgcn_s_setprio(0);
+            stamp(3);
+        } else {
+            if (dyn_prio) __builtin_amdgcn_s_setprio(2);
+            if (t != q) finish(t - Q);
+            if (dyn_prio) __builtin_amdgcn_s_setprio(0);
+            stamp(2);
+            multiply(buf);
+            stamp(3);
+        }
+    }
+    if (late) finish(n_mt - 1 - (n_mt - 1 - q) % Q);     // the last tile of this sequence
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the run-ahead pieces still target this workgroup's LDS
+    if (STAMPS && stamp_wg) {
+        __builtin_amdgcn_s_waitcnt(0);
+        if (wave == 0) {
+            const uint4 v = *reinterpret_cast<const uint4*>(lds + DUMP_OFF + lane * 16);
+            *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.part) + (size_t)g * 1024 + lane * 16) = v;
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------
 // 3x3 convolutions (stride 1 pad 1, or stride 2 with TF-SAME bottom/right padding) with the same lean k loop as
 // gemm1x1_dma_kernel. The A operand is addressed as a RAW BUFFER: a lane's byte offset is fixed (its output pixel,
 // window origin), the filter tap and channel block are one SCALAR offset per k-step, and padding costs no data
@@ -1635,6 +1826,12 @@ static dim3 conv_grid(ConvArgs& a, int BM, int BN) {
     return dim3(8 * ((a.grid_m + 7) / 8) * a.grid_n, 1, z);
 }
 
+static bool wsreg_on() {            // ISB_WSREG=1: weights-stationary kernel for the short-K expand convolutions (A/B switch;
+    // off by default: measured equal to the tile kernels)
+    static const bool on = [] { const char* e = getenv("ISB_WSREG"); return e && atoi(e) != 0; }();
+    return on;
+}
+
 static bool conv3_halo() {          // ISB_C3_HALO=0: im2col A operand (A/B switch)
     static const bool on = [] { const char* e = getenv("ISB_C3_HALO"); return !e || atoi(e) != 0; }();
     return on;
@@ -1666,6 +1863,9 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
             if (g1 && !a.gate) v = 138;
             else if (g1 && a.gate && ohw % 64 == 0) v = 147;
             else v = (!a.gate && a.zeros) ? 64 : 75;
+        } else if (g1 && !a.gate && !a.res && !a.out_f32 && a.splits <= 1 && wsreg_on() && a.Cout % WS_BN == 0 &&
+                   (a.Cin == 96 || a.Cin == 192 || a.Cin == 224 || a.Cin == 384) && a.M >= 64 * WS_BM && (size_t)a.M * a.Cin * 2 < 0xffffffffull) {
+            v = 181;                                   // weights-stationary persistent GEMM (short-K expand convolutions)
         } else if (g1 && !a.gate) {
             if (a.Cout % 192 == 0) v = 131;            // 128 x 192
             else if (a.Cout == 64) v = 135;            // 256 x  64
@@ -1874,6 +2074,41 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
         const dim3 g = conv_grid(aa, 32 * TM * WGM, 32 * TN * WGN);                                              \
         hipLaunchKernelGGL((gemm1x1_dma_kernel<TM, TN, WGM, WGN>), g, dim3(64 * WGM * WGN), 0, st, aa);          \
     } while (0)
+        case 181: {                                          // weights-stationary persistent GEMM, 96 x 192 tiles, 6 waves, 1 per CU
+            const int n_mt = cdiv(a.M, WS_BM), nsl = a.Cout / WS_BN;
+            if (a.gate || a.res || a.out_f32 || a.KH != 1 || a.stride != 1 || a.pad != 0 || a.splits > 1 || a.Cout % WS_BN != 0 ||
+                nsl > 128 || (a.Cin != 96 && a.Cin != 192 && a.Cin != 224 && a.Cin != 384) || (size_t)a.M * a.Cin * 2 >= 0xffffffffull) {
+                set_error("conv_igemm: variant 181 is an un-gated 1x1 GEMM without residual, Cin 96/192/224/384, Cout %% 192 == 0");
+                return ISB_ERR_INVALID;
+            }
+            // one workgroup per CU (256, a multiple of 8 for the XCD decode); Q tile sequences of nsl slices each
+            const int n_wg = 256;
+            const int Q = std::max(1, std::min(n_wg / nsl, n_mt));
+            aa.grid_n = nsl;
+            aa.grid_m = Q;
+            static const int probe = [] { const char* e = getenv("ISB_WS_PROBE"); return e ? atoi(e) : 0; }();
+            aa.probe = a.probe | (probe & ~3);
+            const dim3 g(n_wg);
+            // at least 84 KiB so that two of these never share a CU (the phase pairing assumes one workgroup per CU)
+#define ISB_WS(NK)                                                                                              \
+    do {                                                                                                        \
+        const int bytes = std::max(ws_lds_bytes(NK), 84 * 1024);                                                \
+        static bool attr_set = false;                                                                           \
+        if (!attr_set) {                                                                                        \
+            ISB_HIP(hipFuncSetAttribute((const void*)gemm1x1_wsreg_kernel<NK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));  \
+            ISB_HIP(hipFuncSetAttribute((const void*)gemm1x1_wsreg_kernel<NK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); \
+            attr_set = true;                                                                                    \
+        }                                                                                                       \
+        if (a.probe & 2) {                                                                                      \
+            ISB_HIP(hipFuncSetAttribute((const void*)gemm1x1_wsreg_kernel<NK, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); \
+            hipLaunchKernelGGL((gemm1x1_wsreg_kernel<NK, true, true>), g, dim3(64 * WS_NW), bytes, st, aa);     \
+        } else if (a.act) hipLaunchKernelGGL((gemm1x1_wsreg_kernel<NK, true>), g, dim3(64 * WS_NW), bytes, st, aa); \
+        else hipLaunchKernelGGL((gemm1x1_wsreg_kernel<NK, false>), g, dim3(64 * WS_NW), bytes, st, aa);         \
+    } while (0)
+            if (a.Cin == 96) ISB_WS(3); else if (a.Cin == 192) ISB_WS(6); else if (a.Cin == 224) ISB_WS(7); else ISB_WS(12);
+#undef ISB_WS
+            break;
+        }
         case 131: ISB_CONV_LAUNCH_G1(1, 3, 4, 2); break;   // 128 x 192
         case 132: ISB_CONV_LAUNCH_G1(1, 2, 4, 2); break;   // 128 x 128
         case 133: ISB_CONV_LAUNCH_G1(2, 3, 4, 2); break;   // 256 x 192 (8 waves of 64 x 96)

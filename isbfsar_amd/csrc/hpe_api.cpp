@@ -1,6 +1,7 @@
 // C-ABI glue of the pose stage (include/isbfsar.h, isb_hpe_*): EfficientNetV2-L plan built from
 // the weight blob, activation workspace, per-micro-batch launch sequence, stage-level test hooks.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
@@ -55,6 +56,7 @@ struct isb_hpe {
     isb_hpe_cfg cfg{};
     hipStream_t own_stream = nullptr;
     bool weights = false, jointmap = false;
+    bool dw_fc1_batched = false;  // ISB_DW_FC1=1: batches too compute FC1 inside the depthwise launch (one SE launch per block)
     bool fuse_se = true;          // single-frame split-K projections compute their SE gate in the GEMM; ISB_FUSE_SE=0 disables
     bool split_k = true;          // split-K for the projections of single-frame calls; ISB_SPLIT_K=0 disables
     bool fuse_block = true;       // Fused-MBConv blocks (3x3 expand + 1x1 project) in one launch; ISB_FUSE_BLOCK=0 disables
@@ -283,7 +285,7 @@ int run_backbone(isb_hpe* h, Lane& L, hipStream_t st, const float* crops, int B)
                 d.B = B; d.H = b.in_hw; d.W = b.in_hw; d.C = b.cexp; d.OH = b.out_hw; d.OW = b.out_hw; d.stride = b.stride;
                 d.pad = b.stride == 1 ? 1 : 0;
                 d.pooled = L.pooled.as<float>();
-                if (B == 1 && h->split_k) {        // one frame: FC1 of the squeeze-excite rides in the depthwise launch
+                if ((B == 1 && h->split_k) || h->dw_fc1_batched) {   // FC1 of the squeeze-excite rides in the depthwise launch
                     d.se_w1 = b.se_w1.as<float>(); d.se_part = L.semid.as<float>(); d.cse = b.cse;
                     se_parts = dw_slabs(d);
                 }
@@ -372,6 +374,7 @@ extern "C" int isb_hpe_create(const isb_hpe_cfg* cfg, isb_hpe** out) {
     if (const char* e = getenv("ISB_FUSE_BLOCK")) h->fuse_block = atoi(e) != 0;
     if (const char* e = getenv("ISB_SPLIT_K")) h->split_k = atoi(e) != 0;
     if (const char* e = getenv("ISB_FUSE_SE")) h->fuse_se = atoi(e) != 0;
+    if (const char* e = getenv("ISB_DW_FC1")) h->dw_fc1_batched = atoi(e) != 0;
     if (const char* e = getenv("ISB_FUSE_BLOCK_CEXP")) h->fuse_block_max_cexp = atoi(e);
     if (const char* e = getenv("ISB_HPE_LANES")) h->n_lanes = std::max(1, std::min(kMaxLanes, atoi(e)));
     ISB_HIP(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
@@ -757,7 +760,12 @@ extern "C" int isb_debug_conv(int32_t device, const uint16_t* x, const float* w,
     a.pad = (k == 3 && stride == 1) ? 1 : 0; a.M = B * OH * OW; a.K = k * k * Cin; a.act = act; a.out_f32 = 0; a.zeros = dzero.as<uint16_t>();
     a.variant = variant % 1000;
     DevBuf dpart;
-    if (variant >= 2000) {                      // variant = 1000 * splits + tile variant: split-K
+    if (variant == 9181) {                      // weights-stationary GEMM with in-kernel time stamps (tuning probe)
+        ISB_TRY(dpart.alloc(64 * 1024));
+        ISB_HIP(hipMemset(dpart.p, 0, 64 * 1024));
+        a.part = dpart.as<float>();
+        a.probe = 2;
+    } else if (variant >= 2000) {               // variant = 1000 * splits + tile variant: split-K
         a.splits = variant / 1000;
         ISB_TRY(dpart.alloc((size_t)a.splits * a.M * Cout * 4));
         a.part = dpart.as<float>();
@@ -777,6 +785,20 @@ extern "C" int isb_debug_conv(int32_t device, const uint16_t* x, const float* w,
     (void)hipEventDestroy(e1);
     *ms_per_iter = ms / iters;
     ISB_HIP(hipMemcpy(out, dout.p, nout * 2, hipMemcpyDeviceToHost));
+    if (variant == 9181) {                      // print the stamps of the last launch: cycles per phase, per tile
+        std::vector<uint64_t> st(64 * 128);
+        ISB_HIP(hipMemcpy(st.data(), dpart.p, 64 * 1024, hipMemcpyDeviceToHost));
+        for (int g : {0, 1, 8, 33}) {
+            for (int tl = 0; tl < 4; ++tl)
+                for (int half = 0; half < 2; ++half) {
+                    const uint64_t* s0 = st.data() + (size_t)g * 128 + (tl * 2 + half) * 8;
+                    if (!s0[0]) continue;
+                    fprintf(stderr, "wg %2d tile %d wave %d: barrier %5lld  first phase %5lld  second phase %5lld  total %5lld\n", g,
+                            tl + 1, half * 4, (long long)(s0[1] - s0[0]), (long long)(s0[2] - s0[1]), (long long)(s0[3] - s0[2]),
+                            (long long)(s0[3] - s0[0]));
+                }
+        }
+    }
     return ISB_OK;
     });
 }

@@ -68,6 +68,7 @@ struct ArStatsArgs {
     int x3;
     int online;             // 1: running-max variant (bound too loose to exclude underflow)
     int wt;                 // grid decode: windows per L2 block (set by the launcher, <= STATS_WT)
+    const int32_t* chosen;  // null: every class -> lse2 [B][n][Tp]; else ONLY class chosen[b] of window b -> lse2 [B][Tp]
 };
 int launch_ar_stats(const ArStatsArgs& a, hipStream_t st);
 
@@ -89,6 +90,7 @@ struct ArProtoArgs {
     int B, n, L, T, NT;
     int x3;
     int wt;                 // grid decode: window groups per L2 block (set by the launcher, <= PROTO_WT)
+    int lse_per_window;     // chosen mode: lse2 is [B][Tp] (ArStatsArgs.chosen), not [B][n][Tp]
 };
 int launch_ar_proto(const ArProtoArgs& a, hipStream_t st);
 
@@ -151,6 +153,9 @@ struct ConvArgs {
     const float* se_b2;     // [Cin]
     int se_nparts, se_cse;
     // fused Fused-MBConv block (launch_fused_mb): 3x3 expand (w, bias, act) -> bf16 -> 1x1 project (w2, bias2) + residual
+    // tuning probes of gemm1x1_wsreg_kernel (isb_debug_conv variant 9181 / ISB_WS_PROBE): bit 0 = no output stores,
+    // bit 1 = s_memtime stamps of the first workgroups' wave 0 into `part` (1 KiB per workgroup)
+    int probe;
     const uint16_t* w2;     // bf16 [Cout2][Cout] (BN scale folded)
     const float* bias2;     // [Cout2]
     int Cout2;

@@ -77,7 +77,10 @@ def test_sharp_goldens_open_set_score_resolves(golden_dir, name, precision):
     e_t = float(np.abs(is_true - g["is_true"][:, 0]).max())
     print(f"sharp {name} {precision}: |dlogit|={e_l:.2e} (logits down to {g['logits'].min():.1f}) |dprob|={e_p:.2e} |dis_true|={e_t:.2e}")
     assert e_p < ATOL_PROB and e_t < ATOL_PROB
-    assert e_l < ATOL_LOGIT[precision] * max(1.0, float(np.abs(g["logits"]).max()))
+    # the arg-max class's diff always runs in bf16x3 (ar_api.cpp): the open-set score holds 1e-3 in either setting. The
+    # bf16 LOGITS of the other classes carry the operand rounding of scores that reach |s| ~ 100 here: 1 % of the range
+    rel = 1e-2 if precision == "bf16" else 5e-5
+    assert e_l < rel * max(1.0, float(np.abs(g["logits"]).max()))
 
 
 @pytest.mark.parametrize("L,J,way,B", [(16, 30, 5, 7), (8, 17, 3, 2), (30, 122, 60, 3), (12, 25, 1, 1), (5, 4, 2, 3)])
