@@ -193,7 +193,9 @@ int isb_hpe_profile_read(isb_hpe* h, double* ms_total, int64_t* launches);
  *   h_x bf16 [B,H,W,Cin], h_w f32 [Cout,k,k,Cin], folded BN h_scale/h_shift [Cout], optional residual
  *   h_res bf16 [B,OH,OW,Cout] and squeeze-excite gate h_gate f32 [B,Cin] (1x1 only), act 1 = SiLU,
  *   variant 0 = automatic tile choice; variant = 1000 * splits + v (splits >= 2, v a gemm1x1 variant 131-148) runs
- *   the split-K GEMM + reduction pair; out bf16 [B,OH,OW,Cout]; ms_per_iter = HIP-event time of one launch. */
+ *   the split-K GEMM + reduction pair; variant = 900000 + v (v = 131-148, 181) runs the kernel with in-kernel s_memtime
+ *   stamps and prints the phase clocks of its first workgroups to stderr (tuning probe);
+ *   out bf16 [B,OH,OW,Cout]; ms_per_iter = HIP-event time of one launch. */
 int isb_debug_conv(int32_t device, const uint16_t* h_x, const float* h_w, const float* h_scale, const float* h_shift,
                    const uint16_t* h_res, const float* h_gate, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
                    int32_t k, int32_t stride, int32_t act, int32_t variant, int32_t iters, uint16_t* h_out,

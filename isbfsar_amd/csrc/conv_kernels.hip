@@ -158,6 +158,79 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
     }
 }
 
+// Wave-local epilogue of the lean kernels (bf16 output) -- built, bit-identical, NOT the default (ISB_EPI_SHARED). In-kernel clocks (round 2, s_memtime, 256 frames) put the shared
+// epilogue above at 9 200 cycles per workgroup on the 224 -> 1344 expand (37 % of the workgroup's life) and 26 200 on the
+// 1344 -> 224 projection (25 %): all waves stage the whole tile, meet at a barrier, then walk a store loop with a division,
+// 64-bit address arithmetic and a bounds branch per 16-byte piece -- and a projection first fetches its residual as 28
+// scattered 8-byte loads per lane, each waited for in turn. Here every wave finishes its OWN 32 x 32 blocks, one at a time,
+// through a private 2.5-KiB LDS area: the residual block arrives as two coalesced 16-byte loads per lane one block ahead,
+// (all blocks requested up front) is transposed through the area into the accumulator layout, bias / SiLU / residual / one rounding happen in registers
+// exactly as above (same operations, same order: bit-identical), the packed block goes back through the same area and
+// leaves as two 16-byte stores per lane (rows past M masked). No barrier; whole 32-column blocks past Cout are skipped
+// (wave-uniform).
+// The caller guarantees that every wave of the workgroup has left the k loop (the loop's last barrier): the areas overlay
+// the operand buffers.
+#ifndef ISB_EPI_SHARED
+#define ISB_EPI_SHARED 1          // build-time A/B switch: 1 = the lean kernels keep the shared epilogue above (the default:
+#endif                            // same-session A/B, 256 frames: shared 639 TFLOP/s on the convolution family, wave-local 609)
+constexpr int WL_SROW = 80, WL_AREA = 32 * WL_SROW;
+template <int TM, int TN, int WGM, int WGN>
+__device__ __forceinline__ void conv_epilogue_wl(const ConvArgs& p, f32x16 (&acc)[TM][TN], unsigned char* lds, int m0, int n0,
+                                                 int wm, int wn, int r, int h, int lane, int wave, int bias_off) {
+    unsigned char* const st = lds + wave * WL_AREA;
+    uint16_t* const out16 = reinterpret_cast<uint16_t*>(p.out);
+    const int row16 = lane >> 2, cc = lane & 3;
+    const bool has_res = p.res != nullptr;                // wave-uniform
+    auto res_load = [&](int b, uint4 (&rr)[2]) {          // block b = i * TN + j: rows 16 k2 + row16, channels 8 cc .. + 7
+        const int i = b / TN, j = b - i * TN;
+        const int nb = n0 + (wn * TN + j) * 32;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const int m = min(m0 + (wm * TM + i) * 32 + 16 * k2 + row16, p.M - 1);
+            rr[k2] = nb < p.Cout ? *reinterpret_cast<const uint4*>(p.res + (size_t)m * p.Cout + nb + cc * 8) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    // every residual block of the wave is requested at once: coalesced 64-byte row segments, ONE memory round trip for
+    // the whole epilogue (2 x TM x TN registers of 16 bytes)
+    uint4 rall[TM * TN][2];
+    if (has_res) {
+#pragma unroll
+        for (int b = 0; b < TM * TN; ++b) res_load(b, rall[b]);
+    }
+#pragma unroll
+    for (int b = 0; b < TM * TN; ++b) {
+        const int i = b / TN, j = b - i * TN;
+        const int nl0 = (wn * TN + j) * 32, nb = n0 + nl0;
+        if (nb >= p.Cout) continue;                                      // tile overhang past the last channel: nothing to store
+        if (has_res) {
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) *reinterpret_cast<uint4*>(st + (16 * k2 + row16) * WL_SROW + cc * 16) = rall[b][k2];
+        }
+        uint2 pk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 bs = *reinterpret_cast<const float4*>(lds + bias_off + (nl0 + 8 * q + 4 * h) * 4);
+            float v0 = acc[i][j][4 * q] + bs.x, v1 = acc[i][j][4 * q + 1] + bs.y, v2 = acc[i][j][4 * q + 2] + bs.z, v3 = acc[i][j][4 * q + 3] + bs.w;
+            if (p.act) { v0 = silu_fast(v0); v1 = silu_fast(v1); v2 = silu_fast(v2); v3 = silu_fast(v3); }
+            if (has_res) {
+                const uint2 rr = *reinterpret_cast<const uint2*>(st + r * WL_SROW + q * 16 + h * 8);
+                v0 += bf2f_((uint16_t)(rr.x & 0xffff)); v1 += bf2f_((uint16_t)(rr.x >> 16));
+                v2 += bf2f_((uint16_t)(rr.y & 0xffff)); v3 += bf2f_((uint16_t)(rr.y >> 16));
+            }
+            pk[q].x = (uint32_t)f2bf_(v0) | ((uint32_t)f2bf_(v1) << 16);
+            pk[q].y = (uint32_t)f2bf_(v2) | ((uint32_t)f2bf_(v3) << 16);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(st + r * WL_SROW + q * 16 + h * 8) = pk[q];
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const uint4 v = *reinterpret_cast<const uint4*>(st + (16 * k2 + row16) * WL_SROW + cc * 16);
+            const int m = m0 + (wm * TM + i) * 32 + 16 * k2 + row16;
+            if (m < p.M) *reinterpret_cast<uint4*>(out16 + (size_t)m * p.Cout + nb + cc * 8) = v;
+        }
+    }
+}
+
 // workgroup -> output tile. Mode 0: 2-D grid. Modes 1/2: 1-D grid; hardware hands consecutive workgroup ids
 // to the 8 XCDs round-robin, so id % 8 names the XCD (and its private L2) a workgroup runs on. Within an XCD
 // the N tiles of one M tile are consecutive: the A rows are fetched into that L2 once and re-read from it.
@@ -701,8 +774,13 @@ __device__ __forceinline__ void dma16_s(const void* sbase, uint32_t voff, uint32
 
 // GATE: 0 = none, 1 = gate rows read from p.gate, 2 = gate of the workgroup's k-range computed here from the
 // squeeze-excite FC1 partials (single-frame split-K launches: se_fc2_kernel's arithmetic, in its order)
-template <int TM, int TN, int WGM, int WGN, int GATE = 0>
+// STAMPS (tuning probe, isb_debug_conv variant 9000 + v): wave 0 of the first 64 workgroups sums s_memtime intervals over
+// its k loop -- waiting for the DMA (vmcnt), waiting at the barrier, the rest (fragment reads + MFMAs) -- and writes
+// {prologue, DMA wait, barrier wait, whole k loop, epilogue, k-steps} to p.part[workgroup]
+template <int TM, int TN, int WGM, int WGN, int GATE = 0, bool STAMPS = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_dma_kernel(ConvArgs p) {
+    uint64_t st_t0 = 0, st_wait = 0, st_bar = 0, st_loop0 = 0, st_loop1 = 0;
+    if constexpr (STAMPS) st_t0 = __builtin_amdgcn_s_memtime();
     constexpr int NW = WGM * WGN;
     constexpr int BM = 32 * TM * WGM;
     constexpr int BN = 32 * TN * WGN;
@@ -888,11 +966,22 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_dma_kernel(ConvArgs p)
         ++kt_now;
     };
     auto publish = [&]() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if constexpr (STAMPS) {
+            const uint64_t a = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const uint64_t b = __builtin_amdgcn_s_memtime();
+            __syncthreads();
+            const uint64_t c = __builtin_amdgcn_s_memtime();
+            st_wait += b - a;
+            st_bar += c - b;
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
     };
 
     publish();
+    if constexpr (STAMPS) { st_loop0 = __builtin_amdgcn_s_memtime(); st_wait = 0; st_bar = 0; }
     int kt = 0;
     for (; kt + 2 <= nkt; kt += 2) {            // straight-line body: tile kt in buffer 0, tile kt+1 in buffer 1
         dma(std::integral_constant<int, 1>{});
@@ -906,7 +995,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_dma_kernel(ConvArgs p)
         compute(std::integral_constant<int, 0>{});
         __syncthreads();
     }
-    conv_epilogue<TM, TN, WGM, WGN, true>(p, acc, lds, m0, n0, wm, wn, r, h, tid, bias_off);
+    if constexpr (STAMPS) st_loop1 = __builtin_amdgcn_s_memtime();
+    if (ISB_EPI_SHARED || p.splits > 1 || p.out_f32) conv_epilogue<TM, TN, WGM, WGN, true>(p, acc, lds, m0, n0, wm, wn, r, h, tid, bias_off);
+    else conv_epilogue_wl<TM, TN, WGM, WGN>(p, acc, lds, m0, n0, wm, wn, r, h, lane, wave, bias_off);
+    if constexpr (STAMPS) {
+        const uint64_t t_end = __builtin_amdgcn_s_memtime();
+        const int wgid = blockIdx.x + gridDim.x * blockIdx.y;
+        if (tid == 0 && wgid < 64) {
+            uint64_t* o = reinterpret_cast<uint64_t*>(p.part) + (size_t)wgid * 8;
+            o[0] = st_loop0 - st_t0; o[1] = st_wait; o[2] = st_bar; o[3] = st_loop1 - st_loop0; o[4] = t_end - st_loop1; o[5] = (uint64_t)nkt;
+        }
+    }
 }
 
 // -------------------------------------------------------------------------------------------
@@ -1300,7 +1399,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_dma_kernel(ConvArgs p)
         compute(std::integral_constant<int, 0>{});
         __syncthreads();
     }
-    conv_epilogue<TM, TN, WGM, WGN, true>(p, acc, lds, m0, n0, wm, wn, r, h, tid, bias_off);
+    if (ISB_EPI_SHARED || p.out_f32) conv_epilogue<TM, TN, WGM, WGN, true>(p, acc, lds, m0, n0, wm, wn, r, h, tid, bias_off);
+    else conv_epilogue_wl<TM, TN, WGM, WGN>(p, acc, lds, m0, n0, wm, wn, r, h, lane, wave, bias_off);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -1713,7 +1813,8 @@ __global__ __launch_bounds__(128 * WGM) void fused_mb_kernel(ConvArgs p) {
     ConvArgs p2 = p;                                         // epilogue of the projection: bias2, no activation, residual
     p2.Cout = p.Cout2;
     p2.act = 0;
-    conv_epilogue<1, TN2, WGM, 2, true>(p2, acc2, lds, m0, 0, wm, wn, r, h, tid, BIAS2_OFF);
+    if (ISB_EPI_SHARED) conv_epilogue<1, TN2, WGM, 2, true>(p2, acc2, lds, m0, 0, wm, wn, r, h, tid, BIAS2_OFF);
+    else conv_epilogue_wl<1, TN2, WGM, 2>(p2, acc2, lds, m0, 0, wm, wn, r, h, lane, wave, BIAS2_OFF);
 }
 
 static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st);
@@ -2072,7 +2173,8 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
             return ISB_ERR_INVALID;                                                                              \
         }                                                                                                        \
         const dim3 g = conv_grid(aa, 32 * TM * WGM, 32 * TN * WGN);                                              \
-        hipLaunchKernelGGL((gemm1x1_dma_kernel<TM, TN, WGM, WGN>), g, dim3(64 * WGM * WGN), 0, st, aa);          \
+        if (a.probe & 2) hipLaunchKernelGGL((gemm1x1_dma_kernel<TM, TN, WGM, WGN, 0, true>), g, dim3(64 * WGM * WGN), 0, st, aa); \
+        else hipLaunchKernelGGL((gemm1x1_dma_kernel<TM, TN, WGM, WGN>), g, dim3(64 * WGM * WGN), 0, st, aa);     \
     } while (0)
         case 181: {                                          // weights-stationary persistent GEMM, 96 x 192 tiles, 6 waves, 1 per CU
             const int n_mt = cdiv(a.M, WS_BM), nsl = a.Cout / WS_BN;
@@ -2186,6 +2288,11 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
             attr_bytes = bytes;                                                                                  \
         }                                                                                                        \
         const dim3 g = conv_grid(aa, BM_, BN_);                                                                  \
+        if (a.probe & 2) {                                                                                       \
+            auto kern2 = gemm1x1_dma_kernel<TM, TN, WGM, WGN, true, true>;                                       \
+            ISB_HIP(hipFuncSetAttribute((const void*)kern2, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); \
+            hipLaunchKernelGGL(kern2, g, dim3(64 * WGM * WGN), bytes, st, aa);                                   \
+        } else                                                                                                   \
         hipLaunchKernelGGL(kern, g, dim3(64 * WGM * WGN), bytes, st, aa);                                        \
     } while (0)
         case 149: {                                          //  64 x 128, split-K, squeeze-excite FC2 folded in

@@ -760,11 +760,12 @@ extern "C" int isb_debug_conv(int32_t device, const uint16_t* x, const float* w,
     a.pad = (k == 3 && stride == 1) ? 1 : 0; a.M = B * OH * OW; a.K = k * k * Cin; a.act = act; a.out_f32 = 0; a.zeros = dzero.as<uint16_t>();
     a.variant = variant % 1000;
     DevBuf dpart;
-    if (variant == 9181) {                      // weights-stationary GEMM with in-kernel time stamps (tuning probe)
+    if (variant >= 900000) {                    // kernels with in-kernel time stamps (tuning probes): 900181, 900131, 900143, ...
         ISB_TRY(dpart.alloc(64 * 1024));
         ISB_HIP(hipMemset(dpart.p, 0, 64 * 1024));
         a.part = dpart.as<float>();
         a.probe = 2;
+        a.variant = variant - 900000;
     } else if (variant >= 2000) {               // variant = 1000 * splits + tile variant: split-K
         a.splits = variant / 1000;
         ISB_TRY(dpart.alloc((size_t)a.splits * a.M * Cout * 4));
@@ -785,7 +786,26 @@ extern "C" int isb_debug_conv(int32_t device, const uint16_t* x, const float* w,
     (void)hipEventDestroy(e1);
     *ms_per_iter = ms / iters;
     ISB_HIP(hipMemcpy(out, dout.p, nout * 2, hipMemcpyDeviceToHost));
-    if (variant == 9181) {                      // print the stamps of the last launch: cycles per phase, per tile
+    if (variant >= 900000 && variant != 900181) {   // the tile GEMMs: per workgroup {prologue, DMA wait, barrier wait, k loop, epilogue, k-steps}
+        std::vector<uint64_t> st(64 * 8);
+        ISB_HIP(hipMemcpy(st.data(), dpart.p, 64 * 64, hipMemcpyDeviceToHost));
+        double sum[5] = {0, 0, 0, 0, 0};
+        int n = 0;
+        for (int g = 0; g < 64; ++g) {
+            const uint64_t* o = st.data() + (size_t)g * 8;
+            if (!o[5]) continue;
+            for (int i = 0; i < 5; ++i) sum[i] += (double)o[i];
+            ++n;
+            if (g < 4)
+                fprintf(stderr, "wg %2d: prologue %6llu | k loop %7llu (%llu k-steps: DMA wait %6llu, barrier %6llu) | epilogue %6llu\n", g,
+                        (unsigned long long)o[0], (unsigned long long)o[3], (unsigned long long)o[5], (unsigned long long)o[1],
+                        (unsigned long long)o[2], (unsigned long long)o[4]);
+        }
+        if (n)
+            fprintf(stderr, "mean of %d workgroups (cycles, wave 0): prologue %.0f | k loop %.0f of which DMA wait %.0f, barrier wait %.0f | epilogue %.0f\n",
+                    n, sum[0] / n, sum[3] / n, sum[1] / n, sum[2] / n, sum[4] / n);
+    }
+    if (variant == 900181) {                    // print the stamps of the last launch: cycles per phase, per tile
         std::vector<uint64_t> st(64 * 128);
         ISB_HIP(hipMemcpy(st.data(), dpart.p, 64 * 1024, hipMemcpyDeviceToHost));
         for (int g : {0, 1, 8, 33}) {
