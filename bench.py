@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (0 = the BASELINE config's)")
     ap.add_argument("--way", type=int, default=60)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"])
+    ap.add_argument("--host-input", action="store_true",
+                    help="hpe workload: frames start in (pinned) HOST memory each step, isb_hpe_forward_host copies them (PCIe-inclusive "
+                         "rate: the reference's Runner pattern; never the headline value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="items per CPU-baseline iteration (0 = the workload's default)")
     ap.add_argument("--cpu-iters", type=int, default=10, help="timed CPU-baseline iterations (median reported; BASELINE.md 4)")
@@ -118,8 +121,9 @@ class ArWorkload:
         achieved = flops_per_launch / avg_s / 1e12
         peak = MFMA_PEAK_TFLOPS[self.precision]
         traffic = None
-        tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tj) and chunk == 1024 and self.way == 60 and self.precision == "bf16":
+        from bench_workloads import latest_traffic_json
+        tj = latest_traffic_json()
+        if tj and chunk == 1024 and self.way == 60 and self.precision == "bf16":
             with open(tj) as f:       # HBM bytes of one ar_proto launch (PMC passes, profiles/README.md)
                 traffic = json.load(f).get("ar_b1024", {}).get("ar_proto", {}).get("hbm_bytes_per_launch")
         return {"bound": "mfma", "kernel": "ar_proto_kernel", "achieved": round(achieved, 2), "peak": peak,

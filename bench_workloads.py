@@ -36,6 +36,13 @@ def usable_cores() -> int:
     return max(1, n)
 
 
+def latest_traffic_json():
+    """profiles/rNN_traffic.json of the latest round (PMC FETCH_SIZE / WRITE_SIZE passes, tools/round_profiles.sh)"""
+    import glob
+    found = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r[0-9][0-9]_traffic.json")))
+    return found[-1] if found else None
+
+
 def median_time(fn, warm: int = 3, iters: int = 10):
     """BASELINE.md 4 protocol: `warm` untimed passes, then the MEDIAN wall time of `iters` timed ones.
     Returns (median seconds per pass, total seconds spent)."""
@@ -112,8 +119,8 @@ class _HpeBase:
         flops = 2.0 * igemm_macs_per_crop() * self.B * steps
         achieved = flops / (ms / 1e3) / 1e12
         traffic = None
-        tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
-        if os.path.exists(tj):      # HBM bytes of the conv_igemm launches of one forward pass, from the PMC passes
+        tj = latest_traffic_json()
+        if tj:                      # HBM bytes of the conv_igemm launches of one forward pass, from the PMC passes
             with open(tj) as f:     # (FETCH_SIZE / WRITE_SIZE, collected separately; see profiles/README.md)
                 t = json.load(f)["hpe_b256"]["conv_igemm"]["hbm_bytes_per_forward"]
             traffic = t * self.B / 256.0
@@ -166,12 +173,18 @@ class HpeWorkload(_HpeBase):
     def __init__(self, args, rank, world, dev):
         self._setup_hpe(args, rank, dev)
         self.world = world
+        self.host_input = bool(getattr(args, "host_input", False))
+        if self.host_input:          # pinned host frames: what a capture thread would hand over (utils/input.py -> main.py:74)
+            self.frames_pinned = self.torch.from_numpy(self.frames_host).pin_memory().numpy()
 
     def units_per_step(self):
         return self.B
 
     def step(self):
-        self.out = self.hpe.forward(self.frames, self.bbox)
+        if self.host_input:          # H2D of the frames + kernels + D2H of the poses + synchronise, inside the step
+            self.out = self.hpe.forward(self.frames_pinned, self.bbox_host)
+        else:
+            self.out = self.hpe.forward(self.frames, self.bbox)
 
     def roofline(self, steps):
         return self._hpe_roofline(steps)
@@ -185,7 +198,9 @@ class HpeWorkload(_HpeBase):
 
     def config(self, world):
         return {"workload": f"BASELINE configs[1]: B={self.B} synthetic 640x480 frames/GPU, HPE only "
-                            "(homography crop, EfficientNetV2-L bf16, head, decode, reconstruction)",
+                            "(homography crop, EfficientNetV2-L bf16, head, decode, reconstruction)"
+                            + (" -- frames in pinned HOST memory, H2D + D2H inside the step (isb_hpe_forward_host)" if self.host_input else ""),
+                "input": "host (pinned)" if self.host_input else "resident in HBM",
                 "per_gpu_batch": self.B, "n_joints": self.J, "parallelism": f"dp{world}"}
 
 

@@ -14,6 +14,12 @@ shutil.copy(f"{G}/prof_pipe/run_kernel_stats.csv", f"{P}/{tag}_pipeline_b256_ker
 shutil.copy(f"{G}/prof_ar/run_kernel_stats.csv", f"{P}/{tag}_ar_b1024_kernel_stats.csv")
 shutil.copy(f"{G}/prof_hpe1/run_kernel_stats.csv", f"{P}/{tag}_hpe_b256_onelane_kernel_stats.csv")
 shutil.copy(f"{G}/traffic.json", f"{P}/{tag}_traffic.json")
+import os
+for src, dst in (("bench_ar_bf16x3.json", "bench_ar_bf16x3.json"), ("bench_hpe_host.json", "bench_hpe_host_input.json"),
+                 ("bench_pipe_b2048.json", "bench_pipe_b2048.json"), ("mfma_hpe.json", "mfma_counters_hpe_b256_onelane.json"),
+                 ("mfma_ar.json", "mfma_counters_ar_b1024.json"), ("layer_breakdown.txt", "hpe_b256_layer_breakdown.txt")):
+    if os.path.exists(f"{G}/{src}"):
+        shutil.copy(f"{G}/{src}", f"{P}/{tag}_{dst}")
 for src, dst in (("pmc_fetch", "hpe_b256_fetch_size"), ("pmc_write", "hpe_b256_write_size")):
     with open(f"{G}/{src}/run_counter_collection.csv") as f, open(f"{P}/{tag}_{dst}_counters.csv", "w", newline="") as o:
         w = csv.writer(o)

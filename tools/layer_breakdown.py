@@ -1,5 +1,8 @@
-"""Per-layer-group time of conv_igemm launches of the LAST backbone pass in a rocprofv3 kernel trace.
-usage: python tools/layer_breakdown.py <kernel_trace.csv> [B]"""
+"""Per-layer-group time of the convolution launches of the LAST backbone pass in a rocprofv3 kernel trace (one lane).
+usage: python tools/layer_breakdown.py <kernel_trace.csv> [B]
+The expected launch sequence follows csrc/hpe_api.cpp::run_backbone: Fused-MBConv blocks with <= 256 expanded channels
+are ONE launch (fused_mb), the others expand + project; MBConv blocks are expand + project (depthwise / SE are not
+convolution-family launches)."""
 import collections
 import csv
 import os
@@ -7,33 +10,34 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from isbfsar_amd import effnetv2 as E
 
-rows = list(csv.DictReader(open(sys.argv[1])))
+FAMILY = ("conv_igemm", "gemm1x1", "conv3x3_dma", "conv3x3_c32_rows", "fused_mb", "splitk_reduce")
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if any(k in r["Kernel_Name"] for k in FAMILY)]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-ig = [r for r in rows if 'conv_igemm' in r['Kernel_Name'] or 'gemm1x1' in r['Kernel_Name'] or 'isb::conv3x3_dma' in r['Kernel_Name']]
-convs = []
+seq = []                      # (label, out_hw, flops)
 for b in E.blocks():
-    if b.kind == 'fused':
-        if b.cexp != b.cin:
-            convs.append(('exp3x3', b.in_hw, b.out_hw, b.cin, b.cexp, 3, b.stride))
-            convs.append(('proj', b.out_hw, b.out_hw, b.cexp, b.cout, 1, 1))
+    o = b.out_hw * b.out_hw
+    if b.kind == "fused":
+        if b.cexp == b.cin:
+            seq.append((f"f3x3 {b.cin}->{b.cout} @{b.out_hw}", 2.0 * B * o * 9 * b.cin * b.cout))
+        elif b.cexp <= 256 and b.cout <= 128:
+            seq.append((f"fusedMB {b.cin}->{b.cexp}->{b.cout} @{b.out_hw} s{b.stride}", 2.0 * B * o * (9 * b.cin * b.cexp + b.cexp * b.cout)))
         else:
-            convs.append(('f3x3', b.in_hw, b.out_hw, b.cin, b.cout, 3, b.stride))
+            seq.append((f"exp3x3 {b.cin}->{b.cexp} @{b.out_hw}", 2.0 * B * o * 9 * b.cin * b.cexp))
+            seq.append((f"proj {b.cexp}->{b.cout} @{b.out_hw}", 2.0 * B * o * b.cexp * b.cout))
     else:
-        convs.append(('exp1x1', b.in_hw, b.in_hw, b.cin, b.cexp, 1, 1))
-        convs.append(('proj', b.out_hw, b.out_hw, b.cexp, b.cout, 1, 1))
-convs.append(('head', 8, 8, 640, 1280, 1, 1))
-n = len(convs)
-last = ig[-n:]
+        seq.append((f"exp1x1 {b.cin}->{b.cexp} @{b.in_hw}", 2.0 * B * b.in_hw * b.in_hw * b.cin * b.cexp))
+        seq.append((f"proj(SE) {b.cexp}->{b.cout} @{b.out_hw}", 2.0 * B * o * b.cexp * b.cout))
+seq.append(("head 640->1280 @8", 2.0 * B * 64 * 640 * 1280))
+n = len(seq)
+last = rows[-n:]
 agg = collections.OrderedDict()
-tot = 0
-for c, r in zip(convs, last):
-    d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6
-    fl = 2.0 * B * c[2] * c[2] * c[5] * c[5] * c[3] * c[4]
-    by = B * (c[1] * c[1] * c[3] + c[2] * c[2] * c[4]) * 2
-    key = (c[0], c[1], c[3], c[4], c[6])
-    a = agg.setdefault(key, [0, 0, 0, 0, r['Kernel_Name'][:60]])
-    a[0] += d; a[1] += fl; a[2] += by; a[3] += 1
+tot = 0.0
+for (label, fl), r in zip(seq, last):
+    d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+    a = agg.setdefault(label, [0.0, 0.0, 0, r["Kernel_Name"].replace("void isb::", "")[:44]])
+    a[0] += d; a[1] += fl; a[2] += 1
     tot += d
-print('launches', len(ig), 'per pass', n, 'last-pass total ms', round(tot, 3))
+print(f"convolution-family launches in the trace: {len(rows)}; per pass {n}; last pass {tot:.3f} ms "
+      f"({sum(f for _, f in seq) / tot / 1e9:.0f} TFLOP/s over the pass), B={B}")
 for k, a in agg.items():
-    print(f"{str(k):38s} n={a[3]:2d} ms={a[0]:6.3f} ({100*a[0]/tot:4.1f}%) TF={a[1]/a[0]/1e9:6.0f} GB/s={a[2]/a[0]/1e6:6.0f} {a[4]}")
+    print(f"{k:34s} n={a[2]:2d} ms={a[0]:6.3f} ({100 * a[0] / tot:4.1f}%) TFLOP/s={a[1] / a[0] / 1e9:6.0f}  {a[3]}")
