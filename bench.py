@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="auto", choices=["auto", "pipeline", "hpe", "ar", "stream"])
+    ap.add_argument("--workload", default="auto", choices=["auto", "pipeline", "hpe", "ar", "stream", "det"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (0 = the BASELINE config's)")
     ap.add_argument("--way", type=int, default=60)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"])
@@ -160,7 +160,7 @@ class ArWorkload:
 
 
 def pick_workload(name):
-    if name in ("auto", "pipeline", "hpe", "stream"):
+    if name in ("auto", "pipeline", "hpe", "stream", "det"):
         import bench_workloads
         return bench_workloads.get(name)
     return ArWorkload

@@ -386,5 +386,74 @@ class StreamWorkload(_HpeBase):
                 "parallelism": f"dp{world} (one feed per GPU, no collective)"}
 
 
+class DetWorkload:
+    """SURVEY 8f row 1 (not a BASELINE config): the YOLOv4 person detector the reference runs per frame before the pose
+    stage (hpe.py:51-73): frame -> area resize -> CSPDarknet53 + SPP + PANet + heads (22.8 GFLOP) -> boxes / confs -> the
+    person box. Reported beside the BASELINE workloads; its roofline is the whole step against the bf16 MFMA peak."""
+    name = "det"
+    metric = "frames/sec (640x480 frame -> YOLOv4 boxes + class confidences -> person box)"
+    unit = "frames/s"
+    precision = "bf16"
+
+    def __init__(self, args, rank, world, dev):
+        import torch
+        from isbfsar_amd import yolov4
+        from isbfsar_amd.det_engine import DetEngine
+        self.torch = torch
+        self.B = args.batch or 64
+        self.state = yolov4.make_state(0)
+        self.det = DetEngine(device=dev, max_batch=min(self.B, 64))
+        self.det.load_weights(self.state)
+        self.frames_host = synth.frames(self.B, seed=20_000 * (rank + 1))
+        self.frames = torch.from_numpy(self.frames_host).cuda(dev)
+        self.flops = 2.0 * yolov4.macs_per_frame()
+
+    def units_per_step(self):
+        return self.B
+
+    def step(self):
+        boxes, confs = self.det.forward(self.frames)
+        self.out = (boxes, confs)
+
+    def roofline(self, steps):
+        torch = self.torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            self.step()
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / steps
+        achieved = self.flops * self.B / (ms / 1e3) / 1e12
+        return {"bound": "mfma", "kernel": "whole detector step (110 convolutions + pre-processing, SPP, concat, decode)",
+                "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS_BF16, "unit": "TFLOP/s",
+                "frac": round(achieved / MFMA_PEAK_TFLOPS_BF16, 4), "traffic": None, "avg_launch_ms": round(ms, 4), "launches": steps}
+
+    def cpu_baseline(self, sample, iters=10):
+        from oracle.yolov4_oracle import YoloV4Oracle, preprocess
+        import torch
+        torch.set_num_threads(usable_cores())
+        n = sample or 4
+        net = YoloV4Oracle(self.state, "f32")
+        ref = {}
+
+        def one_pass():
+            img = np.stack([preprocess(f) for f in self.frames_host[:n]])
+            ref["maps"] = net.raw_heads(img)
+            ref["out"] = net.decode(ref["maps"])
+
+        med, total = median_time(one_pass, warm=1, iters=iters)
+        _, maps = self.det.debug(self.frames_host[:n]) if n <= self.det.max_batch else (None, None)
+        if maps is not None:
+            self.parity = {"n_frames": n, "maps_rel_l2": [round(float(np.linalg.norm(m - r) / np.linalg.norm(r)), 5) for m, r in zip(maps, ref["maps"])]}
+        return {"value": round(n / med, 3), "unit": "frames/s", "cores": usable_cores(), "kind": "port",
+                "sample": f"median of {iters} passes over {n} frames through the fp32 CPU definition (numpy pre-processing + torch-CPU "
+                          f"YOLOv4 + numpy decode), {total:.1f} s of CPU work"}
+
+    def config(self, world):
+        return {"workload": f"SURVEY 8f row 1: B={self.B} synthetic 640x480 frames/GPU through the YOLOv4 person detector",
+                "per_gpu_batch": self.B, "parallelism": f"dp{world}"}
+
+
 def get(name: str):
-    return {"hpe": HpeWorkload, "stream": StreamWorkload}.get(name, PipelineWorkload)
+    return {"hpe": HpeWorkload, "stream": StreamWorkload, "det": DetWorkload}.get(name, PipelineWorkload)

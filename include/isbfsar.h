@@ -115,8 +115,8 @@ int isb_ar_profile_read(isb_ar* h, double* ms_total, int64_t* launches);
  *   replaces  HumanPoseEstimator.__init__  modules/hpe/hpe.py:15-46  (K, joint assets, 4 engines)
  *             HumanPoseEstimator.estimate  modules/hpe/hpe.py:76-173 (everything after the detector)
  *   and the four Runner(...) calls it makes (utils/tensorrt_runner.py:64-77; hpe.py:97,103,106).
- * The YOLOv4 detector (hpe.py:51-73) is bypassed: the caller supplies the person box
- * (x1,x2,y1,y2 pixel ints, the order estimate() returns them in, hpe.py:173).
+ * The person box (x1,x2,y1,y2 pixel ints, the order estimate() returns them in, hpe.py:173) is an input: it comes from
+ * isb_det_forward + isb_hpe_select_person (the reference's detector + post-processing, hpe.py:51-79) or from the caller.
  * ---------------------------------------------------------------------------------------- */
 typedef struct isb_hpe isb_hpe;
 
@@ -162,6 +162,39 @@ int isb_hpe_select_person(isb_hpe* h, const float* d_boxes, const float* d_confs
                           int32_t* d_bbox, uint8_t* d_found, void* stream);
 int isb_hpe_select_person_host(isb_hpe* h, const float* h_boxes, const float* h_confs, int32_t B, float conf_thresh,
                                int32_t* h_bbox, uint8_t* h_found);
+
+/* ------------------------------------------------------------------------------------------
+ * YOLOv4 person detector
+ *   replaces  Runner(model_config.yolo_engine_path)        modules/hpe/hpe.py:42   (engine load)
+ *             the pre-processing + self.yolo(yolo_in) call modules/hpe/hpe.py:51-60
+ *   contract of the engine: modules/hpe/setup/1_extract_yolo_onnx.py:21-25,44-60 (Yolov4(n_classes=80, inference=True) of the
+ *   un-vendored Tianxiaomo/pytorch-YOLOv4 at 256 x 256; neither definition nor weights are in the reference tree: the network
+ *   here is the public architecture, "parity unpinned").
+ * Input: the BGR frames main.py:74 hands to estimate(); they are area-resized to 256 x 256 (cv2 INTER_AREA, hpe.py:51), turned
+ * to RGB and divided by 255 (hpe.py:53-56) on the device. Output: exactly what hpe.py:60 reshapes the engine outputs to --
+ *   d_boxes [B,4032,1,4] f32 (x1,y1,x2,y2 normalised), d_confs [B,4032,80] f32 -- ready for isb_hpe_select_person.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct isb_det isb_det;
+
+typedef struct isb_det_cfg {
+    int32_t width, height;    /* frame size (640 x 480) */
+    int32_t device;           /* HIP device ordinal */
+    int32_t max_batch;        /* frames per internal micro-batch; 0 = 16; clamped to 128 */
+} isb_det_cfg;
+
+int isb_det_create(const isb_det_cfg* cfg, isb_det** out);
+void isb_det_destroy(isb_det* h);
+/* the 110 convolutions in module order: name (e.g. "down3.resblock.module_list.4.1"; the blob tensors are
+ * yolo.<name>.{w,scale,shift}), dims = {cin, cout, k, stride, act (0 none, 2 Mish, 3 LeakyReLU 0.1), has_batchnorm} */
+int isb_det_n_convs(void);
+int isb_det_describe(int32_t idx, char* name, int32_t name_cap, int32_t* dims);
+/* ISBW blob with yolo.* (isbfsar_amd/yolov4.py: folded BatchNorm, [cout,k,k,cin] kernels). Synchronous. */
+int isb_det_load_weights(isb_det* h, const void* h_blob, size_t nbytes);
+int isb_det_forward(isb_det* h, const uint8_t* d_frames, int32_t B, float* d_boxes, float* d_confs, void* stream);
+int isb_det_forward_host(isb_det* h, const uint8_t* h_frames, int32_t B, float* h_boxes, float* h_confs);
+/* test hook (B <= max_batch): the pre-processed image f32 [B,256,256,3] RGB and the three raw detection maps
+ * f32 [B,32,32,256], [B,16,16,256], [B,8,8,256] (255 channels used); any output may be NULL */
+int isb_det_debug_host(isb_det* h, const uint8_t* h_frames, int32_t B, float* h_image, float* h_map8, float* h_map16, float* h_map32);
 
 /* stage-level entry points (host buffers, synchronous, B <= max_batch): each stage can be pinned
  * against the oracle on its own.

@@ -30,6 +30,10 @@ class isb_hpe_cfg(C.Structure):
                 ("max_batch", C.c_int32), ("n_out_joints", C.c_int32), ("reserved", C.c_int32)]
 
 
+class isb_det_cfg(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("device", C.c_int32), ("max_batch", C.c_int32)]
+
+
 _lib = None
 
 # name -> (restype, argtypes); every symbol include/isbfsar.h declares
@@ -64,6 +68,14 @@ SIGNATURES = {
     "isb_pose_windows": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "isb_hpe_select_person": (C.c_int, [_P, _P, _P, C.c_int32, C.c_float, _P, _P, _P]),
     "isb_hpe_select_person_host": (C.c_int, [_P, _P, _P, C.c_int32, C.c_float, _P, _P]),
+    "isb_det_create": (C.c_int, [C.POINTER(isb_det_cfg), C.POINTER(_P)]),
+    "isb_det_destroy": (None, [_P]),
+    "isb_det_n_convs": (C.c_int, []),
+    "isb_det_describe": (C.c_int, [C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_int32)]),
+    "isb_det_load_weights": (C.c_int, [_P, _P, C.c_size_t]),
+    "isb_det_forward": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P]),
+    "isb_det_forward_host": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
+    "isb_det_debug_host": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P]),
     "isb_debug_expand_dw": (C.c_int, [C.c_int32] + [_P] * 7 + [C.c_int32] * 5 + [_P, _P, C.POINTER(C.c_float)]),
     "isb_debug_fused_mb": (C.c_int, [C.c_int32] + [_P] * 8 + [C.c_int32] * 7 + [_P, C.POINTER(C.c_float)]),
     "isb_debug_dwconv": (C.c_int, [C.c_int32] + [_P] * 4 + [C.c_int32] * 5 + [_P, _P, C.POINTER(C.c_float)]),

@@ -58,6 +58,18 @@ __device__ __forceinline__ float silu_fast(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
 
+// activation codes (ConvArgs.act): 0 none, 1 SiLU (the pose backbone), 2 Mish, 3 LeakyReLU(0.1) (the YOLOv4 detector)
+__device__ __forceinline__ float mish_fast(float x) {
+    // x * tanh(softplus(x)) with n = e^x: tanh(ln(1 + n)) = n (n + 2) / (n (n + 2) + 2); one v_exp + one v_rcp.
+    // n is clamped so that n (n + 2) stays finite (for x > 20 the factor is 1 to f32 precision anyway)
+    const float n = __builtin_amdgcn_exp2f(1.4426950408889634f * fminf(x, 20.0f));
+    const float w = n * (n + 2.0f);
+    return x * w * __builtin_amdgcn_rcpf(w + 2.0f);
+}
+__device__ __forceinline__ float act_other(int act, float x) {     // act >= 2 (wave-uniform)
+    return act == 2 ? mish_fast(x) : (x > 0.f ? x : 0.1f * x);
+}
+
 // epilogue shared by the register-staged and the LDS-DMA kernels
 // BIAS_LDS: the tile's bias row already sits in LDS at byte offset bias_off (requested at kernel start); else it is
 // read from global now.
@@ -103,7 +115,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
                     const float4 bs = *reinterpret_cast<const float4*>(p.bias + n);
                     float4 v = make_float4(acc[i][j][4 * q] + bs.x, acc[i][j][4 * q + 1] + bs.y, acc[i][j][4 * q + 2] + bs.z,
                                            acc[i][j][4 * q + 3] + bs.w);
-                    if (p.act) { v.x = silu_fast(v.x); v.y = silu_fast(v.y); v.z = silu_fast(v.z); v.w = silu_fast(v.w); }
+                    if (p.act == 1) { v.x = silu_fast(v.x); v.y = silu_fast(v.y); v.z = silu_fast(v.z); v.w = silu_fast(v.w); }
+                    else if (p.act) { v.x = act_other(p.act, v.x); v.y = act_other(p.act, v.y); v.z = act_other(p.act, v.z); v.w = act_other(p.act, v.w); }
                     *reinterpret_cast<float4*>(out32 + (size_t)m * p.Cout + n) = v;
                 }
         }
@@ -132,7 +145,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
                     if constexpr (BIAS_LDS) bs = *reinterpret_cast<const float4*>(lds + bias_off + nl * 4);
                     else bs = *reinterpret_cast<const float4*>(p.bias + n);
                     v0 += bs.x; v1 += bs.y; v2 += bs.z; v3 += bs.w;
-                    if (p.act) { v0 = silu_fast(v0); v1 = silu_fast(v1); v2 = silu_fast(v2); v3 = silu_fast(v3); }
+                    if (p.act == 1) { v0 = silu_fast(v0); v1 = silu_fast(v1); v2 = silu_fast(v2); v3 = silu_fast(v3); }
+                    else if (p.act) { v0 = act_other(p.act, v0); v1 = act_other(p.act, v1); v2 = act_other(p.act, v2); v3 = act_other(p.act, v3); }
                     if (p.res && mok) {       // (requesting all residual pieces up front measured 5-7 % slower, twice)
                         const uint2 rr = *reinterpret_cast<const uint2*>(p.res + (size_t)m * p.Cout + n);
                         v0 += bf2f_((uint16_t)(rr.x & 0xffff)); v1 += bf2f_((uint16_t)(rr.x >> 16));
@@ -211,7 +225,8 @@ __device__ __forceinline__ void conv_epilogue_wl(const ConvArgs& p, f32x16 (&acc
         for (int q = 0; q < 4; ++q) {
             const float4 bs = *reinterpret_cast<const float4*>(lds + bias_off + (nl0 + 8 * q + 4 * h) * 4);
             float v0 = acc[i][j][4 * q] + bs.x, v1 = acc[i][j][4 * q + 1] + bs.y, v2 = acc[i][j][4 * q + 2] + bs.z, v3 = acc[i][j][4 * q + 3] + bs.w;
-            if (p.act) { v0 = silu_fast(v0); v1 = silu_fast(v1); v2 = silu_fast(v2); v3 = silu_fast(v3); }
+            if (p.act == 1) { v0 = silu_fast(v0); v1 = silu_fast(v1); v2 = silu_fast(v2); v3 = silu_fast(v3); }
+            else if (p.act) { v0 = act_other(p.act, v0); v1 = act_other(p.act, v1); v2 = act_other(p.act, v2); v3 = act_other(p.act, v3); }
             if (has_res) {
                 const uint2 rr = *reinterpret_cast<const uint2*>(st + r * WL_SROW + q * 16 + h * 8);
                 v0 += bf2f_((uint16_t)(rr.x & 0xffff)); v1 += bf2f_((uint16_t)(rr.x >> 16));
@@ -1520,7 +1535,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c32_rows_kernel(ConvArgs p, in
             unsigned char* cell = Cs + q * 64 + ((qq ^ swq) << 4) + 8 * h;
             float v0 = acc[4 * qq] + bias4[qq].x, v1 = acc[4 * qq + 1] + bias4[qq].y, v2 = acc[4 * qq + 2] + bias4[qq].z,
                   v3 = acc[4 * qq + 3] + bias4[qq].w;
-            if (p.act) { v0 = silu_fast(v0); v1 = silu_fast(v1); v2 = silu_fast(v2); v3 = silu_fast(v3); }
+            if (p.act == 1) { v0 = silu_fast(v0); v1 = silu_fast(v1); v2 = silu_fast(v2); v3 = silu_fast(v3); }
+            else if (p.act) { v0 = act_other(p.act, v0); v1 = act_other(p.act, v1); v2 = act_other(p.act, v2); v3 = act_other(p.act, v3); }
             if (has_res) {
                 const uint2 rr = *reinterpret_cast<const uint2*>(cell);
                 v0 += bf2f_((uint16_t)(rr.x & 0xffff)); v1 += bf2f_((uint16_t)(rr.x >> 16));
@@ -1964,7 +1980,7 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
             if (g1 && !a.gate) v = 138;
             else if (g1 && a.gate && ohw % 64 == 0) v = 147;
             else v = (!a.gate && a.zeros) ? 64 : 75;
-        } else if (g1 && !a.gate && !a.res && !a.out_f32 && a.splits <= 1 && wsreg_on() && a.Cout % WS_BN == 0 &&
+        } else if (g1 && !a.gate && !a.res && !a.out_f32 && a.act <= 1 && a.splits <= 1 && wsreg_on() && a.Cout % WS_BN == 0 &&
                    (a.Cin == 96 || a.Cin == 192 || a.Cin == 224 || a.Cin == 384) && a.M >= 64 * WS_BM && (size_t)a.M * a.Cin * 2 < 0xffffffffull) {
             v = 181;                                   // weights-stationary persistent GEMM (short-K expand convolutions)
         } else if (g1 && !a.gate) {
@@ -1984,7 +2000,7 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
             else v = 142;                              // 128 x 128
         } else if (!a.gate && a.KH == 3 && a.KW == 3 && ((a.stride == 1 && a.pad == 1) || (a.stride == 2 && a.pad == 0)) &&
                    (size_t)a.B * a.H * a.W * a.Cin * 2 + (size_t)(a.W + 1) * a.Cin * 2 < 0x7ffffff0ull) {
-            if (a.Cout == 32 && a.Cin == 32 && a.stride == 1 && a.W == 128 && a.H % 2 == 0 && !a.out_f32)
+            if (a.Cout == 32 && a.Cin == 32 && a.stride == 1 && a.W == 128 && a.H % 2 == 0 && !a.out_f32 && a.act <= 1)
                 v = 171;                              // rows ring in LDS, +50 % over the implicit GEMM (bit-identical)
             else if (a.Cout == 32) v = 163;           // 256 x  32   (lean 3x3, buffer-addressed A operand)
             else if (a.Cout % 192 == 0 && a.stride == 1 && a.Cin == 96 && a.W == 32 && a.H % 4 == 0 && conv3_halo())
@@ -2178,7 +2194,7 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
     } while (0)
         case 181: {                                          // weights-stationary persistent GEMM, 96 x 192 tiles, 6 waves, 1 per CU
             const int n_mt = cdiv(a.M, WS_BM), nsl = a.Cout / WS_BN;
-            if (a.gate || a.res || a.out_f32 || a.KH != 1 || a.stride != 1 || a.pad != 0 || a.splits > 1 || a.Cout % WS_BN != 0 ||
+            if (a.gate || a.res || a.out_f32 || a.act > 1 || a.KH != 1 || a.stride != 1 || a.pad != 0 || a.splits > 1 || a.Cout % WS_BN != 0 ||
                 nsl > 128 || (a.Cin != 96 && a.Cin != 192 && a.Cin != 224 && a.Cin != 384) || (size_t)a.M * a.Cin * 2 >= 0xffffffffull) {
                 set_error("conv_igemm: variant 181 is an un-gated 1x1 GEMM without residual, Cin 96/192/224/384, Cout %% 192 == 0");
                 return ISB_ERR_INVALID;

@@ -246,4 +246,12 @@ int launch_select_person(const float* boxes, const float* confs, int B, int n_an
                          int32_t* bbox, uint8_t* found, hipStream_t st);
 int launch_pose_windows(const float* joints, int n_cam, int n_frames, int J, int L, float* windows, hipStream_t st);
 
+// ---------------------------------------------------------------- det_kernels.hip (YOLOv4 person detector)
+int launch_det_preprocess(const uint8_t* frames, int B, int FH, int FW, float* out, hipStream_t st);
+int launch_det_stem(const StemArgs& a, hipStream_t st);      // conv 3x3 s1 p1, 3 -> 32, Mish (StemArgs.H/W = map size)
+int launch_concat(const uint16_t* a, const uint16_t* b, uint16_t* out, int B, int H, int W, int Ca, int Cb, int up_b, hipStream_t st);
+int launch_spp(const uint16_t* in, uint16_t* out, int B, int H, int W, int C, hipStream_t st);
+int launch_yolo_decode(const float* map, int B, int H, int W, int ldm, const float* anchors_wh, float sxy, float* boxes, float* confs,
+                       int n_boxes, int box_off, hipStream_t st);
+
 }  // namespace isb

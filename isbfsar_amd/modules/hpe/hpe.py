@@ -6,10 +6,11 @@ and the per-frame consumer (``main.py:77-105``) run unmodified:
     estimate(frame uint8[480,640,3] BGR) -> None | {"pose": float64[n,3], "edges": [...], "bbox": (x1,x2,y1,y2)}
     just_box mode                         -> {"bbox": (x1,y1,x2,y2)}            (hpe.py:82-83)
 
-The YOLOv4 network itself (hpe.py:51-59, an un-vendored engine) is not part of this build: pass
-``detector(frame) -> (boxes, confs)`` (the YOLO export tensors; their post-processing, hpe.py:60-79,
-runs on the GPU) or ``bbox_provider(frame) -> (x1,x2,y1,y2) | None`` (default:
-``model_config.fixed_bbox`` or the whole frame). Everything after that runs on the GPU; no CPU path.
+The person box comes, in this order of precedence, from: ``detector(frame) -> (boxes, confs)`` (any callable returning
+the YOLO export tensors); the built-in YOLOv4 detector (``isb_det_*``: pre-processing hpe.py:51-56 + network hpe.py:59,
+used when ``model_config.yolo_weights`` / ``yolo_weights_path`` / ``yolo_synthetic`` is set); ``bbox_provider(frame) ->
+(x1,x2,y1,y2) | None``; ``model_config.fixed_bbox``; the whole frame. Detector outputs are post-processed on the GPU
+(hpe.py:60-79). Everything runs on the GPU; there is no CPU path.
 """
 from __future__ import annotations
 
@@ -45,6 +46,21 @@ class HumanPoseEstimator:
         self.bbox_provider = bbox_provider
         self.detector = detector          # callable(frame) -> (boxes [1,4032,1,4], confs [1,4032,80]) like Runner(yolo)
         self.fixed_bbox = getattr(model_config, "fixed_bbox", None)
+
+        # the reference's Runner(yolo_engine_path) (hpe.py:42): the built-in YOLOv4 network, when weights are configured
+        self.det = None
+        yw = getattr(model_config, "yolo_weights", None)
+        if yw is None and getattr(model_config, "yolo_weights_path", None):
+            with open(model_config.yolo_weights_path, "rb") as f:
+                yw = f.read()
+        if yw is None and getattr(model_config, "yolo_synthetic", False):
+            from ... import yolov4
+            yw = yolov4.make_state(getattr(model_config, "weights_seed", 0))
+        if yw is not None and self.detector is None:
+            from ...det_engine import DetEngine
+            self.det = DetEngine(cam_config.width, cam_config.height, device=getattr(model_config, "device", 0), max_batch=1)
+            self.det.load_weights(yw)
+            self.detector = lambda frame: self.det.forward(np.asarray(frame, dtype=np.uint8)[None])
 
         self.engine = None
         if not self.just_box or self.detector is not None:

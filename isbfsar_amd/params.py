@@ -35,6 +35,9 @@ class MetrabsHIPConfig(object):
         self.weights = None                    # mapping name -> ndarray, or bytes (ISBW)
         self.weights_path = None               # path to an .isbw blob
         self.weights_seed = 0                  # used when neither is given: deterministic synthetic weights
+        self.yolo_weights = None               # YOLOv4 detector (the reference's yolo_engine_path, params.py:27): mapping / ISBW
+        self.yolo_weights_path = None          # bytes / path to an .isbw blob (isbfsar_amd/yolov4.py); none of them set: no
+        self.yolo_synthetic = False            # built-in detector (boxes come from bbox_provider / fixed_bbox / the whole frame)
         self.expand_joints_path = os.path.join(_ASSETS, "32_to_122.npy")
         self.skeleton_types_path = os.path.join(_ASSETS, "skeleton_types.json")
         self.skeleton = skeleton_type

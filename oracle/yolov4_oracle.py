@@ -30,22 +30,32 @@ N_CLASSES = 80
 
 def area_resize_u8(frame: np.ndarray, out_hw: int = 256) -> np.ndarray:
     """cv2.resize(frame, (256, 256), interpolation=INTER_AREA) for a uint8 image (hpe.py:51): every output pixel is the
-    area-weighted mean of the source rectangle it covers, rounded to the nearest integer (ties to even)."""
+    area-weighted mean of the source rectangle it covers, rounded to the nearest integer (ties to even). Separable, rows
+    first then columns, float32 products and sums in ascending source order (the order the HIP kernel uses)."""
     H, W, _ = frame.shape
 
-    def weights(n_in, n_out):
+    def taps(n_in, n_out):
         sc = n_in / n_out
-        m = np.zeros((n_out, n_in), np.float64)
+        out = []
         for o in range(n_out):
             lo, hi = o * sc, (o + 1) * sc
-            for i in range(int(np.floor(lo)), min(int(np.ceil(hi)), n_in)):
-                m[o, i] = max(0.0, min(hi, i + 1) - max(lo, i)) / sc
-        return m.astype(np.float32)
+            idx = list(range(int(np.floor(lo)), min(int(np.ceil(hi)), n_in)))
+            out.append([(i, np.float32(max(0.0, min(hi, i + 1) - max(lo, i)) / sc)) for i in idx])
+        return out
 
-    wy, wx = weights(H, out_hw), weights(W, out_hw)
     img = frame.astype(np.float32)
-    out = np.einsum("oy,yxc->oxc", wy, img)
-    out = np.einsum("px,oxc->opc", wx, out)
+    rows = np.zeros((out_hw, W, 3), np.float32)
+    for o, tp in enumerate(taps(H, out_hw)):
+        acc = np.zeros((W, 3), np.float32)
+        for i, w in tp:
+            acc = acc + w * img[i]
+        rows[o] = acc
+    out = np.zeros((out_hw, out_hw, 3), np.float32)
+    for o, tp in enumerate(taps(W, out_hw)):
+        acc = np.zeros((out_hw, 3), np.float32)
+        for i, w in tp:
+            acc = acc + w * rows[:, i]
+        out[:, o] = acc
     return np.clip(np.rint(out), 0, 255).astype(np.uint8)
 
 
