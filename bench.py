@@ -187,7 +187,16 @@ def main():
         local = 0
     backend = os.environ.get("ISB_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
-    if world > 1:
+    # ISB_BENCH_FORCE_DIST=1: run the N > 1 code path (process group on RCCL, side-stream all-gather, barrier, all-reduce of the
+    # time) with ONE rank -- the only way to exercise the real RCCL calls on a one-GPU box; never used by the driver
+    force_dist = os.environ.get("ISB_BENCH_FORCE_DIST") == "1" and world == 1
+    if force_dist:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+    dist_on = world > 1 or force_dist
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -195,7 +204,7 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    W = pick_workload(args.workload)(args, rank, world, local)
+    W = pick_workload(args.workload)(args, rank, 2 if force_dist else world, local)      # (force: the workload takes its N > 1 branch)
     # set-up, not measurement: the first calls allocate the per-lane activation workspaces and load the code objects
     # (and, for N > 1, establish the RCCL rings), and a fraction of a second of load brings the clocks to their sustained
     # state (a 100-step run averages 19.9 ms per step, the first steps after start-up 21); the W warm-up steps the
@@ -205,7 +214,7 @@ def main():
     torch.cuda.synchronize()
 
     def barrier():
-        if world > 1:
+        if dist_on:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -218,7 +227,7 @@ def main():
         W.step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -232,7 +241,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = W.cpu_baseline(args.cpu_sample, max(1, args.cpu_iters))
     devices = [f"cuda:{local}"]
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
         world = dist.get_world_size()                    # what the process group says, not what the flags said
         gathered = [None] * world
@@ -253,7 +262,7 @@ def main():
             "world_size": world, "devices": devices,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -8,6 +8,7 @@ There is no cross-rank arithmetic, so a sharded run is bit-identical to the unsh
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 
@@ -44,7 +45,7 @@ def all_gather_records(rec, counts=None):
     import torch
     import torch.distributed as dist
     world = dist.get_world_size()
-    if world == 1:
+    if world == 1 and os.environ.get("ISB_BENCH_FORCE_DIST") != "1":     # (the switch: exercise the collective with one rank)
         return rec
     if rec.is_cuda and dist.get_backend() == "gloo":
         # gloo has no device all-gather: only reached when the N > 1 path is rehearsed on a one-GPU box

@@ -235,3 +235,21 @@ def test_bench_launches_its_own_ranks():
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                         env=env2, capture_output=True, text=True, timeout=300)
     assert r2.returncode == 2 and "refusing" in r2.stderr
+
+
+def test_bench_rccl_path_with_one_rank():
+    """The N > 1 branch of bench.py on REAL RCCL calls with a one-rank process group (ISB_BENCH_FORCE_DIST=1): process group
+    on the "nccl" backend, the match stage + all_gather_into_tensor on the side stream beside the next step's pose stage,
+    barrier, MAX all-reduce of the time, all_gather_object of the device list. A one-GPU box cannot hold two RCCL ranks
+    (duplicate device), so this is as close as a test here gets to the driver's 2/4/8-GPU runs; the two-rank logic is
+    covered over gloo (test_bench_launches_its_own_ranks, tests/test_dist_cpu.py)."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(ISB_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "64",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["world_size"] == 1 and line["value"] > 0 and line["devices"] == ["rank0=cuda:0"]
