@@ -80,6 +80,12 @@ struct isb_hpe {
     Lane lanes[kMaxLanes];
     int n_lanes = 2;              // ISB_HPE_LANES=1 disables the split, up to kMaxLanes
     hipEvent_t fork_ev = nullptr, join_ev[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
+    // host-buffer entry point: persistent staging (grow-only) + a copy stream so that the H2D of chunk i + 1 travels
+    // while chunk i computes
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t h2d_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    DevBuf hs_frames, hs_bbox, hs_joints, hs_valid;
+    int hs_B = 0;
     // profiling of conv_igemm launches
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
@@ -378,6 +384,8 @@ extern "C" int isb_hpe_create(const isb_hpe_cfg* cfg, isb_hpe** out) {
     if (const char* e = getenv("ISB_FUSE_BLOCK_CEXP")) h->fuse_block_max_cexp = atoi(e);
     if (const char* e = getenv("ISB_HPE_LANES")) h->n_lanes = std::max(1, std::min(kMaxLanes, atoi(e)));
     ISB_HIP(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
+    ISB_HIP(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    for (auto& e : h->h2d_ev) ISB_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (int l = 1; l < kMaxLanes; ++l) {
         ISB_HIP(hipStreamCreateWithFlags(&h->lanes[l].side, hipStreamNonBlocking));
         ISB_HIP(hipEventCreateWithFlags(&h->join_ev[l], hipEventDisableTiming));
@@ -401,6 +409,9 @@ extern "C" void isb_hpe_destroy(isb_hpe* h) {
         if (h->join_ev[l]) (void)hipEventDestroy(h->join_ev[l]);
     }
     if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+    for (auto& e : h->h2d_ev)
+        if (e) (void)hipEventDestroy(e);
     delete h;
 }
 
@@ -588,16 +599,38 @@ extern "C" int isb_hpe_forward_host(isb_hpe* h, const uint8_t* frames, const int
     ISB_HIP(hipSetDevice(h->cfg.device));
     hipStream_t st = h->own_stream;
     const size_t fsz = (size_t)h->cfg.height * h->cfg.width * 3;
-    DevBuf df, db, dj, dv;
-    ISB_TRY(df.alloc(fsz * B));
-    ISB_TRY(db.alloc((size_t)B * 16));
-    ISB_TRY(dj.alloc((size_t)B * h->n_out * 12));
-    ISB_TRY(dv.alloc((size_t)B));
-    ISB_HIP(hipMemcpyAsync(df.p, frames, fsz * B, hipMemcpyHostToDevice, st));
-    ISB_HIP(hipMemcpyAsync(db.p, bbox, (size_t)B * 16, hipMemcpyHostToDevice, st));
-    ISB_TRY(isb_hpe_forward(h, df.as<uint8_t>(), db.as<int32_t>(), B, dj.as<float>(), dv.as<uint8_t>(), st));
-    ISB_HIP(hipMemcpyAsync(joints, dj.p, (size_t)B * h->n_out * 12, hipMemcpyDeviceToHost, st));
-    ISB_HIP(hipMemcpyAsync(valid, dv.p, (size_t)B, hipMemcpyDeviceToHost, st));
+    if (B > h->hs_B) {                          // staging buffers live in the handle (no hipMalloc per call), grow-only
+        h->hs_B = 0;
+        ISB_TRY(h->hs_frames.alloc(fsz * B));
+        ISB_TRY(h->hs_bbox.alloc((size_t)B * 16));
+        ISB_TRY(h->hs_joints.alloc((size_t)B * 122 * 12));
+        ISB_TRY(h->hs_valid.alloc((size_t)B));
+        h->hs_B = B;
+    }
+    uint8_t* df = h->hs_frames.as<uint8_t>();
+    int32_t* db = h->hs_bbox.as<int32_t>();
+    float* dj = h->hs_joints.as<float>();
+    uint8_t* dv = h->hs_valid.as<uint8_t>();
+    // up to four chunks of >= 256 frames: the frames of chunk i + 1 cross PCIe (copy stream) while chunk i computes. Smaller
+    // batches go in one piece: measured at 256 frames, two chunks of 128 lose in launch efficiency (64-frame lanes) exactly what
+    // the overlapped copy gains (23.6 ms either way, 18.0 with resident frames)
+    const int n_chunks = std::max(1, std::min(4, B / 256));
+    const int per = (B + n_chunks - 1) / n_chunks;
+    ISB_HIP(hipMemcpyAsync(db, bbox, (size_t)B * 16, hipMemcpyHostToDevice, st));
+    for (int c = 0; c < n_chunks; ++c) {
+        const int b0 = c * per, n = std::min(per, B - b0);
+        if (n <= 0) break;
+        ISB_HIP(hipMemcpyAsync(df + (size_t)b0 * fsz, frames + (size_t)b0 * fsz, fsz * n, hipMemcpyHostToDevice, h->copy_stream));
+        ISB_HIP(hipEventRecord(h->h2d_ev[c], h->copy_stream));
+    }
+    for (int c = 0; c < n_chunks; ++c) {
+        const int b0 = c * per, n = std::min(per, B - b0);
+        if (n <= 0) break;
+        ISB_HIP(hipStreamWaitEvent(st, h->h2d_ev[c], 0));
+        ISB_TRY(isb_hpe_forward(h, df + (size_t)b0 * fsz, db + (size_t)b0 * 4, n, dj + (size_t)b0 * h->n_out * 3, dv + b0, st));
+    }
+    ISB_HIP(hipMemcpyAsync(joints, dj, (size_t)B * h->n_out * 12, hipMemcpyDeviceToHost, st));
+    ISB_HIP(hipMemcpyAsync(valid, dv, (size_t)B, hipMemcpyDeviceToHost, st));
     ISB_HIP(hipStreamSynchronize(st));
     return ISB_OK;
     });
