@@ -794,8 +794,8 @@ extern "C" int isb_debug_conv(int32_t device, const uint16_t* x, const float* w,
     a.variant = variant % 1000;
     DevBuf dpart;
     if (variant >= 900000) {                    // kernels with in-kernel time stamps (tuning probes): 900181, 900131, 900143, ...
-        ISB_TRY(dpart.alloc(64 * 1024));
-        ISB_HIP(hipMemset(dpart.p, 0, 64 * 1024));
+        ISB_TRY(dpart.alloc(128 * 1024));
+        ISB_HIP(hipMemset(dpart.p, 0, 128 * 1024));
         a.part = dpart.as<float>();
         a.probe = 2;
         a.variant = variant - 900000;
@@ -819,7 +819,7 @@ extern "C" int isb_debug_conv(int32_t device, const uint16_t* x, const float* w,
     (void)hipEventDestroy(e1);
     *ms_per_iter = ms / iters;
     ISB_HIP(hipMemcpy(out, dout.p, nout * 2, hipMemcpyDeviceToHost));
-    if (variant >= 900000 && variant != 900181) {   // the tile GEMMs: per workgroup {prologue, DMA wait, barrier wait, k loop, epilogue, k-steps}
+    if (variant >= 900000 && variant != 900181 && variant != 900182 && variant != 900183 && variant != 900184) {   // the tile GEMMs: per workgroup {prologue, DMA wait, barrier wait, k loop, epilogue, k-steps}
         std::vector<uint64_t> st(64 * 8);
         ISB_HIP(hipMemcpy(st.data(), dpart.p, 64 * 64, hipMemcpyDeviceToHost));
         double sum[5] = {0, 0, 0, 0, 0};
@@ -838,7 +838,78 @@ extern "C" int isb_debug_conv(int32_t device, const uint16_t* x, const float* w,
             fprintf(stderr, "mean of %d workgroups (cycles, wave 0): prologue %.0f | k loop %.0f of which DMA wait %.0f, barrier wait %.0f | epilogue %.0f\n",
                     n, sum[0] / n, sum[3] / n, sum[1] / n, sum[2] / n, sum[4] / n);
     }
-    if (variant == 900181) {                    // print the stamps of the last launch: cycles per phase, per tile
+    if (variant == 900183 || variant == 900184) {                        // wave 0: cycles per phase of tiles 1..4
+        std::vector<uint64_t> st(64 * 128);
+        ISB_HIP(hipMemcpy(st.data(), dpart.p, 64 * 1024, hipMemcpyDeviceToHost));
+        {   // every workgroup's entry / exit on the constant 100 MHz counter
+            std::vector<uint64_t> rt(2 * 1024);
+            ISB_HIP(hipMemcpy(rt.data(), (const char*)dpart.p + 64 * 1024, 16 * 1024, hipMemcpyDeviceToHost));
+            uint64_t e_min = ~0ull, e_max = 0, x_min = ~0ull, x_max = 0;
+            int n = 0;
+            for (int g = 0; g < 1024; ++g) {
+                if (!rt[2 * g] || !rt[2 * g + 1]) continue;
+                e_min = std::min(e_min, rt[2 * g]); e_max = std::max(e_max, rt[2 * g]);
+                x_min = std::min(x_min, rt[2 * g + 1]); x_max = std::max(x_max, rt[2 * g + 1]);
+                ++n;
+            }
+            if (n) {
+                const int nwg = (a.variant == 184) ? 512 : 256, nsl = cdiv(Cout, 128), Q = std::max(1, nwg / nsl);
+                double xs[8] = {0}, ss[64] = {0}; int xn[8] = {0}, sn[64] = {0};
+                for (int g = 0; g < nwg; ++g) {
+                    if (!rt[2 * g] || !rt[2 * g + 1]) continue;
+                    const double d = (double)(rt[2 * g + 1] - rt[2 * g]) * 0.01;
+                    const int idx = (g & 7) * (nwg >> 3) + (g >> 3), sl = idx % nsl;
+                    xs[g & 7] += d; ++xn[g & 7];
+                    if (idx / nsl < Q && sl < 64) { ss[sl] += d; ++sn[sl]; }
+                }
+                {
+                    std::vector<std::pair<double, int>> ds;
+                    for (int g = 0; g < nwg; ++g)
+                        if (rt[2 * g] && rt[2 * g + 1]) ds.push_back({(double)(rt[2 * g + 1] - rt[2 * g]) * 0.01, g});
+                    std::sort(ds.begin(), ds.end());
+                    fprintf(stderr, "workgroup duration deciles (us):");
+                    for (int d = 0; d <= 10; ++d) fprintf(stderr, " %.1f", ds[std::min(ds.size() - 1, ds.size() * d / 10)].first);
+                    fprintf(stderr, "\nslowest:");
+                    for (size_t k = ds.size() - 8; k < ds.size(); ++k) {
+                        const int g = ds[k].second, idx = (g & 7) * (nwg >> 3) + (g >> 3);
+                        fprintf(stderr, " [g %d xcd %d slice %d q %d: %.1f]", g, g & 7, idx % nsl, idx / nsl, ds[k].first);
+                    }
+                    fprintf(stderr, "\nfastest:");
+                    for (size_t k = 0; k < 8; ++k) {
+                        const int g = ds[k].second, idx = (g & 7) * (nwg >> 3) + (g >> 3);
+                        fprintf(stderr, " [g %d xcd %d slice %d q %d: %.1f]", g, g & 7, idx % nsl, idx / nsl, ds[k].first);
+                    }
+                    fprintf(stderr, "\n");
+                }
+                fprintf(stderr, "mean workgroup duration by XCD (us):");
+                for (int x = 0; x < 8; ++x) fprintf(stderr, " %.1f", xn[x] ? xs[x] / xn[x] : 0.0);
+                fprintf(stderr, "\nmean workgroup duration by channel slice (us):");
+                for (int x = 0; x < nsl && x < 64; ++x) fprintf(stderr, " %.1f", sn[x] ? ss[x] / sn[x] : 0.0);
+                fprintf(stderr, "\n");
+            }
+            if (n)
+                fprintf(stderr, "%d workgroups: entries spread over %.2f us, first exit at %.2f us, last exit at %.2f us after the first entry\n", n,
+                        (double)(e_max - e_min) * 0.01, (double)(x_min - e_min) * 0.01, (double)(x_max - e_min) * 0.01);
+        }
+        uint64_t t_first = ~0ull;
+        for (int g = 0; g < 64; ++g)
+            if (st[(size_t)g * 128 + 120]) t_first = std::min(t_first, st[(size_t)g * 128 + 120]);
+        for (int g : {0, 1, 2, 8, 16, 33, 63}) {
+            const uint64_t* w = st.data() + (size_t)g * 128 + 120;
+            if (!w[0]) continue;
+            fprintf(stderr, "wg %2d: entry at +%6lld | prologue %6lld | %2lld tiles in %7lld | last epilogue %6lld | entry to exit %7lld cycles = %.1f us (%.2f GHz)\n", g,
+                    (long long)(w[0] - t_first), (long long)(w[1] - w[0]), (long long)w[4], (long long)(w[2] - w[1]), (long long)(w[3] - w[2]),
+                    (long long)(w[3] - w[0]), (double)(w[6] - w[5]) * 0.01, (double)(w[3] - w[0]) / ((double)(w[6] - w[5]) * 10.0));
+        }
+        for (int g : {0, 1, 8, 33})
+            for (int tl = 0; tl < 4; ++tl) {
+                const uint64_t* s0 = st.data() + (size_t)g * 128 + tl * 8;
+                if (!s0[0]) continue;
+                fprintf(stderr, "wg %2d tile %d: barrier %5lld  tile pass %5lld  accumulator copy %5lld  total %5lld\n", g, tl + 1,
+                        (long long)(s0[1] - s0[0]), (long long)(s0[2] - s0[1]), (long long)(s0[3] - s0[2]), (long long)(s0[3] - s0[0]));
+            }
+    }
+    if (variant == 900181 || variant == 900182) {   // print the stamps of the last launch: cycles per phase, per tile
         std::vector<uint64_t> st(64 * 128);
         ISB_HIP(hipMemcpy(st.data(), dpart.p, 64 * 1024, hipMemcpyDeviceToHost));
         for (int g : {0, 1, 8, 33}) {
@@ -846,8 +917,8 @@ extern "C" int isb_debug_conv(int32_t device, const uint16_t* x, const float* w,
                 for (int half = 0; half < 2; ++half) {
                     const uint64_t* s0 = st.data() + (size_t)g * 128 + (tl * 2 + half) * 8;
                     if (!s0[0]) continue;
-                    fprintf(stderr, "wg %2d tile %d wave %d: barrier %5lld  first phase %5lld  second phase %5lld  total %5lld\n", g,
-                            tl + 1, half * 4, (long long)(s0[1] - s0[0]), (long long)(s0[2] - s0[1]), (long long)(s0[3] - s0[2]),
+                    fprintf(stderr, "wg %2d tile %d wave %c: barrier %5lld  first phase %5lld  second phase %5lld  total %5lld\n", g,
+                            tl + 1, half ? 'B' : 'A', (long long)(s0[1] - s0[0]), (long long)(s0[2] - s0[1]), (long long)(s0[3] - s0[2]),
                             (long long)(s0[3] - s0[0]));
                 }
         }

@@ -10,7 +10,7 @@ w = (rng.normal(0, 1, (cout, 1, 1, cin)) / np.sqrt(cin)).astype(np.float32)
 sc = np.ones(cout, np.float32); sh = np.zeros(cout, np.float32)
 mode = sys.argv[1] if len(sys.argv) > 1 else "stamp"
 if mode == "stamp":
-    _, ms = conv_debug(x, w, sc, sh, 1, 1, 1, None, None, variant=900181, iters=5)
+    _, ms = conv_debug(x, w, sc, sh, 1, 1, 1, None, None, variant=900000 + int(os.environ.get('EXP_V', '181')), iters=5)
     print(f"stamped v181 probe={os.environ.get('ISB_WS_PROBE','0')} {ms*1e3:7.1f} us", flush=True)
 else:
     for act in (1, 0):
