@@ -1317,16 +1317,23 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-template <int NK, bool ACT, bool STAMPS = false, int TMB = 4>
-__global__ __launch_bounds__(256, TMB == 4 ? 1 : 2) void gemm1x1_wspipe_kernel(ConvArgs p) {
-    constexpr int K = 32 * NK, NW = 4;
-    constexpr int BM = 32 * TMB, BN = 32 * NW;
+// TMB = 32-row blocks per WAVE, NWM = waves along the rows (the workgroup has 4 NWM waves: 4 channel blocks x NWM row groups),
+// WPC = workgroups per CU; waves per SIMD = NWM WPC (1: staging in a[200:255], 2: in v[228:255]).
+template <int NK, bool ACT, bool STAMPS = false, int TMB = 4, int WPC = (TMB == 4 ? 1 : 2), int NWM = 1>
+__global__ __launch_bounds__(256 * NWM, WPC) void gemm1x1_wspipe_kernel(ConvArgs p) {
+    constexpr int K = 32 * NK, NW = 4, NWT = NW * NWM;
+    constexpr int BM = 32 * TMB * NWM, BN = 32 * NW;
     constexpr int CHUNK = BM * ROWB, TILE = NK * CHUNK;
-    constexpr int PIECES = BM / (16 * NW);               // 16-row pieces per wave and k-step: 2 (128-row tiles) or 1 (64-row tiles)
-    constexpr int NLD = NK * PIECES;                     // 16-byte loads per lane and tile
+    constexpr int PPK = BM / 16;                         // 16-row pieces per k-step, dealt to the NWT waves in turn: piece P = x NWT + wave
+    static_assert(PPK % NWT == 0 || NWT % PPK == 0, "pieces and waves");
+    constexpr int JJ = PPK > NWT ? PPK / NWT : 1;        // row pieces per wave and k-step (128-row tiles of 4 waves: 2)
+    constexpr int SR = NWT > PPK ? NWT / PPK : 1;        // k-steps covered by one round of pieces (64-row tiles of 8 waves: 2)
+    constexpr int NLD = NK * PPK / NWT;                  // 16-byte loads per lane and tile
     constexpr int SLOTS = 2 * TMB * NK;                  // MFMAs per tile and wave
     constexpr int NH = 16 * TMB;                         // epilogue halves per tile and wave
-    constexpr int RSET = TMB == 4 ? 0 : 1;               // which literal staging registers
+    constexpr int RSET = NWM * WPC == 1 ? 0 : 1;         // which literal staging registers (one or two waves per SIMD)
+    static_assert(NLD * NWT == NK * PPK, "whole pieces");
+    static_assert(NLD <= (RSET == 0 ? 14 : 7), "staging pieces");
     static_assert(SLOTS == 4 * NLD, "one piece every fourth slot");
     constexpr int STAGE_OFF = 2 * TILE;                  // per wave: two staging blocks (row blocks alternate)
     unsigned char* const lds = conv_lds_dyn;
@@ -1338,7 +1345,8 @@ __global__ __launch_bounds__(256, TMB == 4 ? 1 : 2) void gemm1x1_wspipe_kernel(C
     const int q = idx / nsl, slice = idx - q * nsl;
     const int n_mt = (p.M + BM - 1) / BM;
     if (q >= Q || q >= n_mt) return;
-    const int nw0 = slice * BN + 32 * wave;
+    const int wn = wave & 3, wmh = wave >> 2;             // channel block, row group
+    const int nw0 = slice * BN + 32 * wn;
     const bool live = nw0 < p.Cout;
 
     auto stamp_wg = [&](int slot) {             // probe: wave 0 of the first 64 workgroups, whole-kernel marks in slots 120..
@@ -1378,22 +1386,25 @@ __global__ __launch_bounds__(256, TMB == 4 ? 1 : 2) void gemm1x1_wspipe_kernel(C
     // the wait in front of each LDS write is explicit -- vmcnt(NLD - 1): the NLD - 1 pieces requested after the one being
     // written (and any epilogue stores, which only make the wait stricter) may still fly.
     const unsigned char* a_bytes = reinterpret_cast<const unsigned char*>(p.in);
-    uint32_t ld_off[PIECES];
-    int ld_row[PIECES];
+    // piece x of this wave: k-step s = SX(x) + s_base, row piece jj = JX(x) (rows 16 (NWT jj + wave % PPK) ..)
+    uint32_t ld_off[JJ];
+    int ld_row[JJ];
+    const int s_base = NWT > PPK ? wave / PPK : 0;
 #pragma unroll
-    for (int j = 0; j < PIECES; ++j) {
-        ld_row[j] = 16 * (NW * j + wave) + (lane >> 2);
-        ld_off[j] = (uint32_t)(((lane & 3) ^ ((ld_row[j] >> 2) & 3)) * 16);
+    for (int j = 0; j < JJ; ++j) {
+        ld_row[j] = 16 * (NWT * j + wave % PPK) + (lane >> 2);
+        ld_off[j] = (uint32_t)(((lane & 3) ^ ((ld_row[j] >> 2) & 3)) * 16) + (uint32_t)(s_base * 64);
     }
-    const uint32_t lds_wr = (uint32_t)(uintptr_t)(lds_ptr_t)lds + (uint32_t)(wave * 1024 + lane * 16);
+    const uint32_t lds_wr = (uint32_t)(uintptr_t)(lds_ptr_t)lds + (uint32_t)((wave % PPK) * 1024 + lane * 16 + s_base * CHUNK);
+#define ISB_WSP_SX(X) (NWT > PPK ? (X) * SR : (X) / JJ)
 #define ISB_WSP_LOAD(X, tile)                                                                                      \
-    wsp_request<RSET, (X), ((X) / PIECES) * 64>(a_bytes + (size_t)min((tile) * BM + ld_row[(X) % PIECES], p.M - 1) * (K * 2) + ld_off[(X) % PIECES])
+    wsp_request<RSET, (X), ISB_WSP_SX(X) * 64>(a_bytes + (size_t)min((tile) * BM + ld_row[(X) % JJ], p.M - 1) * (K * 2) + ld_off[(X) % JJ])
 #define ISB_WSP_STORE(X, buf, WAITN)                                                                               \
-    wsp_to_lds<RSET, (X), ((X) / PIECES) * CHUNK, (WAITN)>(lds_wr + (uint32_t)((buf) * TILE + NW * ((X) % PIECES) * 1024))
+    wsp_to_lds<RSET, (X), ISB_WSP_SX(X) * CHUNK, (WAITN)>(lds_wr + (uint32_t)((buf) * TILE + NWT * ((X) % JJ) * 1024))
 
     unsigned char* const stage = lds + STAGE_OFF + wave * (2 * WS_STAGE);
     uint16_t* const out16 = reinterpret_cast<uint16_t*>(p.out);
-    const int a_sw0 = swz(r, h), a_sw1 = swz(r, 2 + h);
+    const int a_sw0 = swz(r, h) + wmh * TMB * 2048, a_sw1 = swz(r, 2 + h) + wmh * TMB * 2048;
     f32x16 acc[TMB], accp[TMB];                 // tile being multiplied / tile being finished
 
     // The epilogue of the previous tile in 64 halves of a value pair -- quad = 4 values of row block i (pixel 32 i + r,
@@ -1426,7 +1437,7 @@ __global__ __launch_bounds__(256, TMB == 4 ? 1 : 2) void gemm1x1_wspipe_kernel(C
         for (int k2 = 0; k2 < 2; ++k2) {
             const int row = 16 * k2 + (lane >> 2), cc = lane & 3;
             const uint4 v = *reinterpret_cast<const uint4*>(stage + (i & 1) * WS_STAGE + row * WS_SROW + cc * 16);
-            const int m = min(m0 + 32 * i + row, p.M - 1);             // rows past M repeat row M - 1: same bytes, same address
+            const int m = min(m0 + 32 * (wmh * TMB + i) + row, p.M - 1);   // rows past M repeat row M - 1: same bytes, same address
             *reinterpret_cast<uint4*>(out16 + (size_t)m * p.Cout + nw0 + cc * 8) = v;
         }
     };
@@ -1528,6 +1539,7 @@ __global__ __launch_bounds__(256, TMB == 4 ? 1 : 2) void gemm1x1_wspipe_kernel(C
         }
         if (wave == 0 && lane == 0) reinterpret_cast<uint64_t*>(p.part)[8192 + 2 * g + 1] = rt;                              // ... and exit
     }
+#undef ISB_WSP_SX
 #undef ISB_WSP_LOAD
 #undef ISB_WSP_STORE
 }
@@ -2262,7 +2274,7 @@ static dim3 conv_grid(ConvArgs& a, int BM, int BN) {
     return dim3(8 * ((a.grid_m + 7) / 8) * a.grid_n, 1, z);
 }
 
-static int wsreg_on() {             // ISB_WSREG: weights-stationary kernel for the short-K expand convolutions. Default 184 (K <= 224);
+static int wsreg_on() {             // ISB_WSREG: weights-stationary kernel for the short-K expand convolutions. Default 184 (K <= 224; K = 384: 186);
                                     // 0 = tile kernels only, 181 / 182 / 183 = the earlier forms (A/B switch; 181 / 182 also take K = 384)
     static const int on = [] { const char* e = getenv("ISB_WSREG"); const int v = e ? atoi(e) : 184; return v == 1 ? 184 : v; }();
     return on;
@@ -2300,9 +2312,10 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
             else if (g1 && a.gate && ohw % 64 == 0) v = 147;
             else v = (!a.gate && a.zeros) ? 64 : 75;
         } else if (g1 && !a.gate && !a.res && !a.out_f32 && a.act <= 1 && a.splits <= 1 && wsreg_on() &&
-                   (a.Cin == 96 || a.Cin == 192 || a.Cin == 224 || (a.Cin == 384 && wsreg_on() < 183)) && a.Cout % 32 == 0 && a.M >= 64 * 128 &&
+                   (a.Cin == 96 || a.Cin == 192 || a.Cin == 224 || (a.Cin == 384 && wsreg_on() != 183 && wsreg_on() != 1840)) && a.Cout % 32 == 0 && a.M >= 64 * 128 &&
                    (size_t)a.M * a.Cin * 2 < 0xffffffffull) {
             v = wsreg_on();                                                      // weights-stationary persistent GEMM (short-K expand convolutions)
+            if (v >= 184) v = a.Cin == 384 ? 186 : 184;                          // (1840: K <= 224 only, A/B switch)                          // two waves per SIMD: 2 workgroups x 4 waves, or (K = 384) 1 x 8
         } else if (g1 && !a.gate) {
             if (a.Cout % 192 == 0) v = 131;            // 128 x 192
             else if (a.Cout == 64) v = 135;            // 256 x  64
@@ -2344,7 +2357,7 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
             else v = 5;
         }
     }
-    const bool is_g1 = (v >= 131 && v <= 150);
+    const bool is_g1 = (v >= 131 && v <= 153);
     if (aa.splits > 1 && !(is_g1 && aa.part)) {
         set_error("conv_igemm: split-K is implemented by the gemm1x1 variants (131-149) and needs a partial buffer");
         return ISB_ERR_INVALID;
@@ -2558,41 +2571,41 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
 #undef ISB_WS
             break;
         }
-        case 183: case 184: {                                // weights-stationary, epilogue pipelined into the MFMA stream: one (183) or two (184) waves per SIMD
-            const int tmb = v == 183 ? 4 : 2, bm = 32 * tmb;
+        case 183: case 184: case 185: case 186: {            // weights-stationary, epilogue pipelined into the MFMA stream:
+            // 183: 128-row tiles, one wave per SIMD; 184: 64-row tiles, two workgroups per CU (K <= 224); 185: 64-row tiles, one
+            // workgroup of 4 waves per CU, K = 384 (96 weight registers per lane); 186: the same tiles, 8 waves (2 x 32 rows)
+            const int bm = v == 183 ? 128 : 64;
             const int nsl = cdiv(a.Cout, 128), n_mt = cdiv(a.M, bm);
+            const bool k_ok = v >= 185 ? a.Cin == 384 : (a.Cin == 96 || a.Cin == 192 || a.Cin == 224);
             if (a.gate || a.res || a.out_f32 || a.act > 1 || a.KH != 1 || a.stride != 1 || a.pad != 0 || a.splits > 1 || a.Cout % 32 != 0 ||
-                nsl > 128 || (a.Cin != 96 && a.Cin != 192 && a.Cin != 224) || (size_t)a.M * a.Cin * 2 >= 0xffffffffull) {
-                set_error("conv_igemm: variants 183 / 184 are un-gated 1x1 GEMMs without residual, Cin 96/192/224");
+                nsl > 128 || !k_ok || (size_t)a.M * a.Cin * 2 >= 0xffffffffull) {
+                set_error("conv_igemm: variants 183 / 184 (Cin 96/192/224) and 185 / 186 (Cin 384) are un-gated 1x1 GEMMs without residual");
                 return ISB_ERR_INVALID;
             }
-            const int n_wg = v == 183 ? 256 : 512;
+            const int n_wg = v == 184 ? 512 : 256;
             aa.grid_n = nsl;
             aa.grid_m = std::max(1, std::min(n_wg / nsl, n_mt));
             const dim3 g(n_wg);
-#define ISB_WSP_GO(NK, ACT, STAMPS, TMB)                                                                        \
+#define ISB_WSP_GO(NK, ACT, STAMPS, TMB, WPC, NWM)                                                              \
     do {                                                                                                        \
-        const int bytes = 2 * NK * (32 * TMB) * 64 + 8 * WS_STAGE;                                              \
+        const int bytes = std::max(2 * NK * (32 * TMB * NWM) * 64 + 4 * NWM * 2 * WS_STAGE, WPC == 1 ? 84 * 1024 : 0); \
         static bool attr_set = false;                                                                           \
         if (!attr_set) {                                                                                        \
-            ISB_HIP(hipFuncSetAttribute((const void*)gemm1x1_wspipe_kernel<NK, ACT, STAMPS, TMB>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); \
+            ISB_HIP(hipFuncSetAttribute((const void*)gemm1x1_wspipe_kernel<NK, ACT, STAMPS, TMB, WPC, NWM>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); \
             attr_set = true;                                                                                    \
         }                                                                                                       \
-        hipLaunchKernelGGL((gemm1x1_wspipe_kernel<NK, ACT, STAMPS, TMB>), g, dim3(256), bytes, st, aa);         \
+        hipLaunchKernelGGL((gemm1x1_wspipe_kernel<NK, ACT, STAMPS, TMB, WPC, NWM>), g, dim3(256 * NWM), bytes, st, aa); \
     } while (0)
-#define ISB_WSP(NK)                                                                                             \
+#define ISB_WSP(NK, TMB, WPC, NWM)                                                                              \
     do {                                                                                                        \
-        if (v == 183) {                                                                                         \
-            if (a.probe & 2) ISB_WSP_GO(NK, true, true, 4);                                                     \
-            else if (a.act) ISB_WSP_GO(NK, true, false, 4);                                                     \
-            else ISB_WSP_GO(NK, false, false, 4);                                                               \
-        } else {                                                                                                \
-            if (a.probe & 2) ISB_WSP_GO(NK, true, true, 2);                                                     \
-            else if (a.act) ISB_WSP_GO(NK, true, false, 2);                                                     \
-            else ISB_WSP_GO(NK, false, false, 2);                                                               \
-        }                                                                                                       \
+        if (a.probe & 2) ISB_WSP_GO(NK, true, true, TMB, WPC, NWM);                                             \
+        else if (a.act) ISB_WSP_GO(NK, true, false, TMB, WPC, NWM);                                             \
+        else ISB_WSP_GO(NK, false, false, TMB, WPC, NWM);                                                       \
     } while (0)
-            if (a.Cin == 96) ISB_WSP(3); else if (a.Cin == 192) ISB_WSP(6); else ISB_WSP(7);
+            if (v == 186) ISB_WSP(12, 1, 1, 2);
+            else if (v == 185) ISB_WSP(12, 2, 1, 1);
+            else if (v == 183) { if (a.Cin == 96) ISB_WSP(3, 4, 1, 1); else if (a.Cin == 192) ISB_WSP(6, 4, 1, 1); else ISB_WSP(7, 4, 1, 1); }
+            else { if (a.Cin == 96) ISB_WSP(3, 2, 2, 1); else if (a.Cin == 192) ISB_WSP(6, 2, 2, 1); else ISB_WSP(7, 2, 2, 1); }
 #undef ISB_WSP
 #undef ISB_WSP_GO
             break;
@@ -2714,6 +2727,8 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
         case 146: ISB_CONV_LAUNCH_G1G(1, 3, 2, 2); break;   //  64 x 192
         case 147: ISB_CONV_LAUNCH_G1G(1, 2, 2, 2); break;   //  64 x 128
         case 148: ISB_CONV_LAUNCH_G1G(2, 7, 4, 1); break;   // 256 x 224
+        case 152: ISB_CONV_LAUNCH_G1G(1, 7, 8, 1); break;   // 256 x 224, eight waves
+        case 153: ISB_CONV_LAUNCH_G1G(1, 6, 8, 1); break;   // 256 x 192, eight waves
 #undef ISB_CONV_LAUNCH_G1G
         default:
             set_error("conv_igemm: unknown tile variant %d", v);

@@ -819,7 +819,7 @@ extern "C" int isb_debug_conv(int32_t device, const uint16_t* x, const float* w,
     (void)hipEventDestroy(e1);
     *ms_per_iter = ms / iters;
     ISB_HIP(hipMemcpy(out, dout.p, nout * 2, hipMemcpyDeviceToHost));
-    if (variant >= 900000 && variant != 900181 && variant != 900182 && variant != 900183 && variant != 900184) {   // the tile GEMMs: per workgroup {prologue, DMA wait, barrier wait, k loop, epilogue, k-steps}
+    if (variant >= 900000 && variant != 900181 && variant != 900182 && variant != 900183 && variant != 900184 && variant != 900185 && variant != 900186) {   // the tile GEMMs: per workgroup {prologue, DMA wait, barrier wait, k loop, epilogue, k-steps}
         std::vector<uint64_t> st(64 * 8);
         ISB_HIP(hipMemcpy(st.data(), dpart.p, 64 * 64, hipMemcpyDeviceToHost));
         double sum[5] = {0, 0, 0, 0, 0};
@@ -838,7 +838,7 @@ extern "C" int isb_debug_conv(int32_t device, const uint16_t* x, const float* w,
             fprintf(stderr, "mean of %d workgroups (cycles, wave 0): prologue %.0f | k loop %.0f of which DMA wait %.0f, barrier wait %.0f | epilogue %.0f\n",
                     n, sum[0] / n, sum[3] / n, sum[1] / n, sum[2] / n, sum[4] / n);
     }
-    if (variant == 900183 || variant == 900184) {                        // wave 0: cycles per phase of tiles 1..4
+    if (variant >= 900183 && variant <= 900186) {                        // wave 0: cycles per phase of tiles 1..4
         std::vector<uint64_t> st(64 * 128);
         ISB_HIP(hipMemcpy(st.data(), dpart.p, 64 * 1024, hipMemcpyDeviceToHost));
         {   // every workgroup's entry / exit on the constant 100 MHz counter

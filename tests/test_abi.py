@@ -149,7 +149,8 @@ def test_wspipe_staging_registers_are_private(built_lib, tmp_path):
         return out
 
     for name, lines in kernels.items():
-        two_waves = name.endswith("Li2EEEvNS_8ConvArgsE")
+        nk, tmb, wpc, nwm = (int(x) for x in re.search(r"ILi(\d+)ELb[01]ELb[01]ELi(\d+)ELi(\d+)ELi(\d+)EEE", name).groups())
+        two_waves = wpc * nwm == 2                  # waves per SIMD
         letter, lo = ("v", 228) if two_waves else ("a", 200)
         n_req = n_wr = 0
         for line in lines:
