@@ -792,7 +792,9 @@ __device__ __forceinline__ void dma16_s(const void* sbase, uint32_t voff, uint32
 // STAMPS (tuning probe, isb_debug_conv variant 9000 + v): wave 0 of the first 64 workgroups sums s_memtime intervals over
 // its k loop -- waiting for the DMA (vmcnt), waiting at the barrier, the rest (fragment reads + MFMAs) -- and writes
 // {prologue, DMA wait, barrier wait, whole k loop, epilogue, k-steps} to p.part[workgroup]
-template <int TM, int TN, int WGM, int WGN, int GATE = 0, bool STAMPS = false>
+// NBUF = 3: three k-step buffers, requests run TWO steps ahead and the wait before a step is a counted vmcnt (the pieces of
+// the step after it may still fly) instead of vmcnt(0).
+template <int TM, int TN, int WGM, int WGN, int GATE = 0, bool STAMPS = false, int NBUF = 2>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_dma_kernel(ConvArgs p) {
     uint64_t st_t0 = 0, st_wait = 0, st_bar = 0, st_loop0 = 0, st_loop1 = 0;
     if constexpr (STAMPS) st_t0 = __builtin_amdgcn_s_memtime();
@@ -803,8 +805,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_dma_kernel(ConvArgs p)
     constexpr int A_PW = (A_INST + NW - 1) / NW, B_PW = (B_INST + NW - 1) / NW;
     constexpr int BUF = (BM + BN) * ROWB;
     constexpr int CROW = BN * 2 + 16;
-    constexpr int LDS_BYTES = (2 * BUF > BM * CROW || BM * CROW > 65536) ? 2 * BUF : BM * CROW;
-    constexpr int GATE_OFF = 2 * BUF;                       // GATE: f32 gate rows of the tile's samples (dynamic LDS)
+    constexpr int LDS_BYTES = (NBUF * BUF > BM * CROW || BM * CROW > 65536) ? NBUF * BUF : BM * CROW;
+    constexpr int GATE_OFF = NBUF * BUF;                       // GATE: f32 gate rows of the tile's samples (dynamic LDS)
     // the tile's bias row is requested with the first k-step and sits behind everything else in LDS (the epilogue's
     // staging area overlays the k-loop buffers): no global-load latency between the last MFMA and the first store
     __shared__ __attribute__((aligned(16))) unsigned char lds_static[GATE ? 16 : LDS_BYTES + BN * 4];
@@ -995,6 +997,62 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_dma_kernel(ConvArgs p)
         }
     };
 
+    if constexpr (NBUF == 3) {
+        // pieces this wave requests per k-step (wave-uniform): the counted wait needs it as an immediate
+        int n_req = 0;
+#pragma unroll
+        for (int s = 0; s < A_PW; ++s) n_req += (wave + NW * s < A_INST) ? 1 : 0;
+#pragma unroll
+        for (int s = 0; s < B_PW; ++s) n_req += (wave + NW * s < B_INST) ? 1 : 0;
+        static_assert(A_PW + B_PW <= 8, "counted waits for up to 8 pieces per wave and k-step");
+        auto wait_landed = [&](bool next_in_flight) {       // the step about to be read has landed; only the step after it may fly
+            if (!next_in_flight) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            else switch (n_req) {
+                case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+                case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+                case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+                case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            }
+            __builtin_amdgcn_s_barrier();
+        };
+        // the gate rows / bias were staged with ordinary stores and the bias DMA above: make them visible once
+        if (nkt > 1) dma(std::integral_constant<int, 1>{});
+        if (nkt > 1) {                                      // step 0 landed, step 1 may fly
+            switch (n_req) {
+                case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+                case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+                case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+                case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            }
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if constexpr (STAMPS) { st_loop0 = __builtin_amdgcn_s_memtime(); st_wait = 0; st_bar = 0; }
+        for (int kt = 0; kt < nkt; kt += 3) {               // step kt in buffer 0, kt + 1 in buffer 1, kt + 2 in buffer 2 (nkt % 3 == 0: launcher)
+            dma(std::integral_constant<int, 2>{});
+            compute(std::integral_constant<int, 0>{});
+            wait_landed(true);
+            const bool more = kt + 3 < nkt;
+            if (more) dma(std::integral_constant<int, 0>{});
+            compute(std::integral_constant<int, 1>{});
+            wait_landed(more);
+            if (more) dma(std::integral_constant<int, 1>{});
+            compute(std::integral_constant<int, 2>{});
+            wait_landed(more);
+        }
+        __syncthreads();
+    } else {
     publish();
     if constexpr (STAMPS) { st_loop0 = __builtin_amdgcn_s_memtime(); st_wait = 0; st_bar = 0; }
     int kt = 0;
@@ -1009,6 +1067,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_dma_kernel(ConvArgs p)
     if (kt < nkt) {                             // odd tail: requested into buffer 0 and published above
         compute(std::integral_constant<int, 0>{});
         __syncthreads();
+    }
     }
     if constexpr (STAMPS) st_loop1 = __builtin_amdgcn_s_memtime();
     if (ISB_EPI_SHARED || p.splits > 1 || p.out_f32) conv_epilogue<TM, TN, WGM, WGN, true>(p, acc, lds, m0, n0, wm, wn, r, h, tid, bias_off);
@@ -2357,7 +2416,7 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
             else v = 5;
         }
     }
-    const bool is_g1 = (v >= 131 && v <= 153);
+    const bool is_g1 = (v >= 131 && v <= 153) || (v >= 191 && v <= 197);
     if (aa.splits > 1 && !(is_g1 && aa.part)) {
         set_error("conv_igemm: split-K is implemented by the gemm1x1 variants (131-149) and needs a partial buffer");
         return ISB_ERR_INVALID;
@@ -2669,20 +2728,22 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
         case 165: ISB_CONV_LAUNCH_C3(1, 2, 8, 1); break;   // 256 x  64
         case 166: ISB_CONV_LAUNCH_C3(2, 3, 4, 2); break;   // 256 x 192
 #undef ISB_CONV_LAUNCH_C3
-#define ISB_CONV_LAUNCH_G1G(TM, TN, WGM, WGN)                                                                    \
+#define ISB_CONV_LAUNCH_G1G(TM, TN, WGM, WGN) ISB_CONV_LAUNCH_G1GN(TM, TN, WGM, WGN, 2)
+#define ISB_CONV_LAUNCH_G1GN(TM, TN, WGM, WGN, NBUF_)                                                                   \
     do {                                                                                                         \
         constexpr int BM_ = 32 * TM * WGM, BN_ = 32 * TN * WGN;                                                  \
         const int ohw = a.OH * a.OW;                                                                             \
-        if (!a.gate || a.KH != 1 || a.stride != 1 || a.pad != 0 || (ohw % BM_ != 0 && BM_ % ohw != 0)) {        \
-            set_error("conv_igemm: variants 141-149 are gated 1x1 GEMMs on sample-aligned tiles");               \
+        if (!a.gate || a.KH != 1 || a.stride != 1 || a.pad != 0 || (ohw % BM_ != 0 && BM_ % ohw != 0) ||        \
+            (NBUF_ == 3 && (a.Cin % 96 != 0 || a.splits > 1))) {                                                 \
+            set_error("conv_igemm: variants 141-149 / 191-197 are gated 1x1 GEMMs on sample-aligned tiles (19x: Cin %% 96 == 0)"); \
             return ISB_ERR_INVALID;                                                                              \
         }                                                                                                        \
         const int ns = BM_ > ohw ? BM_ / ohw : 1;                                                                \
-        const int ring = 2 * (BM_ + BN_) * ROWB + ns * a.Cin * 4;                                                \
+        const int ring = NBUF_ * (BM_ + BN_) * ROWB + ns * a.Cin * 4;                                                \
         const int stage = BM_ * (BN_ * 2 + 16);                                                                  \
         aa.grid_bias_off = ring > stage ? ring : stage;                                                          \
         const int bytes = aa.grid_bias_off + BN_ * 4;                                                            \
-        auto kern = gemm1x1_dma_kernel<TM, TN, WGM, WGN, true>;                                                  \
+        auto kern = gemm1x1_dma_kernel<TM, TN, WGM, WGN, true, false, NBUF_>;                                                  \
         static int attr_bytes = 0;                                                                               \
         if (bytes > attr_bytes) {                                                                                \
             ISB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));  \
@@ -2690,7 +2751,7 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
         }                                                                                                        \
         const dim3 g = conv_grid(aa, BM_, BN_);                                                                  \
         if (a.probe & 2) {                                                                                       \
-            auto kern2 = gemm1x1_dma_kernel<TM, TN, WGM, WGN, true, true>;                                       \
+            auto kern2 = gemm1x1_dma_kernel<TM, TN, WGM, WGN, true, true, NBUF_>;                                       \
             ISB_HIP(hipFuncSetAttribute((const void*)kern2, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); \
             hipLaunchKernelGGL(kern2, g, dim3(64 * WGM * WGN), bytes, st, aa);                                   \
         } else                                                                                                   \
@@ -2728,6 +2789,11 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
         case 147: ISB_CONV_LAUNCH_G1G(1, 2, 2, 2); break;   //  64 x 128
         case 148: ISB_CONV_LAUNCH_G1G(2, 7, 4, 1); break;   // 256 x 224
         case 152: ISB_CONV_LAUNCH_G1G(1, 7, 8, 1); break;   // 256 x 224, eight waves
+        case 191: ISB_CONV_LAUNCH_G1GN(1, 3, 4, 2, 3); break;   // three k-step buffers: 128 x 192
+        case 193: ISB_CONV_LAUNCH_G1GN(1, 7, 4, 1, 3); break;   // 128 x 224
+        case 194: ISB_CONV_LAUNCH_G1GN(1, 5, 4, 2, 3); break;   // 128 x 320
+        case 196: ISB_CONV_LAUNCH_G1GN(1, 3, 2, 2, 3); break;   //  64 x 192
+        case 197: ISB_CONV_LAUNCH_G1GN(1, 2, 2, 2, 3); break;   //  64 x 128
         case 153: ISB_CONV_LAUNCH_G1G(1, 6, 8, 1); break;   // 256 x 192, eight waves
 #undef ISB_CONV_LAUNCH_G1G
         default:

@@ -46,10 +46,13 @@ CASES = [
     (4, 32, 160, 224, 1, 1, 1, False, False),     # 5 k-steps (odd), 224 = 7 x 32 output channels
     (3, 16, 96, 160, 3, 1, 1, False, False),      # 3x3, 3 k-steps per tap, ragged M (768 rows), Cout tile overhang
     (2, 32, 64, 64, 3, 2, 0, True, False),        # 3x3 stride 2 (TF SAME), residual, no activation
+    (2, 16, 192, 224, 1, 1, 0, True, True),       # gated projections with Cin % 96 == 0 (the three-buffer kernels): 6 k-steps
+    (3, 8, 288, 384, 1, 1, 0, True, True),        # 9 k-steps, ragged M
 ]
 G1 = [131, 132, 133, 134, 135, 136, 137, 138, 139]   # lean 1x1 GEMM kernels
 C3 = [161, 162, 163, 164, 165, 166]                  # lean 3x3 kernels (buffer-addressed A operand)
-GATED_DMA = [81, 82, 83, 84, 85, 86, 91, 92, 93, 94, 95, 96, 111, 112, 113, 114, 115, 116, 141, 142, 143, 144, 145, 146, 147, 148]
+GATED_DMA = [81, 82, 83, 84, 85, 86, 91, 92, 93, 94, 95, 96, 111, 112, 113, 114, 115, 116, 141, 142, 143, 144, 145, 146, 147, 148,
+             191, 193, 194, 196, 197]      # 19x: three k-step buffers, counted waits
 K64 = [101, 102, 103, 104, 105, 106, 107, 108, 111, 112, 113, 114, 115, 116]
 
 
@@ -69,6 +72,8 @@ def test_conv_variants(case, variant):
         pytest.skip("64-wide k-tiles need Cin % 64 == 0")
     if variant in GATED_DMA and not use_gate:
         pytest.skip("the gated LDS-DMA kernels need an SE gate")
+    if 191 <= variant <= 197 and Cin % 96 != 0:
+        pytest.skip("the three-buffer kernels take whole groups of three k-steps")
     rng = np.random.default_rng(hash((case, 7)) % (2 ** 31))
     x = rng.normal(0, 1, (B, H, H, Cin)).astype(np.float32)
     w = (rng.normal(0, 1, (Cout, k, k, Cin)) / np.sqrt(k * k * Cin)).astype(np.float32)
