@@ -266,6 +266,11 @@ int isb_debug_dwconv(int32_t device, const uint16_t* h_x, const float* h_w, cons
 int isb_pose_windows(const float* d_joints, int32_t n_cam, int32_t n_frames, int32_t J, int32_t L,
                      float* d_windows, void* stream);
 
+/* The frame's "distance" element (main.py:102): d_distance[i] = ||d_joints[i, 0, :]|| * 2.5 (camera-frame root joint,
+ * evaluated in float64 like the reference's numpy expression on the float64 pose).
+ *   d_joints [n, J, 3] f32 (absolute joints as isb_hpe_forward writes them)    d_distance [n] f32 */
+int isb_pose_distance(const float* d_joints, int32_t n, int32_t J, float* d_distance, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -763,6 +763,15 @@ extern "C" int isb_pose_windows(const float* d_joints, int32_t n_cam, int32_t n_
     });
 }
 
+extern "C" int isb_pose_distance(const float* d_joints, int32_t n, int32_t J, float* d_distance, void* stream) {
+    return isb::guard([&]() -> int {
+    ISB_REQUIRE(d_joints && d_distance, ISB_ERR_INVALID, "null argument");
+    ISB_REQUIRE(n >= 1 && J >= 1, ISB_ERR_INVALID, "bad shape n=%d J=%d", n, J);
+    ISB_TRY(set_device_of(d_joints));
+    return launch_pose_distance(d_joints, n, J, d_distance, (hipStream_t)stream);
+    });
+}
+
 // test / tuning hook: one conv_igemm layer on host tensors, timed with HIP events
 extern "C" int isb_debug_conv(int32_t device, const uint16_t* x, const float* w, const float* scale, const float* shift,
                               const uint16_t* res, const float* gate, int32_t B, int32_t H, int32_t W, int32_t Cin,

@@ -394,6 +394,22 @@ __global__ __launch_bounds__(256) void pose_windows_kernel(const float* joints, 
     windows[idx] = pose[e] - pose[e % 3];
 }
 
+// pose_distance: the frame's "distance" element (main.py:102): ||pose[0]|| * 2.5 on the camera-frame root joint. The reference
+// evaluates it in float64 on the float64 pose the estimator returns (hpe.py:171: the float32 joints widened): same here.
+__global__ __launch_bounds__(256) void pose_distance_kernel(const float* joints, int n, int J, float* distance) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float* r = joints + (size_t)i * J * 3;
+    const double x = (double)r[0], y = (double)r[1], z = (double)r[2];
+    distance[i] = (float)(sqrt(x * x + y * y + z * z) * 2.5);
+}
+
+int launch_pose_distance(const float* joints, int n, int J, float* distance, hipStream_t st) {
+    hipLaunchKernelGGL(pose_distance_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, joints, n, J, distance);
+    ISB_LAUNCHED("pose_distance", st);
+    return ISB_OK;
+}
+
 int launch_pose_windows(const float* joints, int n_cam, int n_frames, int J, int L, float* windows, hipStream_t st) {
     const size_t total = (size_t)n_cam * (n_frames - L + 1) * L * J * 3;
     hipLaunchKernelGGL(pose_windows_kernel, dim3((unsigned)cdivz(total, 256)), dim3(256), 0, st, joints, n_cam, n_frames, J, L, windows);

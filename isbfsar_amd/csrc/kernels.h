@@ -245,6 +245,7 @@ int launch_hpe_post(const PostArgs& a, hipStream_t st);
 int launch_select_person(const float* boxes, const float* confs, int B, int n_anchor, int n_cls, float thresh, int width, int height,
                          int32_t* bbox, uint8_t* found, hipStream_t st);
 int launch_pose_windows(const float* joints, int n_cam, int n_frames, int J, int L, float* windows, hipStream_t st);
+int launch_pose_distance(const float* joints, int n, int J, float* distance, hipStream_t st);
 
 // ---------------------------------------------------------------- det_kernels.hip (YOLOv4 person detector)
 int launch_det_preprocess(const uint8_t* frames, int B, int FH, int FW, float* out, hipStream_t st);

@@ -271,6 +271,18 @@ def pose_windows(joints, seq_len: int):
     return out
 
 
+def pose_distance(joints):
+    """joints torch CUDA f32 [..., J, 3] (absolute) -> f32 [...]: the frame's ``distance`` element (main.py:102)."""
+    import torch
+    j = joints.contiguous().float()
+    J = j.shape[-2]
+    n = j.numel() // (J * 3)
+    out = torch.empty(j.shape[:-2], dtype=torch.float32, device=j.device)
+    stream = torch.cuda.current_stream(j.device).cuda_stream
+    _lib.check(_lib.lib().isb_pose_distance(j.data_ptr(), n, J, out.data_ptr(), C.c_void_p(stream)), "isb_pose_distance")
+    return out
+
+
 def load_joint_assets(expand_path: str, skeleton_types_path: str, skeleton: Optional[str]):
     expand = np.load(expand_path)
     with open(skeleton_types_path) as f:

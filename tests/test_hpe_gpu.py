@@ -507,6 +507,19 @@ def test_pose_windows_kernel():
             assert np.array_equal(w[cam * 5 + k], c[cam, k:k + 16].reshape(16, 90))
 
 
+def test_pose_distance_kernel():
+    """main.py:102: np.sqrt(np.sum(np.square(np.array([0, 0, 0]) - np.array(pose[0])))) * 2.5 on the float64 pose."""
+    import torch
+    from isbfsar_amd.hpe_engine import pose_distance
+    rng = np.random.default_rng(5)
+    j = (rng.normal(0, 1, (4, 7, 30, 3)) * np.array([0.4, 0.4, 1.0]) + np.array([0.0, 0.0, 2.5])).astype(np.float32)
+    d = pose_distance(torch.from_numpy(j).cuda()).cpu().numpy()
+    assert d.shape == (4, 7)
+    pose = j.astype(np.float64)
+    ref = np.sqrt(np.sum(np.square(np.array([0, 0, 0]) - pose[..., 0, :]), axis=-1)) * 2.5
+    assert np.array_equal(d, ref.astype(np.float32))
+
+
 def test_human_pose_estimator_dropin(bbone_state, assets):
     from isbfsar_amd.modules.hpe.hpe import HumanPoseEstimator
     from isbfsar_amd.params import MetrabsHIPConfig, RealSenseIntrinsics
