@@ -2374,7 +2374,7 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
                    (a.Cin == 96 || a.Cin == 192 || a.Cin == 224 || (a.Cin == 384 && wsreg_on() != 183 && wsreg_on() != 1840)) && a.Cout % 32 == 0 && a.M >= 64 * 128 &&
                    (size_t)a.M * a.Cin * 2 < 0xffffffffull) {
             v = wsreg_on();                                                      // weights-stationary persistent GEMM (short-K expand convolutions)
-            if (v >= 184) v = a.Cin == 384 ? 186 : 184;                          // (1840: K <= 224 only, A/B switch)                          // two waves per SIMD: 2 workgroups x 4 waves, or (K = 384) 1 x 8
+            if (v >= 184) v = a.Cin == 384 ? (a.M >= 16384 ? 186 : 185) : 184;   // (1840: K <= 224 only, A/B switch); K = 384: eight waves pay from 256 tiles on                          // two waves per SIMD: 2 workgroups x 4 waves, or (K = 384) 1 x 8
         } else if (g1 && !a.gate) {
             if (a.Cout % 192 == 0) v = 131;            // 128 x 192
             else if (a.Cout == 64) v = 135;            // 256 x  64
