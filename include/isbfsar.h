@@ -249,6 +249,16 @@ int isb_debug_fused_mb(int32_t device, const uint16_t* h_x, const float* h_w1, c
                        int32_t H, int32_t Cin, int32_t Cexp, int32_t Cout2, int32_t stride, int32_t iters, uint16_t* h_out,
                        float* ms_per_iter);
 
+/* test / tuning hook: the exact-f32 Linear kernel (gemm_f32.hip) on host tensors:
+ *   C[m,n] = act( bias[n] + sum_k a_act( sum_{s < a_parts} A[s][m][k] + a_bias[k] ) (+ a_add[m % add_period][k]) * W[n][k] )
+ *   A f32 [a_parts,M,K], W f32 [N,K] (torch Linear layout), bias [N] / a_bias [K] / a_add [add_period,K] optional (NULL);
+ *   act / a_act: 0 none, 1 ReLU, 2 SiLU, 3 sigmoid; splits > 1 = split-K with the fixed-order reduction; a_offset (0..3):
+ *   A is placed that many floats past a 16-byte boundary on the device (the 8-byte and 4-byte staging paths) */
+int isb_debug_gemm_f32(int32_t device, const float* h_A, const float* h_W, const float* h_bias, const float* h_a_bias,
+                       const float* h_a_add, int32_t M, int32_t N, int32_t K, int32_t a_parts, int32_t a_act,
+                       int32_t add_period, int32_t act, int32_t splits, int32_t a_offset, int32_t iters, float* h_C,
+                       float* ms_per_iter);
+
 /* test / tuning hook: the depthwise 3x3 (+ folded BN + SiLU) + squeeze-excite mean kernel on host tensors.
  *   h_x bf16 [B,H,H,C], h_w f32 [C,3,3] (taps are rounded to bf16 after the BN scale is folded in, like every
  *   conv weight), stride 1 (pad 1) or 2 (TF SAME: pad bottom/right); out bf16 [B,H/stride,H/stride,C], pooled f32 [B,C] */

@@ -1017,6 +1017,61 @@ extern "C" int isb_debug_fused_mb(int32_t device, const uint16_t* x, const float
 }
 
 // test / tuning hook: depthwise 3x3 + SiLU + SE mean on host tensors
+// test / tuning hook: one launch_gemm_f32 on host tensors (every A-operand option of GemmF32Args), timed with HIP events
+extern "C" int isb_debug_gemm_f32(int32_t device, const float* A, const float* W, const float* bias, const float* a_bias,
+                                  const float* a_add, int32_t M, int32_t N, int32_t K, int32_t a_parts, int32_t a_act,
+                                  int32_t add_period, int32_t act, int32_t splits, int32_t a_offset, int32_t iters, float* C,
+                                  float* ms_per_iter) {
+    return isb::guard([&]() -> int {
+        ISB_REQUIRE(A && W && C && ms_per_iter, ISB_ERR_INVALID, "null argument");
+        ISB_REQUIRE(M >= 1 && N >= 1 && K >= 1 && iters >= 1 && a_parts >= 1 && splits >= 1 && a_offset >= 0 && a_offset < 4 &&
+                        (!a_add || add_period >= 1),
+                    ISB_ERR_INVALID, "bad gemm parameters");
+        ISB_HIP(hipSetDevice(device));
+        const size_t na = (size_t)a_parts * M * K;
+        DevBuf dA, dW, dB, dAb, dAdd, dC, dParts;
+        // a_offset floats of slack in front of A: exercises the less aligned staging paths on an aligned tensor
+        ISB_TRY(dA.alloc((na + 4) * 4));
+        ISB_HIP(hipMemcpy(dA.as<float>() + a_offset, A, na * 4, hipMemcpyHostToDevice));
+        ISB_TRY(upload(dW, W, (size_t)N * K * 4));
+        if (bias) ISB_TRY(upload(dB, bias, (size_t)N * 4));
+        if (a_bias) ISB_TRY(upload(dAb, a_bias, (size_t)K * 4));
+        if (a_add) ISB_TRY(upload(dAdd, a_add, (size_t)add_period * K * 4));
+        ISB_TRY(dC.alloc((size_t)M * N * 4));
+        GemmF32Args g{};
+        g.A = dA.as<float>() + a_offset; g.W = dW.as<float>(); g.bias = bias ? dB.as<float>() : nullptr;
+        g.Aadd = a_add ? dAdd.as<float>() : nullptr; g.C = dC.as<float>();
+        g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = N; g.ldadd = K; g.add_period = a_add ? add_period : 1;
+        g.act = act; g.a_bias = a_bias ? dAb.as<float>() : nullptr; g.a_act = a_act; g.a_parts = a_parts;
+        g.a_part_stride = (size_t)M * K;
+        if (splits > 1) {
+            ISB_TRY(dParts.alloc((size_t)splits * M * N * 4));
+            g.splits = splits; g.split_stride = (size_t)M * N; g.C = dParts.as<float>();
+        }
+        auto run = [&]() -> int {
+            ISB_TRY(launch_gemm_f32(g, nullptr));
+            if (splits > 1) ISB_TRY(launch_reduce_parts(dParts.as<float>(), splits, (size_t)M * N, g.bias, act, dC.as<float>(), M, N, nullptr));
+            return ISB_OK;
+        };
+        ISB_TRY(run());
+        ISB_HIP(hipDeviceSynchronize());
+        hipEvent_t e0, e1;
+        ISB_HIP(hipEventCreate(&e0));
+        ISB_HIP(hipEventCreate(&e1));
+        ISB_HIP(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < iters; ++i) ISB_TRY(run());
+        ISB_HIP(hipEventRecord(e1, nullptr));
+        ISB_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        ISB_HIP(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        *ms_per_iter = ms / iters;
+        ISB_HIP(hipMemcpy(C, dC.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+        return ISB_OK;
+    });
+}
+
 extern "C" int isb_debug_dwconv(int32_t device, const uint16_t* x, const float* w, const float* scale, const float* shift,
                                 int32_t B, int32_t H, int32_t C, int32_t stride, int32_t iters, uint16_t* out, float* pooled,
                                 float* ms_per_iter) {

@@ -206,6 +206,24 @@ def fused_mb_debug(x_bf16, w1, scale1, shift1, w2, scale2, shift2, res_bf16=None
     return out, ms.value
 
 
+def gemm_f32_debug(A, W, bias=None, a_bias=None, a_add=None, act=0, a_act=0, splits=1, a_offset=0, iters=1, device=0):
+    """The exact-f32 Linear kernel through isb_debug_gemm_f32. A f32 [M,K] or [a_parts,M,K], W f32 [N,K].
+    Returns (C f32 [M,N], ms_per_launch)."""
+    f = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+    A, W, bias, a_bias, a_add = f(A), f(W), f(bias), f(a_bias), f(a_add)
+    if A.ndim == 2:
+        A = A[None]
+    a_parts, M, K = A.shape
+    N = W.shape[0]
+    out = np.empty((M, N), np.float32)
+    ms = C.c_float()
+    p = lambda a: None if a is None else _ptr(a)
+    _lib.check(_lib.lib().isb_debug_gemm_f32(device, _ptr(A), _ptr(W), p(bias), p(a_bias), p(a_add), M, N, K, a_parts, a_act,
+                                             1 if a_add is None else a_add.shape[0], act, splits, a_offset, iters, _ptr(out),
+                                             C.byref(ms)), "isb_debug_gemm_f32")
+    return out, ms.value
+
+
 def dwconv_debug(x_bf16, w, scale, shift, stride=1, iters=1, device=0):
     """Depthwise 3x3 + SiLU + SE mean through isb_debug_dwconv. x_bf16 uint16 [B,H,H,C], w f32 [C,3,3].
     Returns (out uint16 [B,H/stride,H/stride,C], pooled f32 [B,C], ms_per_launch)."""
