@@ -286,3 +286,52 @@ def test_wsreg_expand_gemm(B, H, Cin, Cout, act, variant):
     assert np.abs(got - ref).max() <= 2.0 ** -7 * max(1.0, np.abs(ref).max())
     out2, _ = conv_debug(f32_to_bf16(x), w, scale, shift, 1, 1, act, None, None, variant=variant, iters=3)
     assert np.array_equal(out2, out)
+
+
+def _gemm_ref(A, W, bias, a_bias, a_add, act, a_act):
+    """float64 restatement of gemm_f32.hip's contract."""
+    actf = {0: lambda v: v, 1: lambda v: np.maximum(v, 0), 2: lambda v: v / (1 + np.exp(-v)), 3: lambda v: 1 / (1 + np.exp(-v))}
+    a = A.astype(np.float64).sum(axis=0)
+    if a_bias is not None:
+        a = a + a_bias
+    a = actf[a_act](a)
+    if a_add is not None:
+        a = a + a_add[np.arange(a.shape[0]) % a_add.shape[0]]
+    c = a @ W.astype(np.float64).T
+    if bias is not None:
+        c = c + bias
+    return actf[act](c)
+
+
+@pytest.mark.parametrize("M,N,K,opts", [
+    (300, 288, 1280, {}),                                           # the pose head's shape: 128 x 96 tiles, 16-byte staging
+    (257, 732, 366, {"bias": True, "act": 1}),                      # MLP fc1: rows only 8-byte aligned, K tail of 14
+    (190, 256, 732, {"bias": True}),                                # MLP fc2
+    (95, 512, 256, {"a_add": 30}),                                  # tuple projections: positional table added on load
+    (64, 256, 13050, {"splits": 6, "bias": True, "act": 1}),        # discriminator fc1: split-K, odd-ish K
+    (33, 64, 256, {"a_parts": 3, "a_bias": True, "a_act": 1}),      # partial sums + bias + ReLU on load (N <= 64 tiles)
+    (700, 1, 64, {"bias": True, "act": 3}),                         # N = 1 (N <= 32 tiles)
+    (130, 130, 37, {"bias": True}),                                 # K not a multiple of 2: scalar staging, K tail of 5
+    (200, 160, 96, {"a_offset": 2}),                                # A shifted to an 8-byte boundary
+    (200, 160, 96, {"a_offset": 1, "act": 2}),                      # ... and to a 4-byte boundary
+])
+def test_gemm_f32(M, N, K, opts):
+    """The exact-f32 Linear kernel against float64 on every staging path (16 / 8 / 4-byte loads, K tails, A-operand
+    transforms, split-K) and tile shape. f32 products summed in f32: a few ulp of the accumulated magnitude."""
+    from isbfsar_amd.hpe_engine import gemm_f32_debug
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    parts = opts.get("a_parts", 1)
+    A = rng.normal(0, 1, (parts, M, K)).astype(np.float32)
+    W = (rng.normal(0, 1, (N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.normal(0, 0.5, N).astype(np.float32) if opts.get("bias") else None
+    a_bias = rng.normal(0, 0.5, K).astype(np.float32) if opts.get("a_bias") else None
+    a_add = rng.normal(0, 0.1, (opts["a_add"], K)).astype(np.float32) if opts.get("a_add") else None
+    act, a_act = opts.get("act", 0), opts.get("a_act", 0)
+    out, _ = gemm_f32_debug(A, W, bias, a_bias, a_add, act=act, a_act=a_act, splits=opts.get("splits", 1),
+                            a_offset=opts.get("a_offset", 0))
+    ref = _gemm_ref(A, W, bias, a_bias, a_add, act, a_act)
+    scale = np.sqrt(parts) * (1.0 + (0.5 if a_bias is not None else 0.0))
+    assert np.abs(out - ref).max() <= 2e-5 * max(1.0, scale) * np.sqrt(K / 256 + 1)
+    out2, _ = gemm_f32_debug(A, W, bias, a_bias, a_add, act=act, a_act=a_act, splits=opts.get("splits", 1),
+                             a_offset=opts.get("a_offset", 0), iters=2)
+    assert np.array_equal(out, out2)
