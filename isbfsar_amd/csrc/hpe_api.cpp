@@ -828,7 +828,7 @@ extern "C" int isb_debug_conv(int32_t device, const uint16_t* x, const float* w,
     (void)hipEventDestroy(e1);
     *ms_per_iter = ms / iters;
     ISB_HIP(hipMemcpy(out, dout.p, nout * 2, hipMemcpyDeviceToHost));
-    if (variant >= 900000 && variant != 900181 && variant != 900182 && variant != 900183 && variant != 900184 && variant != 900185 && variant != 900186) {   // the tile GEMMs: per workgroup {prologue, DMA wait, barrier wait, k loop, epilogue, k-steps}
+    if (variant >= 900000 && variant != 900181 && variant != 900182 && variant != 900183 && variant != 900184 && variant != 900185 && variant != 900186 && variant != 900187 && variant != 900188) {   // the tile GEMMs: per workgroup {prologue, DMA wait, barrier wait, k loop, epilogue, k-steps}
         std::vector<uint64_t> st(64 * 8);
         ISB_HIP(hipMemcpy(st.data(), dpart.p, 64 * 64, hipMemcpyDeviceToHost));
         double sum[5] = {0, 0, 0, 0, 0};
@@ -847,7 +847,7 @@ extern "C" int isb_debug_conv(int32_t device, const uint16_t* x, const float* w,
             fprintf(stderr, "mean of %d workgroups (cycles, wave 0): prologue %.0f | k loop %.0f of which DMA wait %.0f, barrier wait %.0f | epilogue %.0f\n",
                     n, sum[0] / n, sum[3] / n, sum[1] / n, sum[2] / n, sum[4] / n);
     }
-    if (variant >= 900183 && variant <= 900186) {                        // wave 0: cycles per phase of tiles 1..4
+    if (variant >= 900183 && variant <= 900188) {                        // wave 0: cycles per phase of tiles 1..4
         std::vector<uint64_t> st(64 * 128);
         ISB_HIP(hipMemcpy(st.data(), dpart.p, 64 * 1024, hipMemcpyDeviceToHost));
         {   // every workgroup's entry / exit on the constant 100 MHz counter
@@ -862,7 +862,7 @@ extern "C" int isb_debug_conv(int32_t device, const uint16_t* x, const float* w,
                 ++n;
             }
             if (n) {
-                const int nwg = (a.variant == 184) ? 512 : 256, nsl = cdiv(Cout, 128), Q = std::max(1, nwg / nsl);
+                const int nwg = (a.variant == 184 || a.variant == 187) ? 512 : 256, nsl = cdiv(Cout, 128), Q = std::max(1, nwg / nsl);
                 double xs[8] = {0}, ss[64] = {0}; int xn[8] = {0}, sn[64] = {0};
                 for (int g = 0; g < nwg; ++g) {
                     if (!rt[2 * g] || !rt[2 * g + 1]) continue;

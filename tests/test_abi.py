@@ -139,7 +139,7 @@ def test_wspipe_staging_registers_are_private(built_lib, tmp_path):
                 kernels[cur] = []
         elif cur and line.strip():
             kernels[cur].append(line.split("//")[0])
-    assert len(kernels) >= 12, sorted(kernels)        # NK 3/6/7 x act/no act/stamps x 1 or 2 waves per SIMD
+    assert len(kernels) >= 12, sorted(kernels)        # NK 3/6/7/12 x act/no act/stamps x 1 or 2 waves per SIMD x MFMA shape
 
     def regs(line, letter):
         out = set()
@@ -149,7 +149,7 @@ def test_wspipe_staging_registers_are_private(built_lib, tmp_path):
         return out
 
     for name, lines in kernels.items():
-        nk, tmb, wpc, nwm = (int(x) for x in re.search(r"ILi(\d+)ELb[01]ELb[01]ELi(\d+)ELi(\d+)ELi(\d+)EEE", name).groups())
+        nk, tmb, wpc, nwm = (int(x) for x in re.search(r"ILi(\d+)ELb[01]ELb[01]ELi(\d+)ELi(\d+)ELi(\d+)ELb[01]EEE", name).groups())
         two_waves = wpc * nwm == 2                  # waves per SIMD
         letter, lo = ("v", 228) if two_waves else ("a", 200)
         n_req = n_wr = 0

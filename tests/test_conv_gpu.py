@@ -265,14 +265,14 @@ def test_fused_mbconv_block(B, H, Cin, Cexp, Cout2, stride, use_res):
 @pytest.mark.parametrize("B,H,Cin,Cout,act", [(2, 16, 96, 384, 1), (3, 16, 192, 768, 1), (5, 8, 224, 1344, 1), (1, 8, 224, 192, 0),
                                               (40, 16, 224, 1344, 1), (33, 16, 192, 1152, 1), (7, 32, 96, 384, 1),
                                               (37, 8, 384, 2304, 1), (300, 8, 384, 2304, 1), (130, 16, 224, 1344, 1)])
-@pytest.mark.parametrize("variant", [181, 182, 183, 184, 185, 186])
+@pytest.mark.parametrize("variant", [181, 182, 183, 184, 185, 186, 187, 188])
 def test_wsreg_expand_gemm(B, H, Cin, Cout, act, variant):
     """Weights-stationary persistent GEMMs (variant 181: 96 x 192 tiles, six waves; 182: 128 x 128 tiles, one wave per SIMD;
     the short-K MBConv expand convolutions): against torch on the same bf16 operands, and BIT-identical to the tile kernel
     (variant 131 / 132) -- same k order, same epilogue code. Shapes: ragged last tile, a single partial tile, several tiles
     per workgroup, every K, and for 182 channel counts that are not a multiple of its 128-channel slice (1344, 1152, 192)."""
-    if (variant in (183, 184)) == (Cin == 384) and variant >= 183:
-        pytest.skip("variants 183 / 184 are built for K <= 224, variants 185 / 186 for K = 384")
+    if (variant in (183, 184, 187)) == (Cin == 384) and variant >= 183:
+        pytest.skip("variants 183 / 184 / 187 are built for K <= 224, variants 185 / 186 / 188 for K = 384")
     rng = np.random.default_rng(B * 1000 + Cin)
     x = rng.normal(0, 1, (B, H, H, Cin)).astype(np.float32)
     w = (rng.normal(0, 1, (Cout, 1, 1, Cin)) / np.sqrt(Cin)).astype(np.float32)
@@ -280,7 +280,11 @@ def test_wsreg_expand_gemm(B, H, Cin, Cout, act, variant):
     shift = rng.uniform(-0.1, 0.1, Cout).astype(np.float32)
     out, _ = conv_debug(f32_to_bf16(x), w, scale, shift, 1, 1, act, None, None, variant=variant)
     tile, _ = conv_debug(f32_to_bf16(x), w, scale, shift, 1, 1, act, None, None, variant=131 if Cout % 192 == 0 else 132)
-    assert np.array_equal(out, tile)
+    if variant in (187, 188):       # 16x16x32 MFMA: another f32 summation order -- the same bf16 value except where the sum sits on a rounding edge
+        d = np.abs(bf16_to_f32(out) - bf16_to_f32(tile))
+        assert np.mean(out != tile) < 2e-3 and d.max() <= 2.0 ** -7 * max(1.0, np.abs(bf16_to_f32(tile)).max())
+    else:
+        assert np.array_equal(out, tile)
     ref = _ref(x, w, scale, shift, 1, 1, act, None, None)
     got = bf16_to_f32(out)
     assert np.abs(got - ref).max() <= 2.0 ** -7 * max(1.0, np.abs(ref).max())
