@@ -339,3 +339,19 @@ def test_gemm_f32(M, N, K, opts):
     out2, _ = gemm_f32_debug(A, W, bias, a_bias, a_add, act=act, a_act=a_act, splits=opts.get("splits", 1),
                              a_offset=opts.get("a_offset", 0), iters=2)
     assert np.array_equal(out, out2)
+
+
+@pytest.mark.parametrize("H,Cin,Cout,variant", [(16, 224, 1344, 184), (8, 384, 2304, 186), (32, 96, 384, 184)])
+def test_pipelined_expand_at_full_size(H, Cin, Cout, variant):
+    """BASELINE size (256 frames per launch: 512 workgroups x 11 - 24 tiles): the pipelined weights-stationary kernels are
+    bit-identical to the tile kernel they replace, launch after launch."""
+    rng = np.random.default_rng(H + Cin)
+    x = f32_to_bf16(rng.normal(0, 1, (256, H, H, Cin)).astype(np.float32))
+    w = (rng.normal(0, 1, (Cout, 1, 1, Cin)) / np.sqrt(Cin)).astype(np.float32)
+    scale = rng.uniform(0.8, 1.2, Cout).astype(np.float32)
+    shift = rng.uniform(-0.1, 0.1, Cout).astype(np.float32)
+    out, _ = conv_debug(x, w, scale, shift, 1, 1, 1, None, None, variant=variant, iters=3)
+    tile, _ = conv_debug(x, w, scale, shift, 1, 1, 1, None, None, variant=131)
+    assert np.array_equal(out, tile)
+    auto, _ = conv_debug(x, w, scale, shift, 1, 1, 1, None, None, variant=0)     # what the network launches for this layer
+    assert np.array_equal(auto, tile)
