@@ -2400,7 +2400,7 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
                    (a.Cin == 96 || a.Cin == 192 || a.Cin == 224 || (a.Cin == 384 && wsreg_on() != 183 && wsreg_on() != 1840)) && a.Cout % 32 == 0 && a.M >= 64 * 128 &&
                    (size_t)a.M * a.Cin * 2 < 0xffffffffull) {
             v = wsreg_on();                                                      // weights-stationary persistent GEMM (short-K expand convolutions)
-            if (v >= 184) v = a.Cin == 384 ? (a.M >= 16384 ? 186 : 185) : 184;   // (1840: K <= 224 only, A/B switch); K = 384: eight waves pay from 256 tiles on                          // two waves per SIMD: 2 workgroups x 4 waves, or (K = 384) 1 x 8
+            if (v >= 184) v = a.Cin == 384 ? ((a.M >= 16384 || !a.act) ? 186 : 185) : 184;   // (1840: K <= 224 only, A/B switch); K = 384: eight waves pay from 256 tiles on                          // two waves per SIMD: 2 workgroups x 4 waves, or (K = 384) 1 x 8
         } else if (g1 && !a.gate) {
             if (a.Cout % 192 == 0) v = 131;            // 128 x 192
             else if (a.Cout == 64) v = 135;            // 256 x  64
@@ -2689,18 +2689,23 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
         else if (a.act) ISB_WSP_GO(NK, true, false, TMB, WPC, NWM);                                             \
         else ISB_WSP_GO(NK, false, false, TMB, WPC, NWM);                                                       \
     } while (0)
-#define ISB_WSP16(NK, TMB, WPC, NWM)                                                                            \
+            // the forms the network does not select (183, 185 without activation, 187 / 188) exist with the SiLU epilogue only:
+            // every instantiation is a fully unrolled tile pass
+#define ISB_WSP_ACT(NK, TMB, WPC, NWM, M16_)                                                                    \
     do {                                                                                                        \
-        if (a.probe & 2) ISB_WSP_GO2(NK, true, true, TMB, WPC, NWM, true);                                      \
-        else if (a.act) ISB_WSP_GO2(NK, true, false, TMB, WPC, NWM, true);                                      \
-        else ISB_WSP_GO2(NK, false, false, TMB, WPC, NWM, true);                                                \
+        if (!a.act || (a.probe & 2)) {                                                                          \
+            set_error("conv_igemm: variant %d is built with the SiLU epilogue and without stamps only", v);     \
+            return ISB_ERR_INVALID;                                                                             \
+        }                                                                                                       \
+        ISB_WSP_GO2(NK, true, false, TMB, WPC, NWM, M16_);                                                      \
     } while (0)
-            if (v == 188) ISB_WSP16(12, 1, 1, 2);
-            else if (v == 187) { if (a.Cin == 96) ISB_WSP16(3, 2, 2, 1); else if (a.Cin == 192) ISB_WSP16(6, 2, 2, 1); else ISB_WSP16(7, 2, 2, 1); }
+            if (v == 188) ISB_WSP_ACT(12, 1, 1, 2, true);
+            else if (v == 187) { if (a.Cin == 96) ISB_WSP_ACT(3, 2, 2, 1, true); else if (a.Cin == 192) ISB_WSP_ACT(6, 2, 2, 1, true); else ISB_WSP_ACT(7, 2, 2, 1, true); }
             else if (v == 186) ISB_WSP(12, 1, 1, 2);
-            else if (v == 185) ISB_WSP(12, 2, 1, 1);
-            else if (v == 183) { if (a.Cin == 96) ISB_WSP(3, 4, 1, 1); else if (a.Cin == 192) ISB_WSP(6, 4, 1, 1); else ISB_WSP(7, 4, 1, 1); }
+            else if (v == 185) ISB_WSP_ACT(12, 2, 1, 1, false);
+            else if (v == 183) { if (a.Cin == 96) ISB_WSP_ACT(3, 4, 1, 1, false); else if (a.Cin == 192) ISB_WSP_ACT(6, 4, 1, 1, false); else ISB_WSP_ACT(7, 4, 1, 1, false); }
             else { if (a.Cin == 96) ISB_WSP(3, 2, 2, 1); else if (a.Cin == 192) ISB_WSP(6, 2, 2, 1); else ISB_WSP(7, 2, 2, 1); }
+#undef ISB_WSP_ACT
 #undef ISB_WSP16
 #undef ISB_WSP
 #undef ISB_WSP_GO2

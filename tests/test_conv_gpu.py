@@ -273,6 +273,8 @@ def test_wsreg_expand_gemm(B, H, Cin, Cout, act, variant):
     per workgroup, every K, and for 182 channel counts that are not a multiple of its 128-channel slice (1344, 1152, 192)."""
     if (variant in (183, 184, 187)) == (Cin == 384) and variant >= 183:
         pytest.skip("variants 183 / 184 / 187 are built for K <= 224, variants 185 / 186 / 188 for K = 384")
+    if variant in (183, 185, 187, 188) and not act:
+        pytest.skip("the forms the network does not select are built with the SiLU epilogue only")
     rng = np.random.default_rng(B * 1000 + Cin)
     x = rng.normal(0, 1, (B, H, H, Cin)).astype(np.float32)
     w = (rng.normal(0, 1, (Cout, 1, 1, Cin)) / np.sqrt(Cin)).astype(np.float32)
