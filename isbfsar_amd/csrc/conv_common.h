@@ -1,0 +1,72 @@
+// Device helpers shared by the convolution translation units (conv_kernels.hip, conv_ws.hip): operand typedefs, the LDS row
+// layout and its swizzle, activations, the LDS-DMA issue helper, the dynamic LDS symbol.
+#pragma once
+#include <algorithm>
+#include <type_traits>
+#include <utility>
+
+#include "isb_common.h"
+#include "kernels.h"
+
+namespace isb {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float bf2f_(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+__device__ __forceinline__ uint16_t f2bf_(float x) { return __builtin_bit_cast(uint16_t, (__bf16)x); }
+__device__ __forceinline__ float silu_(float x) { return x / (1.0f + __expf(-x)); }
+
+// SE gate on eight bf16 values: bf16(f32(x) * g), two elements per instruction (shift / mask unpack, v_pk_mul_f32,
+// v_cvt_pk_bf16_f32) -- 4 VALU instructions per dword
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t gate_bf16x2(uint32_t w, float g_lo, float g_hi) {
+    f32x2_t x = {__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
+    const f32x2_t g = {g_lo, g_hi};
+    x = x * g;
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bf16x2_t));
+}
+__device__ __forceinline__ uint4 gate_bf16x8(uint4 v, float4 g0, float4 g1) {
+    return make_uint4(gate_bf16x2(v.x, g0.x, g0.y), gate_bf16x2(v.y, g0.z, g0.w), gate_bf16x2(v.z, g1.x, g1.y),
+                      gate_bf16x2(v.w, g1.z, g1.w));
+}
+
+constexpr int CK = 32;            // k-tile (bf16 elements) = 64 B per row
+constexpr int ROWB = 64;          // bytes per LDS row
+
+__device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+__device__ __forceinline__ float silu_fast(float x) {
+    // x * sigmoid(x) with v_exp_f32 / v_rcp_f32 (about 1 ulp each; the result is rounded to bf16)
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+
+// activation codes (ConvArgs.act): 0 none, 1 SiLU (the pose backbone), 2 Mish, 3 LeakyReLU(0.1) (the YOLOv4 detector)
+__device__ __forceinline__ float mish_fast(float x) {
+    // x * tanh(softplus(x)) with n = e^x: tanh(ln(1 + n)) = n (n + 2) / (n (n + 2) + 2); one v_exp + one v_rcp.
+    // n is clamped so that n (n + 2) stays finite (for x > 20 the factor is 1 to f32 precision anyway)
+    const float n = __builtin_amdgcn_exp2f(1.4426950408889634f * fminf(x, 20.0f));
+    const float w = n * (n + 2.0f);
+    return x * w * __builtin_amdgcn_rcpf(w + 2.0f);
+}
+__device__ __forceinline__ float act_other(int act, float x) {     // act >= 2 (wave-uniform)
+    return act == 2 ? mish_fast(x) : (x > 0.f ? x : 0.1f * x);
+}
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+extern __shared__ __attribute__((aligned(16))) unsigned char conv_lds_dyn[];
+
+// LDS-DMA: 16 bytes per lane from (wave-uniform base + 32-bit lane offset) to LDS address lds_addr + lane * 16
+__device__ __forceinline__ void dma16_s(const void* sbase, uint32_t voff, uint32_t lds_addr) {
+    const uint32_t la = __builtin_amdgcn_readfirstlane(lds_addr);
+    const uint64_t b = (uint64_t)(uintptr_t)sbase;          // wave-uniform by construction; make the compiler see it
+    const uint32_t b_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
+    const uint32_t b_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);   // the builtin returns int: widen unsigned
+    const uint64_t sb = ((uint64_t)b_hi << 32) | (uint64_t)b_lo;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sb), "s"(la) : "memory");
+}
+
+}  // namespace isb

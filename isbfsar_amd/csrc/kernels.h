@@ -161,6 +161,8 @@ struct ConvArgs {
     int Cout2;
 };
 int launch_conv_igemm(const ConvArgs& a, hipStream_t st);
+// conv_ws.hip: the weights-stationary expand GEMMs (tile variants 181 - 188); aa = a with the grid fields the launcher fills
+int launch_conv_ws(const ConvArgs& a, ConvArgs& aa, int v, hipStream_t st);
 int launch_conv_expand_dw(const ConvArgs& a, hipStream_t st);
 int launch_fused_mb(const ConvArgs& a, hipStream_t st);
 int launch_splitk_reduce(const ConvArgs& a, hipStream_t st);
