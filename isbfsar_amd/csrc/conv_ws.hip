@@ -239,7 +239,7 @@ __global__ __launch_bounds__(64 * NW, NW == 6 ? 2 : 1) void gemm1x1_wsreg_kernel
 // The staging registers of gemm1x1_wspipe_kernel, named literally: a[200:255] (set 0: one wave per SIMD, fourteen pieces) or
 // v[228:255] (set 1: two waves per SIMD, seven pieces; no accumulation registers at all there, so that the MFMAs accumulate in vector registers and the epilogue reads them without copies). A load that is still in flight must never be copied or moved by the
 // register allocator, so these registers are kept out of its sight: the compiler sees them only as clobbers of the requests
-// (tests/test_abi_cpu.py checks in the built library that no other instruction of these kernels names them).
+// (tests/test_abi.py checks in the built library that no other instruction of these kernels names them).
 template <int SET, int X, int OFF>
 __device__ __forceinline__ void wsp_request(const void* src) {
     static_assert(X >= 0 && X < (SET == 0 ? 14 : 7), "staging pieces");
