@@ -115,7 +115,7 @@ def test_keras_variable_round_trip():
 
 def test_wspipe_staging_registers_are_private(built_lib, tmp_path):
     """gemm1x1_wspipe_kernel keeps global loads in flight in literally named registers (a[200:255] one wave per SIMD,
-    v[228:255] two waves per SIMD; conv_kernels.hip, wsp_request / wsp_to_lds). The register allocator only sees them as
+    v[228:255] two waves per SIMD; conv_ws.hip, wsp_request / wsp_to_lds). The register allocator only sees them as
     clobbers, so nothing but those requests and their LDS writes may name them in the code the compiler produced:
     disassemble the built library and check."""
     import shutil
