@@ -48,6 +48,10 @@ extern "C" {
 
 const char* isb_last_error(void);
 int isb_version(void);
+/* 1 if the build verified, in the disassembly of this very library, that the weights-stationary expand kernels' literally
+ * named staging registers are touched by nothing else (isbfsar_amd/build.py); 0 = unverified: those kernels are then never
+ * selected by default and the tile kernels run instead (same results, ~4 % slower pose stage). */
+int isb_wsreg_verified(void);
 /* number of visible HIP devices (does not initialise a context) */
 int isb_device_count(void);
 
@@ -128,7 +132,13 @@ typedef struct isb_hpe_cfg {
                                * convolution kernels address a tensor with 32-bit byte offsets and the largest activation
                                * is 2 MiB per frame. Any B is accepted by isb_hpe_forward (it micro-batches). */
     int32_t n_out_joints;     /* informational: joints per pose after selection (30 / 122) */
-    int32_t reserved;
+    int32_t precision;        /* 16-bit storage type of the backbone (was `reserved`; 0 keeps old callers valid):
+                               * 0 = bf16, with the two 8x8 stages (32 of the 79 blocks) and the 640 -> 1280 convolution in IEEE
+                               *     fp16 (weights and activations; same MFMA rate, 3 more mantissa bits): the returned absolute
+                               *     pose (hpe.py:171) then sits within 1e-3 of the fp32 definition, where bf16 everywhere is at
+                               *     1e-3 ... 3e-3 (per-stage budget: DESIGN.md section 4). The reference's own engines are fp16
+                               *     throughout (7_create_engines.py:10).
+                               * 1 = bf16 everywhere (the round-2 layout). */
 } isb_hpe_cfg;
 
 int isb_hpe_create(const isb_hpe_cfg* cfg, isb_hpe** out);
@@ -228,7 +238,9 @@ int isb_hpe_profile_read(isb_hpe* h, double* ms_total, int64_t* launches);
  *   variant 0 = automatic tile choice; variant = 1000 * splits + v (splits >= 2, v a gemm1x1 variant 131-148) runs
  *   the split-K GEMM + reduction pair; variant = 900000 + v (v = 131-148, 181) runs the kernel with in-kernel s_memtime
  *   stamps and prints the phase clocks of its first workgroups to stderr (tuning probe);
- *   out bf16 [B,OH,OW,Cout]; ms_per_iter = HIP-event time of one launch. */
+ *   out bf16 [B,OH,OW,Cout]; ms_per_iter = HIP-event time of one launch. 
+ *   act | 0x100: fp16 operands (ConvArgs.f16): h_x / h_res / h_out hold fp16 bits and the weights are rounded to fp16;
+ *   implemented by the variants the 8x8 stages select (131, 132, 138, 141, 144, 146, 147, 185, 186; 0 = automatic). */
 int isb_debug_conv(int32_t device, const uint16_t* h_x, const float* h_w, const float* h_scale, const float* h_shift,
                    const uint16_t* h_res, const float* h_gate, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
                    int32_t k, int32_t stride, int32_t act, int32_t variant, int32_t iters, uint16_t* h_out,
@@ -261,7 +273,9 @@ int isb_debug_gemm_f32(int32_t device, const float* h_A, const float* h_W, const
 
 /* test / tuning hook: the depthwise 3x3 (+ folded BN + SiLU) + squeeze-excite mean kernel on host tensors.
  *   h_x bf16 [B,H,H,C], h_w f32 [C,3,3] (taps are rounded to bf16 after the BN scale is folded in, like every
- *   conv weight), stride 1 (pad 1) or 2 (TF SAME: pad bottom/right); out bf16 [B,H/stride,H/stride,C], pooled f32 [B,C] */
+ *   conv weight), stride 1 (pad 1) or 2 (TF SAME: pad bottom/right); out bf16 [B,H/stride,H/stride,C], pooled f32 [B,C].
+ *   stride | 0x100: h_x and the taps are fp16; stride | 0x200: out is fp16 (forms of the fp16 stages: stride 1 with both,
+ *   stride 2 with 0x200 alone) */
 int isb_debug_dwconv(int32_t device, const uint16_t* h_x, const float* h_w, const float* h_scale, const float* h_shift,
                      int32_t B, int32_t H, int32_t C, int32_t stride, int32_t iters, uint16_t* h_out, float* h_pooled,
                      float* ms_per_iter);

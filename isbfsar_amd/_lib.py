@@ -27,7 +27,7 @@ class isb_ar_cfg(C.Structure):
 class isb_hpe_cfg(C.Structure):
     _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("ppx", C.c_float), ("ppy", C.c_float),
                 ("width", C.c_int32), ("height", C.c_int32), ("device", C.c_int32),
-                ("max_batch", C.c_int32), ("n_out_joints", C.c_int32), ("reserved", C.c_int32)]
+                ("max_batch", C.c_int32), ("n_out_joints", C.c_int32), ("precision", C.c_int32)]
 
 
 class isb_det_cfg(C.Structure):
@@ -41,6 +41,7 @@ _P = C.c_void_p
 SIGNATURES = {
     "isb_last_error": (C.c_char_p, []),
     "isb_version": (C.c_int, []),
+    "isb_wsreg_verified": (C.c_int, []),
     "isb_device_count": (C.c_int, []),
     "isb_ar_create": (C.c_int, [C.POINTER(isb_ar_cfg), C.POINTER(_P)]),
     "isb_ar_destroy": (None, [_P]),

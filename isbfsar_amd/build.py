@@ -8,9 +8,11 @@ working tree to the GPU box. Objects are rebuilt when a source or header is newe
 from __future__ import annotations
 
 import os
+import re
 import shutil
 import subprocess
 import sys
+import tempfile
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -50,6 +52,76 @@ def _deps_mtime() -> float:
     return m
 
 
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+GUARD_SRC = "wsreg_guard.cpp"          # defines isb_wsreg_verified(); compiled AFTER the check below with its result
+
+
+def wspipe_registers_private(lib_path: str):
+    """gemm1x1_wspipe_kernel (csrc/conv_ws.hip) keeps global loads in flight in literally named registers -- a[200:255]
+    with one wave per SIMD, v[228:255] with two -- that the register allocator sees only as clobbers of the request asm.
+    Whether the compiler kept its hands off them depends on the hipcc that built the library, so the built code is
+    checked: disassemble every gemm1x1_wspipe_kernel instantiation and require that nothing but the requests
+    (global_load_dwordx4) and their LDS writes (ds_write_b128) names a staging register. Returns None when the library
+    passes, else the reason (also when llvm-objdump is missing: unverified = not trusted)."""
+    if not os.path.exists(OBJDUMP):
+        return f"{OBJDUMP} not found: the staging registers cannot be verified"
+    with tempfile.TemporaryDirectory() as tmp:
+        so = os.path.join(tmp, "lib.so")
+        shutil.copy(lib_path, so)
+        r = subprocess.run([OBJDUMP, "--offloading", so], capture_output=True, cwd=tmp)
+        if r.returncode != 0:
+            return "llvm-objdump --offloading failed: " + r.stderr.decode(errors="replace")[-300:]
+        text = ""
+        for f in sorted(os.listdir(tmp)):
+            if f.startswith("lib.so.") and f.endswith("gfx950"):
+                d = subprocess.run([OBJDUMP, "-d", os.path.join(tmp, f)], capture_output=True, text=True)
+                if d.returncode != 0:
+                    return "llvm-objdump -d failed: " + d.stderr[-300:]
+                text += d.stdout
+    kernels, cur = {}, None
+    for line in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            cur = m.group(1) if "gemm1x1_wspipe_kernel" in m.group(1) else None
+            if cur:
+                kernels[cur] = []
+        elif cur and line.strip():
+            kernels[cur].append(line.split("//")[0])
+    if len(kernels) < 12:       # NK 3/6/7/12 x act / no act / stamps x 1 or 2 waves per SIMD x MFMA shape x operand type
+        return f"only {len(kernels)} gemm1x1_wspipe_kernel instantiations found in the code object"
+
+    def regs(line, letter):
+        out = set()
+        for lo, hi in re.findall(rf"\b{letter}\[(\d+):(\d+)\]", line):
+            out.update(range(int(lo), int(hi) + 1))
+        out.update(int(n) for n in re.findall(rf"\b{letter}(\d+)\b", line))
+        return out
+
+    for name, lines in kernels.items():
+        m = re.search(r"ILi(\d+)ELb[01]ELb[01]ELi(\d+)ELi(\d+)ELi(\d+)ELb[01]ELb[01]EEE", name)
+        if not m:
+            return f"cannot parse the template arguments of {name}"
+        nk, tmb, wpc, nwm = (int(x) for x in m.groups())
+        two_waves = wpc * nwm == 2                  # waves per SIMD
+        letter, lo = ("v", 228) if two_waves else ("a", 200)
+        n_req = n_wr = 0
+        for line in lines:
+            if not any(x >= lo for x in regs(line, letter)):
+                continue
+            op = next((t for t in line.split() if t.startswith(("global_", "ds_", "v_", "s_", "buffer_", "scratch_"))), "")
+            if op == "global_load_dwordx4":
+                n_req += 1
+            elif op == "ds_write_b128":
+                n_wr += 1
+                if two_waves and not all(x >= lo for x in regs(line.split(",", 1)[1], "v")):
+                    return f"{name}: LDS write mixes staging and ordinary registers: {line.strip()}"
+            else:
+                return f"{name}: staging register in a foreign instruction: {line.strip()}"
+        if not (n_req > 0 and n_wr > 0):
+            return f"{name}: no staged requests found"
+    return None
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = _hipcc()
     os.makedirs(OBJ, exist_ok=True)
@@ -76,8 +148,19 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
-    if jobs or force or not os.path.exists(LIB):
-        run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", *objs, "-o", LIB])
+    guard_o = os.path.join(OBJ, "wsreg_guard.o")
+    if jobs or force or not os.path.exists(LIB) or not os.path.exists(guard_o):
+        # fail closed: link once without the guard's verdict, check the code the compiler actually produced,
+        # then compile the verdict in. isb_wsreg_verified() == 0 makes conv_kernels.hip fall back to the tile kernels.
+        def guard(ok: int):
+            run([hipcc, "-O2", "-std=c++17", "-fPIC", f"-DISB_WSREG_VERIFIED={ok}", "-c", os.path.join(CSRC, GUARD_SRC), "-o", guard_o])
+            run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", *objs, guard_o, "-o", LIB])
+        guard(0)
+        why = wspipe_registers_private(LIB)
+        if why is None:
+            guard(1)
+        else:
+            print(f"[build] WARNING: weights-stationary expand kernels DISABLED (tile kernels are used instead): {why}", flush=True)
     return LIB
 
 

@@ -32,6 +32,56 @@ __device__ __forceinline__ uint4 gate_bf16x8(uint4 v, float4 g0, float4 g1) {
                       gate_bf16x2(v.w, g1.z, g1.w));
 }
 
+// ---- 16-bit storage type of a layer: bf16 (stages 0-4 of the pose backbone, the detector) or IEEE fp16 (the two 8x8 stages
+// and the 640 -> 1280 convolution under isb_hpe_cfg.precision 0: 3 more mantissa bits at the same MFMA rate; per-stage error
+// budget in DESIGN.md section 4). One traits struct so that a kernel takes `bool F16` and nothing else changes.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float h2f_(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+// round to nearest even, saturating at the largest finite fp16 (an inf would poison every later layer)
+__device__ __forceinline__ float f16_sat(float x) { return __builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f); }
+__device__ __forceinline__ uint16_t f2h_(float x) { return __builtin_bit_cast(uint16_t, (_Float16)f16_sat(x)); }
+
+template <bool F16>
+struct T16 {
+    static __device__ __forceinline__ float to_f32(uint16_t h) {
+        if constexpr (F16) return h2f_(h); else return bf2f_(h);
+    }
+    static __device__ __forceinline__ uint16_t from_f32(float x) {
+        if constexpr (F16) return f2h_(x); else return f2bf_(x);
+    }
+    static __device__ __forceinline__ float lo(uint32_t w) { return to_f32((uint16_t)(w & 0xffffu)); }
+    static __device__ __forceinline__ float hi(uint32_t w) { return to_f32((uint16_t)(w >> 16)); }
+    static __device__ __forceinline__ uint32_t pack2(float a, float b) {
+        if constexpr (F16) {
+            const f32x2_t v = {f16_sat(a), f16_sat(b)};
+            return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+        } else {
+            const f32x2_t v = {a, b};
+            return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+        }
+    }
+    // D = A (32 x 16) * B (16 x 32) + C on the matrix cores; operands as the raw 16 bytes of a fragment
+    static __device__ __forceinline__ f32x16 mfma32(uint4 a, uint4 b, f32x16 c) {
+        if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+    // acc + x.lo * w.lo + x.hi * w.hi in f32 (v_dot2_f32_*: with one half of w zero, an f32 FMA straight from the pair)
+    static __device__ __forceinline__ float dot2(uint32_t x, uint32_t w, float acc) {
+        if constexpr (F16) return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, x), __builtin_bit_cast(f16x2_t, w), acc, false);
+        else return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, x), __builtin_bit_cast(bf16x2_t, w), acc, false);
+    }
+    static constexpr uint32_t ONE = F16 ? 0x3c00u : 0x3f80u;        // 1.0 in the low half
+    // SE gate on a pair: T(f32(x) * g)
+    static __device__ __forceinline__ uint32_t gate2(uint32_t w, float g_lo, float g_hi) {
+        if constexpr (F16) return pack2(lo(w) * g_lo, hi(w) * g_hi);
+        else return gate_bf16x2(w, g_lo, g_hi);
+    }
+    static __device__ __forceinline__ uint4 gate8(uint4 v, float4 g0, float4 g1) {
+        return make_uint4(gate2(v.x, g0.x, g0.y), gate2(v.y, g0.z, g0.w), gate2(v.z, g1.x, g1.y), gate2(v.w, g1.z, g1.w));
+    }
+};
+
 constexpr int CK = 32;            // k-tile (bf16 elements) = 64 B per row
 constexpr int ROWB = 64;          // bytes per LDS row
 

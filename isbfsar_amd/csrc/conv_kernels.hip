@@ -25,7 +25,7 @@ namespace isb {
 // BIAS_LDS: the tile's bias row already sits in LDS at byte offset bias_off (requested at kernel start); else it is
 // read from global now.
 // (8-byte stores straight from registers instead of the LDS-staged 16-byte rows measured 25 % slower.)
-template <int TM, int TN, int WGM, int WGN, bool BIAS_LDS = false>
+template <int TM, int TN, int WGM, int WGN, bool BIAS_LDS = false, bool F16 = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[TM][TN], unsigned char* lds, int m0, int n0,
                                               int wm, int wn, int r, int h, int tid, int bias_off = 0) {
     constexpr int NT = 64 * WGM * WGN;
@@ -100,13 +100,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
                     else if (p.act) { v0 = act_other(p.act, v0); v1 = act_other(p.act, v1); v2 = act_other(p.act, v2); v3 = act_other(p.act, v3); }
                     if (p.res && mok) {       // (requesting all residual pieces up front measured 5-7 % slower, twice)
                         const uint2 rr = *reinterpret_cast<const uint2*>(p.res + (size_t)m * p.Cout + n);
-                        v0 += bf2f_((uint16_t)(rr.x & 0xffff)); v1 += bf2f_((uint16_t)(rr.x >> 16));
-                        v2 += bf2f_((uint16_t)(rr.y & 0xffff)); v3 += bf2f_((uint16_t)(rr.y >> 16));
+                        v0 += T16<F16>::lo(rr.x); v1 += T16<F16>::hi(rr.x);
+                        v2 += T16<F16>::lo(rr.y); v3 += T16<F16>::hi(rr.y);
                     }
                 }
                 uint2 pk;
-                pk.x = (uint32_t)f2bf_(v0) | ((uint32_t)f2bf_(v1) << 16);
-                pk.y = (uint32_t)f2bf_(v2) | ((uint32_t)f2bf_(v3) << 16);
+                pk.x = (uint32_t)T16<F16>::from_f32(v0) | ((uint32_t)T16<F16>::from_f32(v1) << 16);
+                pk.y = (uint32_t)T16<F16>::from_f32(v2) | ((uint32_t)T16<F16>::from_f32(v3) << 16);
                 if constexpr (STAGE) *reinterpret_cast<uint2*>(Cs + ml * CROW + nl * 2) = pk;
                 else if (mok && n < p.Cout) *reinterpret_cast<uint2*>(out16 + (size_t)m * p.Cout + n) = pk;
             }
@@ -734,7 +734,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_kernel(ConvArgs
 // {prologue, DMA wait, barrier wait, whole k loop, epilogue, k-steps} to p.part[workgroup]
 // NBUF = 3: three k-step buffers, requests run TWO steps ahead and the wait before a step is a counted vmcnt (the pieces of
 // the step after it may still fly) instead of vmcnt(0).
-template <int TM, int TN, int WGM, int WGN, int GATE = 0, bool STAMPS = false, int NBUF = 2>
+template <int TM, int TN, int WGM, int WGN, int GATE = 0, bool STAMPS = false, int NBUF = 2, bool F16 = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_dma_kernel(ConvArgs p) {
     uint64_t st_t0 = 0, st_wait = 0, st_bar = 0, st_loop0 = 0, st_loop1 = 0;
     if constexpr (STAMPS) st_t0 = __builtin_amdgcn_s_memtime();
@@ -900,25 +900,25 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_dma_kernel(ConvArgs p)
         constexpr int buf = decltype(bufc)::value;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[TM], bfr[TN];
+            uint4 af[TM], bfr[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 uint4 v = *reinterpret_cast<const uint4*>(lds + a_sw[ks] + (buf * BUF + i * 2048));
                 if constexpr (GATE) {
                     const float* gs = reinterpret_cast<const float*>(lds + GATE_OFF) + g_row[i] + kt_now * CK + ks * 16;
                     const float4 g0 = *reinterpret_cast<const float4*>(gs), g1 = *reinterpret_cast<const float4*>(gs + 4);
-                    v = gate_bf16x8(v, g0, g1);
+                    v = T16<F16>::gate8(v, g0, g1);
                 }
-                af[i] = __builtin_bit_cast(bf16x8, v);
+                af[i] = v;
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + b_sw[ks] + (buf * BUF + j * 2048)));
+                bfr[j] = *reinterpret_cast<const uint4*>(lds + b_sw[ks] + (buf * BUF + j * 2048));
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = T16<F16>::mfma32(bfr[j], af[i], acc[i][j]);
         }
         ++kt_now;
     };
@@ -1010,7 +1010,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_dma_kernel(ConvArgs p)
     }
     }
     if constexpr (STAMPS) st_loop1 = __builtin_amdgcn_s_memtime();
-    if (ISB_EPI_SHARED || p.splits > 1 || p.out_f32) conv_epilogue<TM, TN, WGM, WGN, true>(p, acc, lds, m0, n0, wm, wn, r, h, tid, bias_off);
+    if (ISB_EPI_SHARED || p.splits > 1 || p.out_f32) conv_epilogue<TM, TN, WGM, WGN, true, F16>(p, acc, lds, m0, n0, wm, wn, r, h, tid, bias_off);
     else conv_epilogue_wl<TM, TN, WGM, WGN>(p, acc, lds, m0, n0, wm, wn, r, h, lane, wave, bias_off);
     if constexpr (STAMPS) {
         const uint64_t t_end = __builtin_amdgcn_s_memtime();
@@ -1713,12 +1713,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs p) {
     if (p.act) { v.x = silu_fast(v.x); v.y = silu_fast(v.y); v.z = silu_fast(v.z); v.w = silu_fast(v.w); }
     if (p.res) {
         const uint2 rr = *reinterpret_cast<const uint2*>(p.res + e);
-        v.x += bf2f_((uint16_t)(rr.x & 0xffff)); v.y += bf2f_((uint16_t)(rr.x >> 16));
-        v.z += bf2f_((uint16_t)(rr.y & 0xffff)); v.w += bf2f_((uint16_t)(rr.y >> 16));
+        if (p.f16) { v.x += T16<true>::lo(rr.x); v.y += T16<true>::hi(rr.x); v.z += T16<true>::lo(rr.y); v.w += T16<true>::hi(rr.y); }
+        else { v.x += T16<false>::lo(rr.x); v.y += T16<false>::hi(rr.x); v.z += T16<false>::lo(rr.y); v.w += T16<false>::hi(rr.y); }
     }
     uint2 pk;
-    pk.x = (uint32_t)f2bf_(v.x) | ((uint32_t)f2bf_(v.y) << 16);
-    pk.y = (uint32_t)f2bf_(v.z) | ((uint32_t)f2bf_(v.w) << 16);
+    if (p.f16) { pk.x = T16<true>::pack2(v.x, v.y); pk.y = T16<true>::pack2(v.z, v.w); }
+    else {
+        pk.x = (uint32_t)f2bf_(v.x) | ((uint32_t)f2bf_(v.y) << 16);
+        pk.y = (uint32_t)f2bf_(v.z) | ((uint32_t)f2bf_(v.w) << 16);
+    }
     *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + e) = pk;
 }
 
@@ -1752,9 +1755,11 @@ static dim3 conv_grid(ConvArgs& a, int BM, int BN) {
     return dim3(8 * ((a.grid_m + 7) / 8) * a.grid_n, 1, z);
 }
 
+extern "C" int isb_wsreg_verified(void);      // wsreg_guard.cpp: 1 only if the build checked the staging registers in the disassembly
 static int wsreg_on() {             // ISB_WSREG: weights-stationary kernel for the short-K expand convolutions. Default 184 (K <= 224; K = 384: 186);
                                     // 0 = tile kernels only, 181 / 182 / 183 = the earlier forms (A/B switch; 181 / 182 also take K = 384)
-    static const int on = [] { const char* e = getenv("ISB_WSREG"); const int v = e ? atoi(e) : 184; return v == 1 ? 184 : v; }();
+    // fail closed: without the build's verdict the default is 0 (tile kernels); an explicit ISB_WSREG still selects a form
+    static const int on = [] { const char* e = getenv("ISB_WSREG"); const int v = e ? atoi(e) : (isb_wsreg_verified() ? 184 : 0); return v == 1 ? 184 : v; }();
     return on;
 }
 
@@ -1789,7 +1794,7 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
             if (g1 && !a.gate) v = 138;
             else if (g1 && a.gate && ohw % 64 == 0) v = 147;
             else v = (!a.gate && a.zeros) ? 64 : 75;
-        } else if (g1 && !a.gate && !a.res && !a.out_f32 && a.act <= 1 && a.splits <= 1 && wsreg_on() &&
+        } else if (g1 && !a.gate && !a.res && !a.out_f32 && a.act <= 1 && a.splits <= 1 && wsreg_on() && (!a.f16 || (a.Cin == 384 && wsreg_on() >= 184)) &&
                    (a.Cin == 96 || a.Cin == 192 || a.Cin == 224 || (a.Cin == 384 && wsreg_on() != 183 && wsreg_on() != 1840)) && a.Cout % 32 == 0 && a.M >= 64 * 128 &&
                    (size_t)a.M * a.Cin * 2 < 0xffffffffull) {
             v = wsreg_on();                                                      // weights-stationary persistent GEMM (short-K expand convolutions)
@@ -1836,6 +1841,10 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
         }
     }
     const bool is_g1 = (v >= 131 && v <= 153) || (v >= 191 && v <= 197);
+    if (a.f16 && !(v == 131 || v == 132 || v == 138 || v == 141 || v == 144 || v == 146 || v == 147 || v == 149 || v == 185 || v == 186)) {
+        set_error("conv_igemm: fp16 operands are implemented by variants 131 / 132 / 138, 141 / 144 / 146 / 147 / 149 and 185 / 186 (got %d)", v);
+        return ISB_ERR_INVALID;
+    }
     if (aa.splits > 1 && !(is_g1 && aa.part)) {
         set_error("conv_igemm: split-K is implemented by the gemm1x1 variants (131-149) and needs a partial buffer");
         return ISB_ERR_INVALID;
@@ -2003,22 +2012,34 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
         if (a.probe & 2) hipLaunchKernelGGL((gemm1x1_dma_kernel<TM, TN, WGM, WGN, 0, true>), g, dim3(64 * WGM * WGN), 0, st, aa); \
         else hipLaunchKernelGGL((gemm1x1_dma_kernel<TM, TN, WGM, WGN>), g, dim3(64 * WGM * WGN), 0, st, aa);     \
     } while (0)
+    // the variants the fp16 stages select exist in both operand types
+#define ISB_CONV_LAUNCH_G1H(TM, TN, WGM, WGN)                                                                    \
+    do {                                                                                                         \
+        if (!a.f16) { ISB_CONV_LAUNCH_G1(TM, TN, WGM, WGN); break; }                                             \
+        if (a.gate || a.KH != 1 || a.stride != 1 || a.pad != 0 || (a.probe & 2)) {                               \
+            set_error("conv_igemm: variants 131-139 are un-gated 1x1 stride-1 GEMMs");                           \
+            return ISB_ERR_INVALID;                                                                              \
+        }                                                                                                        \
+        const dim3 g = conv_grid(aa, 32 * TM * WGM, 32 * TN * WGN);                                              \
+        hipLaunchKernelGGL((gemm1x1_dma_kernel<TM, TN, WGM, WGN, 0, false, 2, true>), g, dim3(64 * WGM * WGN), 0, st, aa); \
+    } while (0)
         case 181: case 182: case 183: case 184: case 185: case 186: case 187: case 188: {    // conv_ws.hip
             const int rc = launch_conv_ws(a, aa, v, st);
             if (rc != ISB_OK) return rc;
             break;
         }
-        case 131: ISB_CONV_LAUNCH_G1(1, 3, 4, 2); break;   // 128 x 192
-        case 132: ISB_CONV_LAUNCH_G1(1, 2, 4, 2); break;   // 128 x 128
+        case 131: ISB_CONV_LAUNCH_G1H(1, 3, 4, 2); break;  // 128 x 192
+        case 132: ISB_CONV_LAUNCH_G1H(1, 2, 4, 2); break;  // 128 x 128
         case 133: ISB_CONV_LAUNCH_G1(2, 3, 4, 2); break;   // 256 x 192 (8 waves of 64 x 96)
         case 134: ISB_CONV_LAUNCH_G1(2, 2, 4, 2); break;   // 256 x 128
         case 135: ISB_CONV_LAUNCH_G1(1, 2, 8, 1); break;   // 256 x  64
         case 136: ISB_CONV_LAUNCH_G1(1, 3, 8, 1); break;   // 256 x  96
         case 137: ISB_CONV_LAUNCH_G1(1, 7, 4, 1); break;   // 128 x 224
-        case 138: ISB_CONV_LAUNCH_G1(1, 1, 2, 2); break;   //  64 x  64
+        case 138: ISB_CONV_LAUNCH_G1H(1, 1, 2, 2); break;  //  64 x  64
         case 139: ISB_CONV_LAUNCH_G1(2, 4, 4, 2); break;   // 256 x 256 (8 waves of 64 x 128)
         case 140: ISB_CONV_LAUNCH_G1(1, 3, 2, 2); break;   //  64 x 192, 4 waves (four workgroups per CU: more independent phases)
         case 150: ISB_CONV_LAUNCH_G1(1, 2, 2, 2); break;   //  64 x 128, 4 waves
+#undef ISB_CONV_LAUNCH_G1H
 #undef ISB_CONV_LAUNCH_G1
 #define ISB_CONV_LAUNCH_C3(TM, TN, WGM, WGN)                                                                     \
     do {                                                                                                         \
@@ -2068,7 +2089,14 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
         case 166: ISB_CONV_LAUNCH_C3(2, 3, 4, 2); break;   // 256 x 192
 #undef ISB_CONV_LAUNCH_C3
 #define ISB_CONV_LAUNCH_G1G(TM, TN, WGM, WGN) ISB_CONV_LAUNCH_G1GN(TM, TN, WGM, WGN, 2)
-#define ISB_CONV_LAUNCH_G1GN(TM, TN, WGM, WGN, NBUF_)                                                                   \
+#define ISB_CONV_LAUNCH_G1GN(TM, TN, WGM, WGN, NBUF_) ISB_CONV_LAUNCH_G1GT(TM, TN, WGM, WGN, NBUF_, false)
+    // the variants the fp16 stages select exist in both operand types
+#define ISB_CONV_LAUNCH_G1GH(TM, TN, WGM, WGN)                                                                   \
+    do {                                                                                                         \
+        if (a.f16) ISB_CONV_LAUNCH_G1GT(TM, TN, WGM, WGN, 2, true);                                              \
+        else ISB_CONV_LAUNCH_G1GT(TM, TN, WGM, WGN, 2, false);                                                   \
+    } while (0)
+#define ISB_CONV_LAUNCH_G1GT(TM, TN, WGM, WGN, NBUF_, F16_)                                                             \
     do {                                                                                                         \
         constexpr int BM_ = 32 * TM * WGM, BN_ = 32 * TN * WGN;                                                  \
         const int ohw = a.OH * a.OW;                                                                             \
@@ -2082,14 +2110,14 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
         const int stage = BM_ * (BN_ * 2 + 16);                                                                  \
         aa.grid_bias_off = ring > stage ? ring : stage;                                                          \
         const int bytes = aa.grid_bias_off + BN_ * 4;                                                            \
-        auto kern = gemm1x1_dma_kernel<TM, TN, WGM, WGN, true, false, NBUF_>;                                                  \
+        auto kern = gemm1x1_dma_kernel<TM, TN, WGM, WGN, true, false, NBUF_, F16_>;                                            \
         static int attr_bytes = 0;                                                                               \
         if (bytes > attr_bytes) {                                                                                \
             ISB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));  \
             attr_bytes = bytes;                                                                                  \
         }                                                                                                        \
         const dim3 g = conv_grid(aa, BM_, BN_);                                                                  \
-        if (a.probe & 2) {                                                                                       \
+        if ((a.probe & 2) && !F16_) {                                                                            \
             auto kern2 = gemm1x1_dma_kernel<TM, TN, WGM, WGN, true, true, NBUF_>;                                       \
             ISB_HIP(hipFuncSetAttribute((const void*)kern2, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); \
             hipLaunchKernelGGL(kern2, g, dim3(64 * WGM * WGN), bytes, st, aa);                                   \
@@ -2110,22 +2138,25 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
             aa.grid_bias_off = ring > stage ? ring : stage;
             const int bytes = aa.grid_bias_off + BN_ * 4;
             auto kern = gemm1x1_dma_kernel<1, 2, 2, 2, 2>;
+            auto kern_h = gemm1x1_dma_kernel<1, 2, 2, 2, 2, false, 2, true>;
             static bool attr_set = false;
             if (!attr_set) {
                 ISB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+                ISB_HIP(hipFuncSetAttribute((const void*)kern_h, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
                 attr_set = true;
             }
             const dim3 g = conv_grid(aa, BM_, BN_);
-            hipLaunchKernelGGL(kern, g, dim3(256), bytes, st, aa);
+            if (a.f16) hipLaunchKernelGGL(kern_h, g, dim3(256), bytes, st, aa);
+            else hipLaunchKernelGGL(kern, g, dim3(256), bytes, st, aa);
             break;
         }
-        case 141: ISB_CONV_LAUNCH_G1G(1, 3, 4, 2); break;   // 128 x 192, SE gate on the A fragments
+        case 141: ISB_CONV_LAUNCH_G1GH(1, 3, 4, 2); break;  // 128 x 192, SE gate on the A fragments
         case 142: ISB_CONV_LAUNCH_G1G(1, 2, 4, 2); break;   // 128 x 128
         case 143: ISB_CONV_LAUNCH_G1G(1, 7, 4, 1); break;   // 128 x 224
-        case 144: ISB_CONV_LAUNCH_G1G(1, 5, 4, 2); break;   // 128 x 320
+        case 144: ISB_CONV_LAUNCH_G1GH(1, 5, 4, 2); break;  // 128 x 320
         case 145: ISB_CONV_LAUNCH_G1G(2, 2, 4, 2); break;   // 256 x 128
-        case 146: ISB_CONV_LAUNCH_G1G(1, 3, 2, 2); break;   //  64 x 192
-        case 147: ISB_CONV_LAUNCH_G1G(1, 2, 2, 2); break;   //  64 x 128
+        case 146: ISB_CONV_LAUNCH_G1GH(1, 3, 2, 2); break;  //  64 x 192
+        case 147: ISB_CONV_LAUNCH_G1GH(1, 2, 2, 2); break;  //  64 x 128
         case 148: ISB_CONV_LAUNCH_G1G(2, 7, 4, 1); break;   // 256 x 224
         case 152: ISB_CONV_LAUNCH_G1G(1, 7, 8, 1); break;   // 256 x 224, eight waves
         case 191: ISB_CONV_LAUNCH_G1GN(1, 3, 4, 2, 3); break;   // three k-step buffers: 128 x 192
@@ -2135,6 +2166,9 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
         case 197: ISB_CONV_LAUNCH_G1GN(1, 2, 2, 2, 3); break;   //  64 x 128
         case 153: ISB_CONV_LAUNCH_G1G(1, 6, 8, 1); break;   // 256 x 192, eight waves
 #undef ISB_CONV_LAUNCH_G1G
+#undef ISB_CONV_LAUNCH_G1GH
+#undef ISB_CONV_LAUNCH_G1GN
+#undef ISB_CONV_LAUNCH_G1GT
         default:
             set_error("conv_igemm: unknown tile variant %d", v);
             return ISB_ERR_INVALID;
@@ -2192,7 +2226,8 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
-template <int S, bool FC1 = false>
+// IN_F16 / OUT_F16: input + taps / output in fp16 instead of bf16 (DwArgs.in_f16 / out_f16)
+template <int S, bool FC1 = false, bool IN_F16 = false, bool OUT_F16 = false>
 __global__ __launch_bounds__(256) void dwconv3x3_pool_kernel(DwArgs p) {
     __shared__ float red[32][129];
     __shared__ __attribute__((aligned(16))) float pmean[FC1 ? 128 : 4];
@@ -2224,7 +2259,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_pool_kernel(DwArgs p) {
     // bf16 (1, 0) and (0, 1) in registers: as a literal 0x3f800000 becomes the INLINE constant 1.0, which a packed
     // bf16 operand reads as (1, 0) -- the pool would sum the wrong channel
     uint32_t one_lo, one_hi;
-    asm volatile("v_mov_b32 %0, 0x3f80\n\tv_lshlrev_b32 %1, 16, %0" : "=v"(one_lo), "=v"(one_hi));
+    if constexpr (OUT_F16) asm volatile("v_mov_b32 %0, 0x3c00\n\tv_lshlrev_b32 %1, 16, %0" : "=v"(one_lo), "=v"(one_hi));
+    else asm volatile("v_mov_b32 %0, 0x3f80\n\tv_lshlrev_b32 %1, 16, %0" : "=v"(one_lo), "=v"(one_hi));
 #pragma unroll
     for (int e = 0; e < 8; ++e) psum[e] = 0.f;
     if (cok) {
@@ -2267,8 +2303,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_pool_kernel(DwArgs p) {
                         if (kx >= 0 && kx < 3) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                acc[o][2 * e] = dot2_bf16(x[e], wlo[ky * 3 + kx][e], acc[o][2 * e]);
-                                acc[o][2 * e + 1] = dot2_bf16(x[e], whi[ky * 3 + kx][e], acc[o][2 * e + 1]);
+                                acc[o][2 * e] = T16<IN_F16>::dot2(x[e], wlo[ky * 3 + kx][e], acc[o][2 * e]);
+                                acc[o][2 * e + 1] = T16<IN_F16>::dot2(x[e], whi[ky * 3 + kx][e], acc[o][2 * e + 1]);
                             }
                         }
                     }
@@ -2279,11 +2315,11 @@ __global__ __launch_bounds__(256) void dwconv3x3_pool_kernel(DwArgs p) {
                 uint32_t pk[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const uint16_t lo = f2bf_(silu_fast(acc[o][2 * e])), hi = f2bf_(silu_fast(acc[o][2 * e + 1]));
+                    const uint16_t lo = T16<OUT_F16>::from_f32(silu_fast(acc[o][2 * e])), hi = T16<OUT_F16>::from_f32(silu_fast(acc[o][2 * e + 1]));
                     pk[e] = (uint32_t)lo | ((uint32_t)hi << 16);
                     // the pool sees the stored (rounded) activations: x * 1.0 + psum, one instruction per channel
-                    psum[2 * e] = dot2_bf16(pk[e], one_lo, psum[2 * e]);
-                    psum[2 * e + 1] = dot2_bf16(pk[e], one_hi, psum[2 * e + 1]);
+                    psum[2 * e] = T16<OUT_F16>::dot2(pk[e], one_lo, psum[2 * e]);
+                    psum[2 * e + 1] = T16<OUT_F16>::dot2(pk[e], one_hi, psum[2 * e + 1]);
                 }
                 *reinterpret_cast<uint4*>(p.out + (((size_t)(b * p.OH + oy) * p.OW + ox0 + o) * p.C + c)) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
             }
@@ -2340,9 +2376,21 @@ int launch_dwconv3x3(const DwArgs& a, hipStream_t st) {
             set_error("dwconv3x3: the folded SE FC1 needs pooled + se_part, cse <= 160 and at most %d slabs (C=%d)", SE_MAX_PARTS, a.C);
             return ISB_ERR_INVALID;
         }
-        if (a.stride == 1) hipLaunchKernelGGL((dwconv3x3_pool_kernel<1, true>), grid, dim3(256), 0, st, a);
+    }
+    // fp16 forms: stride 1 fp16 -> fp16 (the blocks inside the fp16 stages), stride 2 bf16 -> fp16 (the block that enters them)
+    const int form = (a.in_f16 ? 1 : 0) | (a.out_f16 ? 2 : 0);
+    if ((form == 3 && a.stride != 1) || (form == 2 && a.stride != 2) || form == 1) {
+        set_error("dwconv3x3: fp16 forms are stride 1 fp16 -> fp16 and stride 2 bf16 -> fp16 (in_f16=%d out_f16=%d stride=%d)", a.in_f16, a.out_f16, a.stride);
+        return ISB_ERR_INVALID;
+    }
+    if (a.se_w1) {
+        if (form == 3) hipLaunchKernelGGL((dwconv3x3_pool_kernel<1, true, true, true>), grid, dim3(256), 0, st, a);
+        else if (form == 2) hipLaunchKernelGGL((dwconv3x3_pool_kernel<2, true, false, true>), grid, dim3(256), 0, st, a);
+        else if (a.stride == 1) hipLaunchKernelGGL((dwconv3x3_pool_kernel<1, true>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((dwconv3x3_pool_kernel<2, true>), grid, dim3(256), 0, st, a);
-    } else if (a.stride == 1) hipLaunchKernelGGL((dwconv3x3_pool_kernel<1, false>), grid, dim3(256), 0, st, a);
+    } else if (form == 3) hipLaunchKernelGGL((dwconv3x3_pool_kernel<1, false, true, true>), grid, dim3(256), 0, st, a);
+    else if (form == 2) hipLaunchKernelGGL((dwconv3x3_pool_kernel<2, false, false, true>), grid, dim3(256), 0, st, a);
+    else if (a.stride == 1) hipLaunchKernelGGL((dwconv3x3_pool_kernel<1, false>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((dwconv3x3_pool_kernel<2, false>), grid, dim3(256), 0, st, a);
     ISB_LAUNCHED("dwconv3x3_pool", st);
     return ISB_OK;
@@ -2557,15 +2605,15 @@ int launch_stem(const StemArgs& a, hipStream_t st) {
 }
 
 // f32 -> bf16 (weights at load time), with an optional per-row scale (folded BN)
-__global__ void f32_to_bf16_rows_kernel(const float* in, const float* row_scale, uint16_t* out, size_t rows, size_t cols) {
+__global__ void f32_to_bf16_rows_kernel(const float* in, const float* row_scale, uint16_t* out, size_t rows, size_t cols, int f16) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= rows * cols) return;
     const float s = row_scale ? row_scale[i / cols] : 1.f;
-    out[i] = f2bf_(in[i] * s);
+    out[i] = f16 ? f2h_(in[i] * s) : f2bf_(in[i] * s);
 }
 
-int launch_f32_to_bf16_rows(const float* in, const float* row_scale, uint16_t* out, size_t rows, size_t cols, hipStream_t st) {
-    hipLaunchKernelGGL(f32_to_bf16_rows_kernel, dim3((unsigned)cdivz(rows * cols, 256)), dim3(256), 0, st, in, row_scale, out, rows, cols);
+int launch_f32_to_bf16_rows(const float* in, const float* row_scale, uint16_t* out, size_t rows, size_t cols, hipStream_t st, int f16) {
+    hipLaunchKernelGGL(f32_to_bf16_rows_kernel, dim3((unsigned)cdivz(rows * cols, 256)), dim3(256), 0, st, in, row_scale, out, rows, cols, f16);
     ISB_LAUNCHED("f32_to_bf16_rows", st);
     return ISB_OK;
 }

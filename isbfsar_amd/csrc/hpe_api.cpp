@@ -18,10 +18,15 @@ namespace {
 struct ConvW {
     DevBuf w16, bias;
     int cout = 0, cin = 0, k = 0;
+    bool f16 = false;             // w16 holds fp16 (the layer runs on fp16 operands) instead of bf16
 };
 
 struct BlockW {
     bool fused = false, residual = false;
+    // fp16 stages (isb_hpe.f16_from): f16_in = the block's input (residual stream) is fp16, so its expand convolution and depthwise
+    // taps are; f16 = everything after the expand tensor is (depthwise output, projection, block output). The block that
+    // enters the fp16 stages has f16 && !f16_in: bf16 expand, depthwise bf16 -> fp16, fp16 projection.
+    bool f16_in = false, f16 = false;
     int cin = 0, cout = 0, cexp = 0, stride = 1, cse = 0, in_hw = 0, out_hw = 0;
     ConvW expand, project;
     DevBuf dw_w, dw_w16, dw_b, se_w1, se_b1, se_w2, se_b2;   // dw_w: the bf16-rounded taps as f32 (fused kernel), dw_w16: bf16
@@ -61,6 +66,11 @@ struct isb_hpe {
     bool split_k = true;          // split-K for the projections of single-frame calls; ISB_SPLIT_K=0 disables
     bool fuse_block = true;       // Fused-MBConv blocks (3x3 expand + 1x1 project) in one launch; ISB_FUSE_BLOCK=0 disables
     int fuse_block_max_cexp = 256;   // 384 expanded channels (E tile 96 KiB) measured 10 % slower than two launches
+    // Storage type of the last stages: stages >= f16_from (index into kStages; default 5 = the two 8x8 stages, 32 of the 79
+    // blocks, 31 % of the FLOPs) and the 640 -> 1280 convolution keep activations AND weights in IEEE fp16 instead of bf16 -- same
+    // MFMA rate, 3 more mantissa bits where the per-stage error budget (oracle/error_budget.py) puts the
+    // distance to the fp32 definition. isb_hpe_cfg.precision = 1 or ISB_HPE_F16=0 -> bf16 everywhere (f16_from = 7).
+    int f16_from = 5;
     bool fuse_front = false;      // MBConv expand + depthwise + pool in one kernel (ISB_FUSE_FRONT=1): measured equal to
                                   // the two-launch form on MI355X (E stays in the 256 MiB Infinity Cache), so off by default
     int n_out = 0;
@@ -109,7 +119,7 @@ inline float bf16_to_float(uint16_t h) {
 }
 
 int upload_conv(const std::map<std::string, BlobTensor>& m, const std::string& prefix, int cout, int k, int cin,
-                ConvW& cw, hipStream_t st) {
+                ConvW& cw, hipStream_t st, bool f16 = false) {
     const BlobTensor *w, *sc, *sh;
     {
         auto it = m.find(prefix + ".w");
@@ -125,10 +135,10 @@ int upload_conv(const std::map<std::string, BlobTensor>& m, const std::string& p
     ISB_TRY(upload(tmp, w->data, w->numel() * 4));
     ISB_TRY(upload(dsc, sc->data, (size_t)cout * 4));
     ISB_TRY(cw.w16.alloc(w->numel() * 2));
-    ISB_TRY(launch_f32_to_bf16_rows(tmp.as<float>(), dsc.as<float>(), cw.w16.as<uint16_t>(), cout, (size_t)k * k * cin, st));
+    ISB_TRY(launch_f32_to_bf16_rows(tmp.as<float>(), dsc.as<float>(), cw.w16.as<uint16_t>(), cout, (size_t)k * k * cin, st, f16 ? 1 : 0));
     ISB_HIP(hipStreamSynchronize(st));
     ISB_TRY(upload(cw.bias, sh->data, (size_t)cout * 4));
-    cw.cout = cout; cw.cin = cin; cw.k = k;
+    cw.cout = cout; cw.cin = cin; cw.k = k; cw.f16 = f16;
     return ISB_OK;
 }
 
@@ -167,6 +177,7 @@ int ensure_ws(Lane& L, int Bm) {
 int conv(isb_hpe* h, hipStream_t st, const ConvW& cw, const void* in, int B, int H, int W, int stride, bool act,
          const void* res, const float* gate, void* out, bool out_f32, Lane* lane = nullptr, const SeFcArgs* se = nullptr) {
     ConvArgs a{};
+    a.f16 = cw.f16 ? 1 : 0;
     a.in = (const uint16_t*)in; a.w = cw.w16.as<uint16_t>(); a.bias = cw.bias.as<float>();
     a.res = (const uint16_t*)res; a.gate = gate; a.out = out;
     a.B = B; a.H = H; a.W = W; a.Cin = cw.cin; a.Cout = cw.cout; a.KH = cw.k; a.KW = cw.k; a.stride = stride;
@@ -263,7 +274,7 @@ int run_backbone(isb_hpe* h, Lane& L, hipStream_t st, const float* crops, int B)
             }
         } else {
             int se_parts = 0;
-            if (b.stride == 1 && h->fuse_front) {
+            if (b.stride == 1 && h->fuse_front && !b.f16) {
                 // expand 1x1 + dw 3x3 + SE pool in one launch: the expanded tensor never leaves the chip
                 ConvArgs a{};
                 a.in = (const uint16_t*)X; a.w = b.expand.w16.as<uint16_t>(); a.bias = b.expand.bias.as<float>();
@@ -290,6 +301,7 @@ int run_backbone(isb_hpe* h, Lane& L, hipStream_t st, const float* crops, int B)
                 d.in = L.bufE.as<uint16_t>(); d.w = b.dw_w16.as<uint16_t>(); d.bias = b.dw_b.as<float>(); d.out = L.bufD.as<uint16_t>();
                 d.B = B; d.H = b.in_hw; d.W = b.in_hw; d.C = b.cexp; d.OH = b.out_hw; d.OW = b.out_hw; d.stride = b.stride;
                 d.pad = b.stride == 1 ? 1 : 0;
+                d.in_f16 = b.f16_in ? 1 : 0; d.out_f16 = b.f16 ? 1 : 0;
                 d.pooled = L.pooled.as<float>();
                 if ((B == 1 && h->split_k) || h->dw_fc1_batched) {   // FC1 of the squeeze-excite rides in the depthwise launch
                     d.se_w1 = b.se_w1.as<float>(); d.se_part = L.semid.as<float>(); d.cse = b.cse;
@@ -360,6 +372,8 @@ extern "C" int isb_hpe_create(const isb_hpe_cfg* cfg, isb_hpe** out) {
     ISB_REQUIRE(cfg->width >= 16 && cfg->height >= 16 && cfg->width <= 8192 && cfg->height <= 8192, ISB_ERR_INVALID,
                 "frame size %dx%d unsupported", cfg->width, cfg->height);
     ISB_REQUIRE(cfg->fx > 0 && cfg->fy > 0, ISB_ERR_INVALID, "focal lengths must be positive");
+    ISB_REQUIRE(cfg->precision == 0 || cfg->precision == 1, ISB_ERR_INVALID,
+                "isb_hpe_cfg.precision %d: 0 (bf16, fp16 in the two 8x8 stages) or 1 (bf16 everywhere)", cfg->precision);
     int ndev = 0;
     ISB_HIP(hipGetDeviceCount(&ndev));
     ISB_REQUIRE(cfg->device >= 0 && cfg->device < ndev, ISB_ERR_INVALID, "device %d not in [0,%d)", cfg->device, ndev);
@@ -382,6 +396,8 @@ extern "C" int isb_hpe_create(const isb_hpe_cfg* cfg, isb_hpe** out) {
     if (const char* e = getenv("ISB_FUSE_SE")) h->fuse_se = atoi(e) != 0;
     if (const char* e = getenv("ISB_DW_FC1")) h->dw_fc1_batched = atoi(e) != 0;
     if (const char* e = getenv("ISB_FUSE_BLOCK_CEXP")) h->fuse_block_max_cexp = atoi(e);
+    if (cfg->precision == 1) h->f16_from = 7;
+    if (const char* e = getenv("ISB_HPE_F16")) h->f16_from = atoi(e) == 0 ? 7 : 5;
     if (const char* e = getenv("ISB_HPE_LANES")) h->n_lanes = std::max(1, std::min(kMaxLanes, atoi(e)));
     ISB_HIP(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
     ISB_HIP(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
@@ -437,10 +453,15 @@ extern "C" int isb_hpe_load_weights(isb_hpe* h, const void* blob, size_t nbytes)
         ISB_TRY(upload(h->stem_w, w.data(), w.size() * 4));
         ISB_TRY(upload(h->stem_b, sh->data, 32 * 4));
     }
-    int idx = 0, hw = 128;
+    int idx = 0, hw = 128, stage = 0;
+    bool stream_f16 = false;        // type of the tensor the next block reads
     for (const StageDef& s : kStages) {
+        const int si = stage++;
         for (int r = 0; r < s.repeats; ++r, ++idx) {
             std::unique_ptr<BlockW> b(new BlockW());
+            b->f16_in = stream_f16;
+            b->f16 = !s.fused && si >= h->f16_from;
+            stream_f16 = b->f16;
             b->fused = s.fused;
             b->cin = r == 0 ? s.cin : s.cout;
             b->cout = s.cout;
@@ -460,21 +481,30 @@ extern "C" int isb_hpe_load_weights(isb_hpe* h, const void* blob, size_t nbytes)
                     ISB_TRY(upload_conv(m, p + ".project", b->cout, 1, b->cexp, b->project, st));
                 }
             } else {
-                ISB_TRY(upload_conv(m, p + ".expand", b->cexp, 1, b->cin, b->expand, st));
-                ISB_TRY(upload_conv(m, p + ".project", b->cout, 1, b->cexp, b->project, st));
+                ISB_TRY(upload_conv(m, p + ".expand", b->cexp, 1, b->cin, b->expand, st, b->f16_in));
+                ISB_TRY(upload_conv(m, p + ".project", b->cout, 1, b->cexp, b->project, st, b->f16));
                 auto it = m.find(p + ".dw.w");
                 ISB_REQUIRE(it != m.end() && it->second.numel() == (size_t)b->cexp * 9, ISB_ERR_WEIGHTS,
                             "%s.dw.w missing or mis-shaped", p.c_str());
                 const BlobTensor *sc, *sh, *w1, *b1, *w2, *b2;
                 ISB_TRY(blob_get(m, (p + ".dw.scale").c_str(), b->cexp, 1, &sc));
                 ISB_TRY(blob_get(m, (p + ".dw.shift").c_str(), b->cexp, 1, &sh));
-                std::vector<float> wt((size_t)9 * b->cexp);      // tap-major, scale folded, rounded to bf16 like every conv weight
+                std::vector<float> wt((size_t)9 * b->cexp);      // tap-major, scale folded, rounded to bf16 (fp16 in the fp16 stages) like every conv weight
                 std::vector<uint16_t> wt16(wt.size());
                 for (int c = 0; c < b->cexp; ++c)
                     for (int t = 0; t < 9; ++t) {
-                        const uint16_t hb = bf16_rne(it->second.data[(size_t)c * 9 + t] * sc->data[c]);
-                        wt16[(size_t)t * b->cexp + c] = hb;
-                        wt[(size_t)t * b->cexp + c] = bf16_to_float(hb);
+                        const float wf = it->second.data[(size_t)c * 9 + t] * sc->data[c];
+                        if (b->f16_in) {
+                            const _Float16 hh = (_Float16)wf;            // round to nearest even, as the device's conversion
+                            uint16_t hb;
+                            memcpy(&hb, &hh, 2);
+                            wt16[(size_t)t * b->cexp + c] = hb;
+                            wt[(size_t)t * b->cexp + c] = (float)hh;
+                        } else {
+                            const uint16_t hb = bf16_rne(wf);
+                            wt16[(size_t)t * b->cexp + c] = hb;
+                            wt[(size_t)t * b->cexp + c] = bf16_to_float(hb);
+                        }
                     }
                 ISB_TRY(upload(b->dw_w, wt.data(), wt.size() * 4));
                 ISB_TRY(upload(b->dw_w16, wt16.data(), wt16.size() * 2));
@@ -497,7 +527,7 @@ extern "C" int isb_hpe_load_weights(isb_hpe* h, const void* blob, size_t nbytes)
         }
     }
     ISB_REQUIRE(hw == 8, ISB_ERR_WEIGHTS, "internal: backbone plan ends at %dx%d", hw, hw);
-    ISB_TRY(upload_conv(m, "bbone.head", 1280, 1, 640, h->headconv, st));
+    ISB_TRY(upload_conv(m, "bbone.head", 1280, 1, 640, h->headconv, st, stream_f16));
     const BlobTensor *hwt, *hb;
     ISB_TRY(blob_get(m, "head.weight", 288, 1280, &hwt));
     ISB_TRY(blob_get(m, "head.bias", 288, 1, &hb));
@@ -781,6 +811,8 @@ extern "C" int isb_debug_conv(int32_t device, const uint16_t* x, const float* w,
     ISB_REQUIRE(x && w && scale && shift && out && ms_per_iter, ISB_ERR_INVALID, "null argument");
     ISB_REQUIRE((k == 1 || k == 3) && (stride == 1 || stride == 2) && iters >= 1, ISB_ERR_INVALID, "bad conv parameters");
     ISB_HIP(hipSetDevice(device));
+    const int f16 = (act & 0x100) ? 1 : 0;      // x / res / out hold fp16 bits and the weights are rounded to fp16
+    act &= 0xff;
     const int OH = H / stride, OW = W / stride;
     const size_t nin = (size_t)B * H * W * Cin, nout = (size_t)B * OH * OW * Cout, nw = (size_t)Cout * k * k * Cin;
     DevBuf dx, dwf, dsc, dsh, dw16, dres, dgate, dout, dzero;
@@ -794,8 +826,9 @@ extern "C" int isb_debug_conv(int32_t device, const uint16_t* x, const float* w,
     ISB_TRY(dout.alloc(nout * 2));
     if (res) ISB_TRY(upload(dres, res, nout * 2));
     if (gate) ISB_TRY(upload(dgate, gate, (size_t)B * Cin * 4));
-    ISB_TRY(launch_f32_to_bf16_rows(dwf.as<float>(), dsc.as<float>(), dw16.as<uint16_t>(), Cout, (size_t)k * k * Cin, nullptr));
+    ISB_TRY(launch_f32_to_bf16_rows(dwf.as<float>(), dsc.as<float>(), dw16.as<uint16_t>(), Cout, (size_t)k * k * Cin, nullptr, f16));
     ConvArgs a{};
+    a.f16 = f16;
     a.in = dx.as<uint16_t>(); a.w = dw16.as<uint16_t>(); a.bias = dsh.as<float>();
     a.res = res ? dres.as<uint16_t>() : nullptr; a.gate = gate ? dgate.as<float>() : nullptr; a.out = dout.p;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = k; a.KW = k; a.stride = stride; a.OH = OH; a.OW = OW;
@@ -1077,13 +1110,23 @@ extern "C" int isb_debug_dwconv(int32_t device, const uint16_t* x, const float* 
                                 float* ms_per_iter) {
     return isb::guard([&]() -> int {
         ISB_REQUIRE(x && w && scale && shift && out && pooled && ms_per_iter, ISB_ERR_INVALID, "null argument");
+        const int in_f16 = (stride & 0x100) ? 1 : 0, out_f16 = (stride & 0x200) ? 1 : 0;   // fp16 input + taps / fp16 output
+        stride &= 0xff;
         ISB_REQUIRE((stride == 1 || stride == 2) && iters >= 1 && B >= 1, ISB_ERR_INVALID, "bad depthwise parameters");
         ISB_HIP(hipSetDevice(device));
         const int OH = H / stride;
         const size_t nin = (size_t)B * H * H * C, nout = (size_t)B * OH * OH * C;
         std::vector<uint16_t> wt16((size_t)9 * C);
         for (int c = 0; c < C; ++c)
-            for (int t = 0; t < 9; ++t) wt16[(size_t)t * C + c] = bf16_rne(w[(size_t)c * 9 + t] * scale[c]);
+            for (int t = 0; t < 9; ++t) {
+                const float wf = w[(size_t)c * 9 + t] * scale[c];
+                if (in_f16) {
+                    const _Float16 hh = (_Float16)wf;
+                    memcpy(&wt16[(size_t)t * C + c], &hh, 2);
+                } else {
+                    wt16[(size_t)t * C + c] = bf16_rne(wf);
+                }
+            }
         DevBuf dx, dw, db, dout, dpool;
         ISB_TRY(upload(dx, x, nin * 2));
         ISB_TRY(upload(dw, wt16.data(), wt16.size() * 2));
@@ -1094,6 +1137,7 @@ extern "C" int isb_debug_dwconv(int32_t device, const uint16_t* x, const float* 
         d.in = dx.as<uint16_t>(); d.w = dw.as<uint16_t>(); d.bias = db.as<float>(); d.out = dout.as<uint16_t>();
         d.pooled = dpool.as<float>(); d.B = B; d.H = H; d.W = H; d.C = C; d.OH = OH; d.OW = OH; d.stride = stride;
         d.pad = stride == 1 ? 1 : 0;
+        d.in_f16 = in_f16; d.out_f16 = out_f16;
         ISB_TRY(launch_dwconv3x3(d, nullptr));
         ISB_HIP(hipDeviceSynchronize());
         hipEvent_t e0, e1;

@@ -128,6 +128,10 @@ struct ConvArgs {
     int M, K;
     int act;                // 1 = SiLU
     int out_f32;
+    // in / w / res / out (unless out_f32) hold IEEE fp16 instead of bf16: the two 8x8 stages and the 640 -> 1280 convolution of
+    // the pose backbone under isb_hpe_cfg.precision 0. Implemented by the gemm1x1 variants the 8x8 stages
+    // select (131, 132, 138; gated 141, 144, 146, 147, 149; weights-stationary 185 / 186) and the split-K reduction.
+    int f16;
     int variant;            // tile variant, 0 = choose by Cout (conv_kernels.hip)
     const uint16_t* zeros;  // >= 16 bytes of zeros (source of padding taps for the LDS-DMA kernels)
     // fused MBConv front half (launch_conv_expand_dw): depthwise 3x3 + SE pool applied to the staged tile
@@ -179,6 +183,8 @@ struct DwArgs {
     const float* se_w1;     // [cse,C] or null
     float* se_part;         // [dw_slabs(a)][B][cse]
     int cse;
+    int in_f16, out_f16;    // `in` + `w` / `out` hold fp16 instead of bf16 (ConvArgs.f16); in bf16 -> out fp16 is the block that
+                            // enters the fp16 stages
 };
 int launch_dwconv3x3(const DwArgs& a, hipStream_t st);
 int dw_slabs(const DwArgs& a);      // channel slabs (= grid.x) of the launch
@@ -205,7 +211,8 @@ struct StemArgs {
     int B, H, W;
 };
 int launch_stem(const StemArgs& a, hipStream_t st);
-int launch_f32_to_bf16_rows(const float* in, const float* row_scale, uint16_t* out, size_t rows, size_t cols, hipStream_t st);
+// out[r][c] = T(in[r][c] * row_scale[r]), T = bf16 or (f16 != 0) fp16, round to nearest even
+int launch_f32_to_bf16_rows(const float* in, const float* row_scale, uint16_t* out, size_t rows, size_t cols, hipStream_t st, int f16 = 0);
 
 // ---------------------------------------------------------------- hpe_kernels.hip
 struct CropParamArgs {

@@ -12,6 +12,9 @@ from .weights import pack_blob
 
 
 
+PRECISIONS = {"bf16_f16tail": 0, "bf16": 1}      # isb_hpe_cfg.precision
+
+
 def _ptr(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
@@ -21,11 +24,17 @@ class HpeEngine:
     modules/hpe/hpe.py:76-173), batched, on one MI355X."""
 
     def __init__(self, fx=384.025146484375, fy=384.025146484375, ppx=319.09661865234375,
-                 ppy=237.75723266601562, width=640, height=480, device: int = 0, max_batch: int = 64):
+                 ppy=237.75723266601562, width=640, height=480, device: int = 0, max_batch: int = 64,
+                 precision: str = "bf16_f16tail"):
+        """precision: "bf16_f16tail" (default: bf16, with the two 8x8 stages and the 640 -> 1280 convolution in fp16 --
+        absolute pose within 1e-3 of the fp32 definition) or "bf16" (bf16 everywhere)."""
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision {precision!r} not in {sorted(PRECISIONS)}")
         self.width, self.height, self.device, self.max_batch = width, height, device, max_batch
+        self.precision = precision
         self.n_out = 0
         self._h = C.c_void_p()
-        cfg = _lib.isb_hpe_cfg(fx, fy, ppx, ppy, width, height, device, max_batch, 0, 0)
+        cfg = _lib.isb_hpe_cfg(fx, fy, ppx, ppy, width, height, device, max_batch, 0, PRECISIONS[precision])
         _lib.check(_lib.lib().isb_hpe_create(C.byref(cfg), C.byref(self._h)), "isb_hpe_create")
 
     def close(self):
@@ -161,6 +170,15 @@ class HpeEngine:
         return ms.value, n.value
 
 
+def f32_to_f16(a: np.ndarray) -> np.ndarray:
+    """round-to-nearest-even f32 -> IEEE fp16 bit patterns (uint16)"""
+    return np.ascontiguousarray(a, dtype=np.float32).astype(np.float16).view(np.uint16)
+
+
+def f16_to_f32(a: np.ndarray) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.uint16).view(np.float16).astype(np.float32)
+
+
 def f32_to_bf16(a: np.ndarray) -> np.ndarray:
     """round-to-nearest-even f32 -> bf16 bit patterns (uint16)"""
     u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
@@ -171,14 +189,17 @@ def bf16_to_f32(a: np.ndarray) -> np.ndarray:
     return (np.ascontiguousarray(a, dtype=np.uint16).astype(np.uint32) << 16).view(np.float32)
 
 
-def conv_debug(x_bf16, w, scale, shift, k, stride, act, res_bf16=None, gate=None, variant=0, iters=1, device=0):
+def conv_debug(x_bf16, w, scale, shift, k, stride, act, res_bf16=None, gate=None, variant=0, iters=1, device=0, f16=False):
     """One backbone convolution through isb_debug_conv. x_bf16 uint16 [B,H,W,Cin] (bf16 bits),
-    w f32 [Cout,k,k,Cin]. Returns (out uint16 [B,OH,OW,Cout], ms_per_launch)."""
+    w f32 [Cout,k,k,Cin]. Returns (out uint16 [B,OH,OW,Cout], ms_per_launch). f16: x / res / out hold fp16 bits and the
+    weights are rounded to fp16 (ConvArgs.f16, the 8x8 stages)."""
     x = np.ascontiguousarray(x_bf16, dtype=np.uint16)
     B, H, W, Cin = x.shape
     w = np.ascontiguousarray(w, dtype=np.float32)
     Cout = w.shape[0]
     out = np.empty((B, H // stride, W // stride, Cout), np.uint16)
+    if f16:
+        act = int(act) | 0x100
     ms = C.c_float()
     r = None if res_bf16 is None else np.ascontiguousarray(res_bf16, dtype=np.uint16)
     g = None if gate is None else np.ascontiguousarray(gate, dtype=np.float32)
@@ -224,16 +245,18 @@ def gemm_f32_debug(A, W, bias=None, a_bias=None, a_add=None, act=0, a_act=0, spl
     return out, ms.value
 
 
-def dwconv_debug(x_bf16, w, scale, shift, stride=1, iters=1, device=0):
+def dwconv_debug(x_bf16, w, scale, shift, stride=1, iters=1, device=0, in_f16=False, out_f16=False):
     """Depthwise 3x3 + SiLU + SE mean through isb_debug_dwconv. x_bf16 uint16 [B,H,H,C], w f32 [C,3,3].
-    Returns (out uint16 [B,H/stride,H/stride,C], pooled f32 [B,C], ms_per_launch)."""
+    Returns (out uint16 [B,H/stride,H/stride,C], pooled f32 [B,C], ms_per_launch). in_f16: x and the taps are fp16;
+    out_f16: out is fp16 (DwArgs.in_f16 / out_f16)."""
     x = np.ascontiguousarray(x_bf16, dtype=np.uint16)
     B, H, _, Cc = x.shape
     f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
     out = np.empty((B, H // stride, H // stride, Cc), np.uint16)
     pooled = np.empty((B, Cc), np.float32)
     ms = C.c_float()
-    _lib.check(_lib.lib().isb_debug_dwconv(device, _ptr(x), _ptr(f(w)), _ptr(f(scale)), _ptr(f(shift)), B, H, Cc, stride,
+    _lib.check(_lib.lib().isb_debug_dwconv(device, _ptr(x), _ptr(f(w)), _ptr(f(scale)), _ptr(f(shift)), B, H, Cc,
+                                           stride | (0x100 if in_f16 else 0) | (0x200 if out_f16 else 0),
                                            iters, _ptr(out), _ptr(pooled), C.byref(ms)), "isb_debug_dwconv")
     return out, pooled, ms.value
 

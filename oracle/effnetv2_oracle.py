@@ -13,12 +13,15 @@ tests/test_oracle_effnetv2.py asserts on this file's own table: 117,746,848 para
 classifier top (117,234,272 trainable: the figures Keras prints for EfficientNetV2L(include_top=False)),
 15.99 GMAC per 256x256 crop and the output shape [B,8,8,1280].
 
-Two numeric modes:
+Numeric modes:
   * ``mode="f32"``   plain fp32 everywhere;
-  * ``mode="bf16"``  the storage/rounding points of the HIP path: conv weights incl. the depthwise taps (BN
-    scale folded in) and every stored activation are rounded to bf16, accumulation / bias / SiLU / SE in fp32, the
-    last 1x1 conv (640->1280) stores f32 and the pose head runs in f32 -- so a GPU-vs-oracle
-    difference is accumulation order only.
+  * ``mode="bf16"``  the storage/rounding points of the HIP path's default precision (isb_hpe_cfg.precision = 0): conv
+    weights incl. the depthwise taps (BN scale folded in) and every stored activation are rounded to bf16 in the stem and
+    in block strings 0-4; in the two 8x8 stages (block strings 5 and 6) and in the 640->1280 conv they are rounded to IEEE
+    fp16 instead (the block that ENTERS the fp16 stages still runs its expand conv and its depthwise taps on bf16: its
+    input is the bf16 stream); accumulation / bias / SiLU / SE in fp32, the last 1x1 conv stores f32 and the pose head runs
+    in f32 -- so a GPU-vs-oracle difference is accumulation order only;
+  * ``mode="bf16_plain"``  isb_hpe_cfg.precision = 1: bf16 at every rounding point (the round-2 layout).
 Only tests/, smoke() and bench.py's cpu_baseline leg may import this file.
 """
 from __future__ import annotations
@@ -59,6 +62,7 @@ class OBlock:
     residual: bool
     in_hw: int
     out_hw: int
+    stage: int = 0     # index of the block string (0..6) the block was expanded from
 
 
 def parse_block_string(s: str) -> dict:
@@ -82,7 +86,7 @@ def oracle_blocks(in_hw: int = 128, strings=V2_L_BLOCKS) -> List[OBlock]:
     identity skip when stride 1 and in == out."""
     out: List[OBlock] = []
     hw, idx = in_hw, 0
-    for s in strings:
+    for si, s in enumerate(strings):
         a = parse_block_string(s)
         assert a["k"] == 3, "efficientnetv2-l uses 3x3 kernels only"
         for rep in range(a["r"]):
@@ -90,7 +94,7 @@ def oracle_blocks(in_hw: int = 128, strings=V2_L_BLOCKS) -> List[OBlock]:
             stride = a["s"] if rep == 0 else 1
             ohw = hw // stride
             out.append(OBlock(idx, "fused" if a["c"] == 1 else "mb", cin, a["o"], cin * a["e"], stride,
-                              max(1, int(cin * a["se"])) if a["se"] > 0 else 0, stride == 1 and cin == a["o"], hw, ohw))
+                              max(1, int(cin * a["se"])) if a["se"] > 0 else 0, stride == 1 and cin == a["o"], hw, ohw, si))
             hw, idx = ohw, idx + 1
     return out
 
@@ -132,18 +136,62 @@ def count_macs(blocks: Optional[List[OBlock]] = None, crop: int = 256, n_head_lo
 
 
 def _r(x: torch.Tensor, mode: str) -> torch.Tensor:
-    return x.bfloat16().float() if mode == "bf16" else x
+    """Storage rounding: "bf16" = one bf16 value; "bf16x2" = hi + lo bf16 pair (x ~ hi + bf16(x - hi), 16 mantissa
+    bits: what an f32-grade residual stream stores); "f32" = none."""
+    if mode == "bf16":
+        return x.bfloat16().float()
+    if mode == "bf16x2":
+        hi = x.bfloat16().float()
+        return hi + (x - hi).bfloat16().float()
+    if mode == "f16":
+        return x.clamp(-65504.0, 65504.0).half().float()      # the device saturates instead of producing inf
+    return x
 
 
 def _silu(x):
     return x * torch.sigmoid(x)
 
 
+ROUND_POINTS = ("w", "expand", "dw", "gate", "out")
+
+
 class EffNetV2LOracle:
-    def __init__(self, state: Mapping[str, np.ndarray], mode: str = "bf16"):
-        assert mode in ("f32", "bf16")
+    """mode "f32" / "bf16" as in the module docstring. ``rounding`` (optional) overrides the storage type per
+    rounding point: a callable (stage, point) -> "f32" | "bf16" | "f16" | "bf16x2" (hi + lo pair) with stage = index of the block string
+    (0..6; -1 = stem output, 7 = the 640->1280 conv's weights) and point in ROUND_POINTS:
+        "w"       conv + depthwise weights of the stage (BN scale folded in)
+        "expand"  output of the expand conv (3x3 for Fused-MBConv, 1x1 for MBConv)
+        "dw"      output of the depthwise conv (after BN + SiLU)
+        "gate"    the SE-gated tensor the projection reads
+        "out"     the block output = the residual stream ("f32+bf16copy": the skip path keeps f32, the next block's
+                  convolutions read a bf16 copy -- a layout the budget evaluates, not one the product has)
+    This is what oracle/error_budget.py switches one point at a time."""
+
+    F16_FROM = 5        # first block string the product runs in fp16 (hpe_api.cpp f16_from)
+
+    def __init__(self, state: Mapping[str, np.ndarray], mode: str = "bf16", rounding=None):
+        assert mode in ("f32", "bf16", "bf16_plain")
         self.mode = mode
+        mixed = rounding is None and mode == "bf16"
+        if rounding is None:
+            if mode == "bf16":
+                rounding = lambda stage, point: "f16" if stage >= self.F16_FROM else "bf16"
+            elif mode == "bf16_plain":
+                rounding = lambda stage, point: "bf16"
+            else:
+                rounding = lambda stage, point: "f32"
+        self.rounding = rounding
         self.blocks = oracle_blocks()
+        # storage type of every rounding point of every block: w_expand / w_dw / w_project follow "w"
+        self.bt: Dict[int, Dict[str, str]] = {}
+        for b in self.blocks:
+            t = {pt: rounding(b.stage, pt) for pt in ROUND_POINTS}
+            t["w_expand"] = t["w_dw"] = t["w_project"] = t["w"]
+            if mixed and b.stage == self.F16_FROM and b.stride == 2:
+                # the block that enters the fp16 stages reads the bf16 stream: bf16 expand conv (weights and output) and
+                # bf16 depthwise taps; from the depthwise output on it is fp16
+                t["w_expand"] = t["expand"] = t["w_dw"] = "bf16"
+            self.bt[b.idx] = t
         self.w: Dict[str, torch.Tensor] = {}
         for k, v in state.items():
             self.w[k] = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
@@ -153,13 +201,17 @@ class EffNetV2LOracle:
             if k.endswith(".w") and k.startswith("bbone.") and ".dw." not in k and ".se." not in k:
                 p = k[:-2]
                 w = self.w[k] * self.w[p + ".scale"].view(-1, 1, 1, 1)      # [cout,kh,kw,cin]
-                if p != "bbone.stem":
-                    w = _r(w, mode)
+                if p == "bbone.head":
+                    w = _r(w, rounding(7, "w"))
+                elif p != "bbone.stem":
+                    blk, leaf = p.rsplit(".", 1)
+                    w = _r(w, self.bt[int(blk.split(".b")[1])]["w_" + leaf])
                 self.cw[p] = w.permute(0, 3, 1, 2).contiguous()             # -> OIHW
         for b in self.blocks:
             if b.kind == "mb":
                 p = f"bbone.b{b.idx}.dw"
-                self.cw[p] = _r(self.w[p + ".w"] * self.w[p + ".scale"].view(-1, 1, 1), mode).unsqueeze(1)  # [c,1,3,3], bf16-rounded taps
+                self.cw[p] = _r(self.w[p + ".w"] * self.w[p + ".scale"].view(-1, 1, 1),
+                                self.bt[b.idx]["w_dw"]).unsqueeze(1)        # [c,1,3,3], rounded taps
 
     def _conv(self, x, p, k, stride, act, out_f32=False):
         w = self.cw[p]
@@ -178,37 +230,42 @@ class EffNetV2LOracle:
 
     def backbone(self, crops_nhwc: np.ndarray, taps: Optional[dict] = None) -> np.ndarray:
         """crops [B,256,256,3] f32 in [0,1] -> features [B,8,8,1280] f32."""
-        m = self.mode
+        rd = self.rounding
         x = torch.from_numpy(np.ascontiguousarray(crops_nhwc, dtype=np.float32)).permute(0, 3, 1, 2)
         with torch.no_grad():
-            x = _r(self._conv(x, "bbone.stem", 3, 2, True), m)              # stem runs in f32 on f32 crops
+            x = _r(self._conv(x, "bbone.stem", 3, 2, True), rd(-1, "out"))  # stem runs in f32 on f32 crops
             if taps is not None:
                 taps["stem"] = x.permute(0, 2, 3, 1).numpy().copy()
+            skip = x          # the residual stream; equals x unless it is kept in f32 beside a bf16 copy
             for b in self.blocks:
                 p = f"bbone.b{b.idx}"
-                inp = x
+                bt = self.bt[b.idx]
                 if b.kind == "fused":
                     if b.cexp == b.cin:
                         y = self._conv(x, p + ".expand", 3, b.stride, True)
                     else:
-                        h = _r(self._conv(x, p + ".expand", 3, b.stride, True), m)
+                        h = _r(self._conv(x, p + ".expand", 3, b.stride, True), bt["expand"])
                         y = self._conv(h, p + ".project", 1, 1, False)
                 else:
-                    h = _r(self._conv(x, p + ".expand", 1, 1, True), m)
+                    h = _r(self._conv(x, p + ".expand", 1, 1, True), bt["expand"])
                     wd = self.cw[p + ".dw"]
                     if b.stride == 2:
                         d = F.conv2d(F.pad(h, (0, 1, 0, 1)), wd, stride=2, groups=b.cexp)
                     else:
                         d = F.conv2d(h, wd, padding=1, groups=b.cexp)
-                    d = _r(_silu(d + self.w[p + ".dw.shift"].view(1, -1, 1, 1)), m)
+                    d = _r(_silu(d + self.w[p + ".dw.shift"].view(1, -1, 1, 1)), bt["dw"])
                     s = d.mean(dim=(2, 3))                                                    # [B,c] f32
                     s = _silu(s @ self.w[p + ".se.w1"].T + self.w[p + ".se.b1"])
                     g = torch.sigmoid(s @ self.w[p + ".se.w2"].T + self.w[p + ".se.b2"])      # [B,c]
-                    h2 = _r(d * g.view(g.shape[0], -1, 1, 1), m)
+                    h2 = _r(d * g.view(g.shape[0], -1, 1, 1), bt["gate"])
                     y = self._conv(h2, p + ".project", 1, 1, False)
                 if b.residual:
-                    y = y + inp
-                x = _r(y, m)
+                    y = y + skip
+                if bt["out"] == "f32+bf16copy":
+                    skip = y                                   # f32 residual stream ...
+                    x = _r(y, "bf16")                          # ... and the bf16 copy the next block's convs read
+                else:
+                    x = skip = _r(y, bt["out"])
                 if taps is not None and (b.idx in taps.get("_want", ()) or taps.get("_all")):
                     taps[f"b{b.idx}"] = x.permute(0, 2, 3, 1).numpy().copy()
             x = self._conv(x, "bbone.head", 1, 1, True)                     # stored f32

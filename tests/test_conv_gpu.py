@@ -357,3 +357,94 @@ def test_pipelined_expand_at_full_size(H, Cin, Cout, variant):
     assert np.array_equal(out, tile)
     auto, _ = conv_debug(x, w, scale, shift, 1, 1, 1, None, None, variant=0)     # what the network launches for this layer
     assert np.array_equal(auto, tile)
+
+
+def _ref_f16(x, w, scale, shift, act, res, gate):
+    """torch-CPU reference of a 1x1 convolution on fp16-rounded operands (ConvArgs.f16)"""
+    xb = torch.from_numpy(x).half().float()
+    if gate is not None:
+        xb = (xb * torch.from_numpy(gate)[:, None, None, :]).half().float()
+    wf = (torch.from_numpy(w) * torch.from_numpy(scale).view(-1, 1, 1, 1)).half().float()[:, 0, 0, :]
+    y = xb.double() @ wf.double().T + torch.from_numpy(shift).double()
+    if act:
+        y = y * torch.sigmoid(y)
+    if res is not None:
+        y = y + torch.from_numpy(res).half().double()
+    return y.numpy()
+
+
+F16_CASES = [
+    # B, H, Cin, Cout, act, res, gate          the shapes of the two 8x8 stages + the 640 -> 1280 convolution
+    (40, 8, 384, 2304, 1, False, False),       # expand (weights-stationary 185 at this M, tile kernel 131 as an explicit variant)
+    (3, 8, 640, 3840, 1, False, False),        # expand, small M
+    (5, 8, 2304, 384, 0, True, True),          # SE-gated projection with residual
+    (4, 8, 3840, 640, 0, True, True),
+    (2, 8, 1344, 384, 0, False, True),         # the projection of the block that enters the fp16 stages
+    (3, 8, 640, 1280, 1, False, False),        # 640 -> 1280 (the product stores f32 there; the bf16/fp16 store path is checked here)
+    (1, 8, 2304, 384, 0, True, True),          # one frame
+]
+
+
+@pytest.mark.parametrize("variant", [0, 131, 132, 138, 141, 144, 146, 147, 185, 186, 3147, 2138])
+@pytest.mark.parametrize("case", F16_CASES)
+def test_conv_f16_operands(case, variant):
+    """fp16 operands (ConvArgs.f16, isb_hpe_cfg.precision 0: the 8x8 stages): x / weights / residual / output in IEEE
+    fp16, f32 accumulate -- against an f64 reference on the same fp16-rounded operands; both sides round to fp16 once."""
+    from isbfsar_amd.hpe_engine import f16_to_f32, f32_to_f16
+    B, H, Cin, Cout, act, use_res, use_gate = case
+    tv = variant % 1000
+    if tv in (131, 132, 138, 185, 186) and use_gate:
+        pytest.skip("un-gated kernels")
+    if tv in (141, 144, 146, 147) and not use_gate:
+        pytest.skip("gated kernels")
+    if tv in (185, 186) and (Cin != 384 or not act):
+        pytest.skip("weights-stationary fp16 form: K = 384 with SiLU")
+    if tv == 144 and Cout % 320 != 0:
+        pytest.skip("128 x 320 tiles")
+    if variant >= 2000 and (use_res is False and act):
+        pass
+    rng = np.random.default_rng(hash((case, 13)) % (2 ** 31))
+    x = rng.normal(0, 1, (B, H, H, Cin)).astype(np.float32)
+    w = (rng.normal(0, 1, (Cout, 1, 1, Cin)) / np.sqrt(Cin)).astype(np.float32)
+    scale = rng.uniform(0.8, 1.2, Cout).astype(np.float32)
+    shift = rng.uniform(-0.1, 0.1, Cout).astype(np.float32)
+    res = rng.normal(0, 1, (B, H, H, Cout)).astype(np.float32) if use_res else None
+    gate = rng.uniform(0.1, 0.9, (B, Cin)).astype(np.float32) if use_gate else None
+    out, ms = conv_debug(f32_to_f16(x), w, scale, shift, 1, 1, act, None if res is None else f32_to_f16(res), gate,
+                         variant=variant, f16=True)
+    got = f16_to_f32(out).astype(np.float64)
+    ref = _ref_f16(x, w, scale, shift, act, res, gate)
+    assert np.isfinite(got).all()
+    # one fp16 rounding (2^-11 relative) + f32 accumulation order over K <= 3840
+    tol = 2.0 ** -10 * np.maximum(0.25, np.abs(ref)) + 1e-4
+    assert np.all(np.abs(got - ref) <= tol), float(np.abs(got - ref).max())
+
+
+@pytest.mark.parametrize("form", [(1, True, True), (2, False, True)])
+def test_dwconv_f16_forms(form):
+    """depthwise 3x3 + SiLU + pool in the fp16 forms (DwArgs.in_f16 / out_f16): stride 1 fp16 -> fp16 (inside the fp16
+    stages) and stride 2 bf16 -> fp16 (the block that enters them), against torch on the same rounded operands."""
+    from isbfsar_amd.hpe_engine import dwconv_debug, f16_to_f32, f32_to_f16
+    stride, in_f16, out_f16 = form
+    B, H, Cc = 3, 8 * stride, 2304 if stride == 1 else 1344
+    rng = np.random.default_rng(17 + stride)
+    x = rng.normal(0, 1, (B, H, H, Cc)).astype(np.float32)
+    w = (rng.normal(0, 1, (Cc, 3, 3)) / 3.0).astype(np.float32)
+    scale = rng.uniform(0.8, 1.2, Cc).astype(np.float32)
+    shift = rng.uniform(-0.1, 0.1, Cc).astype(np.float32)
+    xin = f32_to_f16(x) if in_f16 else f32_to_bf16(x)
+    out, pooled, _ = dwconv_debug(xin, w, scale, shift, stride=stride, in_f16=in_f16, out_f16=out_f16)
+    xr = torch.from_numpy(f16_to_f32(xin) if in_f16 else bf16_to_f32(xin)).permute(0, 3, 1, 2)
+    wf = torch.from_numpy(w) * torch.from_numpy(scale).view(-1, 1, 1)
+    wf = (wf.half() if in_f16 else wf.bfloat16()).float().unsqueeze(1)
+    if stride == 2:
+        y = F.conv2d(F.pad(xr, (0, 1, 0, 1)), wf, stride=2, groups=Cc)
+    else:
+        y = F.conv2d(xr, wf, padding=1, groups=Cc)
+    y = y + torch.from_numpy(shift).view(1, -1, 1, 1)
+    y = (y * torch.sigmoid(y)).permute(0, 2, 3, 1)
+    ref = y.half().float().numpy()
+    got = f16_to_f32(out)
+    tol = 2.0 ** -10 * np.maximum(0.25, np.abs(ref))
+    assert np.all(np.abs(got - ref) <= tol), float(np.abs(got - ref).max())
+    np.testing.assert_allclose(pooled, got.reshape(B, -1, Cc).mean(axis=1), rtol=0, atol=2e-5)   # the pool sees the stored values

@@ -66,10 +66,15 @@ def _abs_amplification(lg, nk, r, W, idx, eps=1e-4, trials=6, seed=0):
     return amp
 
 
-def _check_pose(joints_gpu, lg_gpu, lg_ref, nk, r, W, idx, tag=""):
-    """3D joints against the oracle: the decoded predictions (pred3d in heatmap units, pred2d / 255) and the root-centred
-    pose -- what the AR stage consumes, main.py:103 -- at the north star's 1e-3; the ABSOLUTE pose at 1e-3 too wherever
-    the reconstruction is conditioned for it, else at (its own amplification at this input) x (the prediction error)."""
+def _check_pose(joints_gpu, lg_gpu, lg_ref, nk, r, W, idx, tag="", lg_f32=None, flat_abs=True):
+    """3D joints against the oracle (bf16-faithful mode = the product's storage points): the decoded predictions (pred3d
+    in heatmap units, pred2d / 255) and the root-centred pose -- what the AR stage consumes, main.py:103 -- at the north
+    star's 1e-3, and the ABSOLUTE pose (what estimate() returns, hpe.py:171) at a flat 1e-3 too (flat_abs; default
+    precision: fp16 in the two 8x8 stages). flat_abs=False (the chaotic "signal" weights, the plain-bf16
+    precision): 1e-3 wherever the reconstruction is conditioned for it, else (its own amplification at this input) x (the
+    prediction error), under a FIXED ceiling of 4e-3 so that a regression cannot hide behind its own error.
+    lg_f32: logits of the fp32 oracle for the same crop -> the absolute pose must also sit within 1e-3 of the fp32
+    definition (BASELINE north star; error budget in DESIGN.md section 4)."""
     from oracle import hpe_oracle as ho
     ref = ho.postprocess(lg_ref, nk, r, W, idx)
     assert ref is not None
@@ -80,10 +85,22 @@ def _check_pose(joints_gpu, lg_gpu, lg_ref, nk, r, W, idx, tag=""):
     e_rc = float(np.abs((joints_gpu - joints_gpu[0]) - (ref - ref[0])).max())
     e_abs = float(np.abs(joints_gpu - ref).max())
     amp = _abs_amplification(lg_ref, nk, r, W, idx)
-    print(f"pose{tag}: |d pred|={e_pred:.2e} |d root-centred|={e_rc:.2e} |d absolute|={e_abs:.2e} (reconstruction gain {amp:.1f})")
+    msg = f"pose{tag}: |d pred|={e_pred:.2e} (2D {e_p2:.3f} px) |d root-centred|={e_rc:.2e} |d absolute|={e_abs:.2e} (reconstruction gain {amp:.1f})"
+    e_f32 = None
+    if lg_f32 is not None:
+        ref32 = ho.postprocess(lg_f32, nk, r, W, idx)
+        assert ref32 is not None
+        e_f32 = float(np.abs(joints_gpu - ref32).max())
+        msg += f" |d absolute vs fp32 definition|={e_f32:.2e}"
+    print(msg)
     assert e_p3 < 1e-3 and e_rc < 1e-3          # north star: 3D joints within 1e-3 (heatmap units / root-centred pose)
-    assert e_p2 < 0.5                           # the 2D heat-map coordinate, in pixels of the 256 x 256 crop
-    assert e_abs < max(1e-3, 1.5 * amp * e_pred), (e_abs, amp, e_pred)
+    assert e_p2 < (0.1 if flat_abs else 0.5)    # the 2D heat-map coordinate, in pixels of the 256 x 256 crop (observed: a few 1e-2)
+    if flat_abs:
+        assert e_abs < 1e-3, (e_abs, amp, e_pred)
+    else:
+        assert e_abs < min(max(1e-3, 1.5 * amp * e_pred), 4e-3), (e_abs, amp, e_pred)
+    if e_f32 is not None:
+        assert e_f32 < 1e-3, e_f32
     return e_abs
 
 
@@ -305,7 +322,7 @@ def test_backbone_signal_profile_vs_oracle(eng, assets):
             ref = ho.postprocess(l16[b:b + 1], nk, r, W, st["smpl+head_30"]["indices"])
             assert bool(valid[b]) == (ref is not None)
             if ref is not None:
-                _check_pose(joints[b], logits[b:b + 1], l16[b:b + 1], nk, r, W, st["smpl+head_30"]["indices"], tag=f" signal frame {b}")
+                _check_pose(joints[b], logits[b:b + 1], l16[b:b + 1], nk, r, W, st["smpl+head_30"]["indices"], tag=f" signal frame {b}", flat_abs=False)
     finally:
         eng.load_weights(effnetv2.make_state(0))            # the module-scoped engine goes back to the default weights
 
@@ -321,6 +338,7 @@ def test_forward_end_to_end_vs_oracle(eng_w, bbone_state, assets):
     bb = synth.bboxes(B, seed=20)
     joints, valid = eng_w.forward(fr, bb)
     o16 = EffNetV2LOracle(bbone_state, "bf16")
+    o32 = EffNetV2LOracle(bbone_state, "f32")
     crops = np.stack([ho.warp(fr[b], ho.crop_params(bb[b], _K())[2][0]) for b in range(B)])
     _, lg_gpu = eng_w.backbone(crops)
     for b in range(B):
@@ -329,12 +347,76 @@ def test_forward_end_to_end_vs_oracle(eng_w, bbone_state, assets):
         ref = ho.postprocess(lg, nk, r, W, idx)
         assert bool(valid[b]) == (ref is not None)
         if ref is not None:
-            _check_pose(joints[b], lg_gpu[b:b + 1], lg, nk, r, W, idx, tag=f" frame {b}")
+            _check_pose(joints[b], lg_gpu[b:b + 1], lg, nk, r, W, idx, tag=f" frame {b}",
+                        lg_f32=o32.head(o32.backbone(crops[b:b + 1])))
     # micro-batching (max_batch=8 here) and the device-pointer path give identical results
     import torch
     j2, v2 = eng_w.forward(torch.from_numpy(fr).cuda(), torch.from_numpy(bb).cuda())
     torch.cuda.synchronize()
     assert np.array_equal(j2.cpu().numpy(), joints) and np.array_equal(v2.cpu().numpy(), valid)
+
+
+def test_absolute_pose_within_1e3_of_fp32_definition(bbone_state, assets):
+    """estimate() RETURNS the absolute pose (hpe.py:171; main.py:102 takes its distance), so it has to
+    sit within the north star's 1e-3 of the fp32 path too, not only of the bf16-faithful oracle. 16 frames (the first 8
+    are the frames bench.py's parity object uses), default weights: default precision (bf16, fp16 in the two 8x8 stages
+    and the 640 -> 1280 convolution) against the fp32 oracle at a flat 1e-3; the plain-bf16 precision is run beside it and must be the worse one
+    (its own distance to fp32 is a property of bf16 storage: oracle/error_budget.py)."""
+    from isbfsar_amd.hpe_engine import HpeEngine
+    from oracle import hpe_oracle as ho
+    from oracle.effnetv2_oracle import EffNetV2LOracle
+    W, st = assets
+    idx = st["smpl+head_30"]["indices"]
+    B = 16
+    fr, bb = synth.frames(B, seed=0), synth.bboxes(B, seed=0)
+    crops = np.stack([ho.warp(fr[b], ho.crop_params(bb[b], _K())[2][0]) for b in range(B)])
+    o32 = EffNetV2LOracle(bbone_state, "f32")
+    l32 = o32.head(o32.backbone(crops))
+    errs = {}
+    for prec in ("bf16_f16tail", "bf16"):
+        e = HpeEngine(device=0, max_batch=16, precision=prec)
+        try:
+            e.set_joint_map(W, idx)
+            e.load_weights(bbone_state)
+            joints, valid = e.forward(fr, bb)
+        finally:
+            e.close()
+        d = []
+        for b in range(B):
+            nk, r, _ = ho.crop_params(bb[b], _K())
+            ref = ho.postprocess(l32[b:b + 1], nk, r, W, idx)
+            assert ref is not None and valid[b] == 1
+            d.append(float(np.abs(joints[b] - ref).max()))
+        errs[prec] = np.array(d)
+        print(f"absolute pose vs fp32 definition, precision {prec}: median {np.median(d):.2e} max {max(d):.2e}")
+    assert errs["bf16_f16tail"].max() < 1e-3
+    assert np.median(errs["bf16_f16tail"]) < np.median(errs["bf16"])
+
+
+def test_plain_bf16_precision_vs_its_oracle(bbone_state, assets):
+    """isb_hpe_cfg.precision = 1 (bf16 everywhere, the round-2 layout) against the oracle's matching mode."""
+    from isbfsar_amd.hpe_engine import HpeEngine
+    from oracle import hpe_oracle as ho
+    from oracle.effnetv2_oracle import EffNetV2LOracle
+    W, st = assets
+    idx = st["smpl+head_30"]["indices"]
+    B = 3
+    fr, bb = synth.frames(B, seed=21), synth.bboxes(B, seed=21)
+    crops = np.stack([ho.warp(fr[b], ho.crop_params(bb[b], _K())[2][0]) for b in range(B)])
+    o16 = EffNetV2LOracle(bbone_state, "bf16_plain")
+    e = HpeEngine(device=0, max_batch=8, precision="bf16")
+    try:
+        e.set_joint_map(W, idx)
+        e.load_weights(bbone_state)
+        joints, valid = e.forward(fr, bb)
+        _, lg_gpu = e.backbone(crops)
+    finally:
+        e.close()
+    for b in range(B):
+        nk, r, _ = ho.crop_params(bb[b], _K())
+        lg = o16.head(o16.backbone(crops[b:b + 1]))
+        assert valid[b] == 1
+        _check_pose(joints[b], lg_gpu[b:b + 1], lg, nk, r, W, idx, tag=f" plain bf16 frame {b}", flat_abs=False)
 
 
 def test_select_person_matches_reference(eng, g):
