@@ -23,6 +23,16 @@ MFMA_PEAK_TFLOPS_BF16 = 2500.0     # MI355X_MICROARCH.md, dense
 _ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "isbfsar_amd", "assets")
 
 
+def make_gather(args, world, dev):
+    """(RecordGather | None, force): N > 1 on RCCL -> the library-owned communicator (isb_dist_*); the gloo rehearsal on a
+    one-GPU box keeps torch.distributed as the test double. force = the one-rank rehearsal of the N > 1 branch."""
+    force = bool(getattr(args, "force_dist", False))
+    if world > 1 and getattr(args, "dist_backend", "nccl") == "nccl" and os.environ.get("ISB_BENCH_TORCH_GATHER") != "1":
+        from isbfsar_amd.dist import RecordGather
+        return RecordGather(dev), force
+    return None, force
+
+
 def usable_cores() -> int:
     """CPU threads this process may actually use (affinity mask and cgroup quota), not the host's."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -234,6 +244,7 @@ class PipelineWorkload(_HpeBase):
         # that carries over lives on the first stream). On one GPU the same arrangement changes nothing (measured:
         # the two pose lanes already fill the chip), so N = 1 runs the stages back to back.
         self.side = torch.cuda.Stream(device=dev) if world > 1 and os.environ.get("ISB_BENCH_OVERLAP", "1") != "0" else None
+        self.gather, self.force = make_gather(args, world, dev)
 
     def units_per_step(self):
         return self.B
@@ -259,12 +270,52 @@ class PipelineWorkload(_HpeBase):
         logits, is_true, embed = self.ar.infer(windows, want_embed=self.world > 1)
         if self.world > 1:
             # ONE all-gather of the packed per-window records over RCCL/xGMI
-            self.out = all_gather_records(pack_records(logits, is_true, embed))
+            self.out = all_gather_records(pack_records(logits, is_true, embed), force=self.force, gather=self.gather)
         else:
             self.out = (logits, is_true)
 
     def roofline(self, steps):
         return self._hpe_roofline(steps)
+
+    def _timed(self, steps, warm=2):
+        torch = self.torch
+        for _ in range(warm):
+            self.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    def extras(self, args):
+        """Measured in the same run as the headline, reported inside `config` (N = 1 only):
+          * value_bf16x3 -- the pipeline with the AR attention at its fp32-grade precision (hi + lo split, 3 MFMAs per
+            product; the reference's TRXOS is fp32);
+          * whole_batch_2048 -- BASELINE configs[3]'s WHOLE batch (2048 frames -> 2048 windows) on this one GPU."""
+        out = {}
+        if self.ar_precision != "bf16x3":
+            ar0 = self.ar
+            self.ar = ArEngine(self.L, self.J, self.way, device=self.dev, precision="bf16x3", max_batch=self.B)
+            self.ar.load_weights(self.ar_state)
+            self.ar.set_support(poses=self.ss)
+            dt = self._timed(max(3, min(args.steps, 10)))
+            out["value_bf16x3"] = round(self.B / dt, 3)
+            out["ms_per_step_bf16x3"] = round(dt * 1e3, 4)
+            self.ar.close() if hasattr(self.ar, "close") else None
+            self.ar = ar0
+        if self.B == 256 and not args.batch:
+            import copy
+            a2 = copy.copy(args)
+            a2.batch = 2048
+            big = PipelineWorkload(a2, 0, 1, self.dev)
+            dt = big._timed(5, warm=3)
+            out["whole_batch_2048"] = {"value": round(2048 / dt, 3), "unit": self.unit, "ms_per_step": round(dt * 1e3, 4), "steps": 5,
+                                       "note": "configs[3]'s whole batch on one GPU: 8 cameras x 256 steps -> 2048 windows, pose "
+                                               "micro-batches of up to 1024 frames"}
+            del big
+            self.torch.cuda.empty_cache()
+        return out
 
     def cpu_baseline(self, sample, iters=10):
         from oracle.ar_oracle import TRXOSOracle
@@ -289,8 +340,10 @@ class PipelineWorkload(_HpeBase):
                             f"({self.N_CAM} cameras x {self.steps_per_cam} steps) -> HPE (EfficientNetV2-L bf16, 122 joints) -> "
                             f"30-frame windows -> AR (way={self.way}) -> open-set score",
                 "per_gpu_batch": self.B, "seq_len": self.L, "n_joints": self.J, "way": self.way,
-                "ar_precision": self.ar_precision,
+                "ar_precision": self.ar_precision, "hpe_precision": self.hpe.precision + " (bf16 storage; fp16 in the two 8x8 stages "
+                "and the 640->1280 conv; f32 accumulate, f32 head / decode, f64 reconstruction)" if self.hpe.precision == "bf16_f16tail" else self.hpe.precision,
                 "parallelism": f"dp{world} (frames sharded; one all-gather of per-window records"
+                               + (": RCCL behind the C ABI (isb_dist_all_gather)" if self.gather is not None else "")
                                + (", on a second stream beside the next step's pose stage)" if self.side is not None else ")")}
 
 
@@ -318,6 +371,12 @@ class StreamWorkload(_HpeBase):
         self.ring = torch.from_numpy(hist).cuda(dev).contiguous()
         self.graph = None
         self.out = None
+        # N > 1: every rank ends a step holding every feed's [probabilities-to-be | open-set score] record; the all-gather
+        # (RCCL behind the C ABI) is part of the captured step
+        self.gather, self.force = make_gather(args, world, dev)
+        self.gathered = None
+        if self.gather is not None:
+            self.gathered = torch.empty((self.gather.world, self.way + 1), dtype=torch.float32, device=f"cuda:{dev}")
         # warm-up outside capture (workspaces are allocated on first use), then capture one step
         for _ in range(2):
             self._step_eager()
@@ -342,7 +401,11 @@ class StreamWorkload(_HpeBase):
         self.ring.copy_(self.torch.cat([self.ring[:, 1:], joints.view(1, 1, self.J, 3)], dim=1))
         windows = pose_windows(self.ring, self.L)                                 # [1,L,3J]
         logits, is_true, _ = self.ar.infer(windows)
-        self.out = (logits, is_true, valid)
+        if self.gather is not None:
+            self.gather.all_gather_into(pack_records(logits, is_true), self.gathered)
+            self.out = (self.gathered, valid)
+        else:
+            self.out = (logits, is_true, valid)
 
     def units_per_step(self):
         return 1
@@ -383,7 +446,9 @@ class StreamWorkload(_HpeBase):
         return {"workload": "BASELINE configs[4]: 1 camera feed per GPU, per-frame step = HPE (1 frame, 122 joints) + AR on the "
                             f"sliding 30-frame window, way={self.way}, hipGraph-captured={self.graph is not None}",
                 "per_gpu_batch": 1, "seq_len": self.L, "n_joints": self.J, "way": self.way,
-                "parallelism": f"dp{world} (one feed per GPU, no collective)"}
+                "parallelism": f"dp{world} (one feed per GPU"
+                               + (", all-gather of the per-feed records inside the captured step: isb_dist_all_gather)" if self.gather is not None
+                                  else ", no collective)")}
 
 
 class DetWorkload:

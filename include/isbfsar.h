@@ -295,6 +295,28 @@ int isb_pose_windows(const float* d_joints, int32_t n_cam, int32_t n_frames, int
  *   d_joints [n, J, 3] f32 (absolute joints as isb_hpe_forward writes them)    d_distance [n] f32 */
 int isb_pose_distance(const float* d_joints, int32_t n, int32_t J, float* d_distance, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Multi-GPU: one process per GPU, frames / windows sharded across ranks with no data-path collective
+ * (the reference has no multi-GPU path; its units are independent: SURVEY.md 8e). The ONE exchange is an
+ * all-gather of the packed per-window records [logits(n) | is_true(1) | embed(L*256, optional)] so that
+ * every rank holds every window's result. The library owns the RCCL communicator (SURVEY.md 8b
+ * ownership); the collective is issued on the caller's stream and may be captured in a hipGraph together
+ * with the step that produces the records (BASELINE configs[4]).
+ *   rank 0: isb_dist_unique_id(id); ship the 128 bytes to the other ranks by any channel (the drop-in uses
+ *   the launcher's torch.distributed group); every rank: isb_dist_create(id, rank, world, device, &h).
+ * isb_dist_create is collective (ncclCommInitRank). RCCL is bound with dlopen when first needed: without
+ * librccl.so these entry points return ISB_ERR_STATE and nothing else in the library is affected. */
+typedef struct isb_dist isb_dist;
+#define ISB_DIST_ID_BYTES 128
+int isb_dist_unique_id(void* h_id_out /* ISB_DIST_ID_BYTES */);
+int isb_dist_create(const void* h_unique_id, int32_t rank, int32_t world, int32_t device, isb_dist** out);
+void isb_dist_destroy(isb_dist* d);
+int isb_dist_info(const isb_dist* d, int32_t* rank, int32_t* world);
+/* d_recv[r * bytes_per_rank .. ] = rank r's d_send[0 .. bytes_per_rank) for every r; asynchronous on `stream`
+ * (ncclAllGather over xGMI). Equal block sizes on every rank (ragged shards: pad to the largest, as the
+ * host-side helper isbfsar_amd/dist.py does). d_send may alias its own slot of d_recv. */
+int isb_dist_all_gather(isb_dist* d, const void* d_send, void* d_recv, size_t bytes_per_rank, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,7 +28,7 @@ SOURCES = [
     "ar_api.cpp",
 ]
 # optional units appear as they are written
-for _extra in ("hpe_kernels.hip", "conv_kernels.hip", "conv_ws.hip", "hpe_api.cpp", "det_kernels.hip", "det_api.cpp"):
+for _extra in ("hpe_kernels.hip", "conv_kernels.hip", "conv_ws.hip", "hpe_api.cpp", "det_kernels.hip", "det_api.cpp", "dist_api.cpp"):
     if os.path.exists(os.path.join(CSRC, _extra)):
         SOURCES.append(_extra)
 
@@ -154,7 +154,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         # then compile the verdict in. isb_wsreg_verified() == 0 makes conv_kernels.hip fall back to the tile kernels.
         def guard(ok: int):
             run([hipcc, "-O2", "-std=c++17", "-fPIC", f"-DISB_WSREG_VERIFIED={ok}", "-c", os.path.join(CSRC, GUARD_SRC), "-o", guard_o])
-            run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", *objs, guard_o, "-o", LIB])
+            run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", *objs, guard_o, "-ldl", "-o", LIB])
         guard(0)
         why = wspipe_registers_private(LIB)
         if why is None:

@@ -51,6 +51,10 @@ struct isb_det {
     int t_image = -1;
     int ws_B = 0;
     DevBuf zeros;
+    // host-buffer entry points: grow-only staging (frames in, boxes / confidences out) so that the per-frame live loop
+    // (HumanPoseEstimator calls isb_det_forward_host once per frame) makes no hipMalloc / hipFree -- hipFree synchronises
+    DevBuf hs_frames, hs_boxes, hs_confs;
+    int hs_B = 0;
 };
 
 namespace {
@@ -230,6 +234,21 @@ int run(isb_det* d, hipStream_t st, const uint8_t* d_frames, int B, float* d_box
 
 }  // namespace
 
+extern "C" void isb_det_destroy(isb_det* d);
+
+namespace {
+int ensure_host_staging(isb_det* d, int B) {
+    if (B <= d->hs_B) return ISB_OK;
+    const size_t fsz = (size_t)d->cfg.height * d->cfg.width * 3;
+    d->hs_B = 0;                                  // failure-atomic: re-allocated on the next call
+    ISB_TRY(d->hs_frames.alloc(fsz * B));
+    ISB_TRY(d->hs_boxes.alloc((size_t)B * kNBoxes * 16));
+    ISB_TRY(d->hs_confs.alloc((size_t)B * kNBoxes * kNCls * 4));
+    d->hs_B = B;
+    return ISB_OK;
+}
+}  // namespace
+
 extern "C" int isb_det_create(const isb_det_cfg* cfg, isb_det** out) {
     return isb::guard([&]() -> int {
     ISB_REQUIRE(cfg && out, ISB_ERR_INVALID, "isb_det_create: null argument");
@@ -239,7 +258,8 @@ extern "C" int isb_det_create(const isb_det_cfg* cfg, isb_det** out) {
     ISB_HIP(hipGetDeviceCount(&ndev));
     ISB_REQUIRE(cfg->device >= 0 && cfg->device < ndev, ISB_ERR_INVALID, "device %d not in [0,%d)", cfg->device, ndev);
     ISB_HIP(hipSetDevice(cfg->device));
-    std::unique_ptr<isb_det> d(new (std::nothrow) isb_det());
+    // a failure after the stream exists must destroy it too: release through isb_det_destroy, not a plain delete
+    std::unique_ptr<isb_det, void (*)(isb_det*)> d(new (std::nothrow) isb_det(), isb_det_destroy);
     ISB_REQUIRE(d, ISB_ERR_NOMEM, "out of host memory");
     d->cfg = *cfg;
     if (d->cfg.max_batch <= 0) d->cfg.max_batch = 16;
@@ -362,10 +382,8 @@ extern "C" int isb_det_forward_host(isb_det* d, const uint8_t* frames, int32_t B
     ISB_HIP(hipSetDevice(d->cfg.device));
     hipStream_t st = d->own_stream;
     const size_t fsz = (size_t)d->cfg.height * d->cfg.width * 3;
-    DevBuf df, db, dc;
-    ISB_TRY(df.alloc(fsz * B));
-    ISB_TRY(db.alloc((size_t)B * kNBoxes * 16));
-    ISB_TRY(dc.alloc((size_t)B * kNBoxes * kNCls * 4));
+    ISB_TRY(ensure_host_staging(d, B));
+    DevBuf &df = d->hs_frames, &db = d->hs_boxes, &dc = d->hs_confs;
     ISB_HIP(hipMemcpyAsync(df.p, frames, fsz * B, hipMemcpyHostToDevice, st));
     ISB_TRY(isb_det_forward(d, df.as<uint8_t>(), B, db.as<float>(), dc.as<float>(), st));
     ISB_HIP(hipMemcpyAsync(boxes, db.p, (size_t)B * kNBoxes * 16, hipMemcpyDeviceToHost, st));
@@ -383,10 +401,8 @@ extern "C" int isb_det_debug_host(isb_det* d, const uint8_t* frames, int32_t B, 
     ISB_HIP(hipSetDevice(d->cfg.device));
     hipStream_t st = d->own_stream;
     const size_t fsz = (size_t)d->cfg.height * d->cfg.width * 3;
-    DevBuf df, db, dc;
-    ISB_TRY(df.alloc(fsz * B));
-    ISB_TRY(db.alloc((size_t)B * kNBoxes * 16));
-    ISB_TRY(dc.alloc((size_t)B * kNBoxes * kNCls * 4));
+    ISB_TRY(ensure_host_staging(d, B));
+    DevBuf &df = d->hs_frames, &db = d->hs_boxes, &dc = d->hs_confs;
     ISB_HIP(hipMemcpyAsync(df.p, frames, fsz * B, hipMemcpyHostToDevice, st));
     ISB_TRY(isb_det_forward(d, df.as<uint8_t>(), B, db.as<float>(), dc.as<float>(), st));
     ISB_HIP(hipStreamSynchronize(st));

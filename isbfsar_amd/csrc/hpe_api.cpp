@@ -36,6 +36,9 @@ struct BlockW {
 struct StageDef { bool fused; int repeats, expand, stride, cin, cout; bool se; };
 constexpr int kMinSplit = 64;     // a batch this large is run as concurrent parts (>= 32 frames each)
 constexpr int kMaxLanes = 4;
+constexpr int kMaxJoints = 122;   // joints per pose after expansion (assets/32_to_122.npy); isb_hpe_set_joint_map checks n_out against it
+constexpr int kRoiMinBatch = 2;   // isb_hpe_forward_host: ROI-only copies from this batch size on (one frame: the 9 KB round trip
+                                  // for the homography costs what the smaller copy saves)
 constexpr int kMaxMicroBatch = 1024;   // frames per micro-batch: keeps every activation tensor <= 2 GiB (32-bit byte offsets)
 const StageDef kStages[] = {
     {true, 4, 1, 1, 32, 32, false},   {true, 7, 4, 2, 32, 64, false},   {true, 7, 4, 2, 64, 96, false},
@@ -96,6 +99,13 @@ struct isb_hpe {
     hipEvent_t h2d_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     DevBuf hs_frames, hs_bbox, hs_joints, hs_valid;
     int hs_B = 0;
+    // ROI-only host input: the warp reads at most the crop square's pre-image, typically 150-480 KB of a 921 600-byte frame.
+    // isb_hpe_forward_host computes the crop homographies first (a 9 KB round trip), bounds each frame's source rectangle on
+    // the host and copies only that (hipMemcpy2DAsync into a packed image). ISB_HPE_ROI: 2 = rectangles (default),
+    // 1 = whole-width row bands (one contiguous copy per frame), 0 = whole frames.
+    int roi_mode = 2;
+    DevBuf hs_H, hs_newK, hs_R, hs_roi;
+    const RoiDesc* roi_dev = nullptr;   // set for the duration of one isb_hpe_forward_host call
     // profiling of conv_igemm launches
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
@@ -355,8 +365,9 @@ int run_crop_params(isb_hpe* h, Lane& L, hipStream_t st, const int32_t* d_bbox, 
     return launch_crop_params(a, st);
 }
 
-int run_warp(isb_hpe* h, Lane& L, hipStream_t st, const uint8_t* d_frames, int B) {
+int run_warp(isb_hpe* h, Lane& L, hipStream_t st, const uint8_t* d_frames, int B, const RoiDesc* roi = nullptr) {
     WarpArgs a{};
+    a.roi = roi;
     a.frames = d_frames; a.H = L.H.as<float>(); a.crops = L.crops.as<float>();
     a.n_aug = std::max(h->n_aug, 1);
     a.B = B * a.n_aug;                      // B frames -> B x n_aug crops
@@ -398,6 +409,7 @@ extern "C" int isb_hpe_create(const isb_hpe_cfg* cfg, isb_hpe** out) {
     if (const char* e = getenv("ISB_FUSE_BLOCK_CEXP")) h->fuse_block_max_cexp = atoi(e);
     if (cfg->precision == 1) h->f16_from = 7;
     if (const char* e = getenv("ISB_HPE_F16")) h->f16_from = atoi(e) == 0 ? 7 : 5;
+    if (const char* e = getenv("ISB_HPE_ROI")) h->roi_mode = std::max(0, std::min(2, atoi(e)));
     if (const char* e = getenv("ISB_HPE_LANES")) h->n_lanes = std::max(1, std::min(kMaxLanes, atoi(e)));
     ISB_HIP(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
     ISB_HIP(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
@@ -587,7 +599,8 @@ extern "C" int isb_hpe_forward(isb_hpe* h, const uint8_t* d_frames, const int32_
     auto run_lane = [&](Lane& L, hipStream_t s, int b0, int Bm) -> int {
         ISB_TRY(ensure_ws(L, Bm));
         ISB_TRY(run_crop_params(h, L, s, d_bbox + (size_t)b0 * 4, Bm));
-        ISB_TRY(run_warp(h, L, s, d_frames + (size_t)b0 * fsz, Bm));
+        if (h->roi_dev) ISB_TRY(run_warp(h, L, s, d_frames, Bm, h->roi_dev + b0));      // packed ROI image: offsets live in the descriptors
+        else ISB_TRY(run_warp(h, L, s, d_frames + (size_t)b0 * fsz, Bm));
         ISB_TRY(run_backbone(h, L, s, L.crops.as<float>(), Bm));
         return run_post(h, L, s, L.logits.as<float>(), Bm, d_joints + (size_t)b0 * h->n_out * 3, d_valid + b0, nullptr,
                         d_bbox + (size_t)b0 * 4);
@@ -633,7 +646,7 @@ extern "C" int isb_hpe_forward_host(isb_hpe* h, const uint8_t* frames, const int
         h->hs_B = 0;
         ISB_TRY(h->hs_frames.alloc(fsz * B));
         ISB_TRY(h->hs_bbox.alloc((size_t)B * 16));
-        ISB_TRY(h->hs_joints.alloc((size_t)B * 122 * 12));
+        ISB_TRY(h->hs_joints.alloc((size_t)B * kMaxJoints * 12));
         ISB_TRY(h->hs_valid.alloc((size_t)B));
         h->hs_B = B;
     }
@@ -641,12 +654,78 @@ extern "C" int isb_hpe_forward_host(isb_hpe* h, const uint8_t* frames, const int
     int32_t* db = h->hs_bbox.as<int32_t>();
     float* dj = h->hs_joints.as<float>();
     uint8_t* dv = h->hs_valid.as<uint8_t>();
+    ISB_HIP(hipMemcpyAsync(db, bbox, (size_t)B * 16, hipMemcpyHostToDevice, st));
+    const int FW = h->cfg.width, FH = h->cfg.height;
+    if (h->roi_mode > 0 && B >= kRoiMinBatch) {
+        // 1. the crop homographies of the whole batch (the kernel isb_hpe_forward runs again per lane: same inputs, same bits)
+        if (h->hs_H.bytes < (size_t)B * 36) {
+            ISB_TRY(h->hs_H.alloc((size_t)B * 36));
+            ISB_TRY(h->hs_newK.alloc((size_t)B * 72));
+            ISB_TRY(h->hs_R.alloc((size_t)B * 72));
+            ISB_TRY(h->hs_roi.alloc((size_t)B * sizeof(RoiDesc)));
+        }
+        CropParamArgs ca{};
+        ca.bbox = db;
+        for (int i = 0; i < 9; ++i) ca.K[i] = h->K[i];
+        ca.H = h->hs_H.as<float>(); ca.newK = h->hs_newK.as<double>(); ca.R = h->hs_R.as<double>(); ca.B = B;
+        ISB_TRY(launch_crop_params(ca, st));
+        std::vector<float> Hh((size_t)B * 9);
+        ISB_HIP(hipMemcpyAsync(Hh.data(), h->hs_H.p, (size_t)B * 36, hipMemcpyDeviceToHost, st));
+        ISB_HIP(hipStreamSynchronize(st));
+        // 2. per frame: the bounding rectangle of the crop square's image under H. The map is projective with a positive
+        // denominator over the square, so the square's image is the convex hull of its corners' images; + 2 px for the
+        // float32 evaluation and the truncation in the kernel. Degenerate H -> the whole frame.
+        std::vector<RoiDesc> roi(B);
+        uint64_t off = 0;
+        for (int b = 0; b < B; ++b) {
+            const float* Hb = Hh.data() + (size_t)b * 9;
+            double xlo = 1e30, xhi = -1e30, ylo = 1e30, yhi = -1e30;
+            bool ok = std::isfinite(Hb[8]) && Hb[8] != 0.f;
+            for (int c = 0; c < 4 && ok; ++c) {
+                const double x = (c & 1) ? 255.0 : 0.0, y = (c & 2) ? 255.0 : 0.0, h8 = Hb[8];
+                const double k = Hb[6] / h8 * x + Hb[7] / h8 * y + 1.0;
+                if (!(k > 1e-6)) { ok = false; break; }
+                const double xs = (Hb[0] / h8 * x + Hb[1] / h8 * y + Hb[2] / h8) / k;
+                const double ys = (Hb[3] / h8 * x + Hb[4] / h8 * y + Hb[5] / h8) / k;
+                if (!std::isfinite(xs) || !std::isfinite(ys)) { ok = false; break; }
+                xlo = std::min(xlo, xs); xhi = std::max(xhi, xs); ylo = std::min(ylo, ys); yhi = std::max(yhi, ys);
+            }
+            int x0 = 0, x1 = FW - 1, y0 = 0, y1 = FH - 1;
+            if (ok) {
+                x0 = (int)std::max(0.0, std::floor(std::min(xlo, 1e9)) - 2.0);
+                y0 = (int)std::max(0.0, std::floor(std::min(ylo, 1e9)) - 2.0);
+                x1 = (int)std::min((double)FW - 1.0, std::ceil(std::max(xhi, -1e9)) + 2.0);
+                y1 = (int)std::min((double)FH - 1.0, std::ceil(std::max(yhi, -1e9)) + 2.0);
+                if (h->roi_mode == 1) { x0 = 0; x1 = FW - 1; }           // whole-width row bands
+            }
+            RoiDesc& r = roi[b];
+            if (x1 < x0 || y1 < y0) { r.x0 = 0; r.y0 = 0; r.w = 0; r.h = 0; r.off = off; continue; }   // the crop misses the frame
+            r.x0 = x0; r.y0 = y0; r.w = x1 - x0 + 1; r.h = y1 - y0 + 1; r.off = off;
+            off += ((uint64_t)r.w * r.h * 3 + 15) & ~15ull;
+        }
+        ISB_REQUIRE(off <= h->hs_frames.bytes, ISB_ERR_INVALID, "internal: packed ROI image larger than the frame staging buffer");
+        // 3. the rectangles cross PCIe on the copy stream (row pitch of the source = a frame row)
+        for (int b = 0; b < B; ++b) {
+            const RoiDesc& r = roi[b];
+            if (r.w <= 0) continue;
+            const uint8_t* src = frames + (size_t)b * fsz + ((size_t)r.y0 * FW + r.x0) * 3;
+            if (r.w == FW) ISB_HIP(hipMemcpyAsync(df + r.off, src, (size_t)r.w * r.h * 3, hipMemcpyHostToDevice, h->copy_stream));
+            else ISB_HIP(hipMemcpy2DAsync(df + r.off, (size_t)r.w * 3, src, (size_t)FW * 3, (size_t)r.w * 3, r.h, hipMemcpyHostToDevice, h->copy_stream));
+        }
+        ISB_HIP(hipMemcpyAsync(h->hs_roi.p, roi.data(), (size_t)B * sizeof(RoiDesc), hipMemcpyHostToDevice, h->copy_stream));
+        ISB_HIP(hipEventRecord(h->h2d_ev[0], h->copy_stream));
+        ISB_HIP(hipStreamWaitEvent(st, h->h2d_ev[0], 0));
+        h->roi_dev = h->hs_roi.as<RoiDesc>();
+        const int rc = isb_hpe_forward(h, df, db, B, dj, dv, st);
+        h->roi_dev = nullptr;
+        if (rc != ISB_OK) return rc;
+        // `roi` and `Hh` must outlive the asynchronous copies that read them: the synchronise below covers it
+    } else {
     // up to four chunks of >= 256 frames: the frames of chunk i + 1 cross PCIe (copy stream) while chunk i computes. Smaller
     // batches go in one piece: measured at 256 frames, two chunks of 128 lose in launch efficiency (64-frame lanes) exactly what
     // the overlapped copy gains (23.6 ms either way, 18.0 with resident frames)
     const int n_chunks = std::max(1, std::min(4, B / 256));
     const int per = (B + n_chunks - 1) / n_chunks;
-    ISB_HIP(hipMemcpyAsync(db, bbox, (size_t)B * 16, hipMemcpyHostToDevice, st));
     for (int c = 0; c < n_chunks; ++c) {
         const int b0 = c * per, n = std::min(per, B - b0);
         if (n <= 0) break;
@@ -658,6 +737,7 @@ extern "C" int isb_hpe_forward_host(isb_hpe* h, const uint8_t* frames, const int
         if (n <= 0) break;
         ISB_HIP(hipStreamWaitEvent(st, h->h2d_ev[c], 0));
         ISB_TRY(isb_hpe_forward(h, df + (size_t)b0 * fsz, db + (size_t)b0 * 4, n, dj + (size_t)b0 * h->n_out * 3, dv + b0, st));
+    }
     }
     ISB_HIP(hipMemcpyAsync(joints, dj, (size_t)B * h->n_out * 12, hipMemcpyDeviceToHost, st));
     ISB_HIP(hipMemcpyAsync(valid, dv, (size_t)B, hipMemcpyDeviceToHost, st));

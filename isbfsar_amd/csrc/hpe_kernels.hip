@@ -125,10 +125,21 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs p) {
     const int xi = finite ? (int)xs : -1, yi = finite ? (int)ys : -1;
     float o0 = 0.f, o1 = 0.f, o2 = 0.f;
     if (xi >= 0 && xi < p.FW && yi >= 0 && yi < p.FH) {
-        const uint8_t* s = p.frames + (((size_t)fb * p.FH + yi) * p.FW + xi) * 3;
+        const uint8_t* s;
+        bool in = true;
+        if (p.roi) {
+            const RoiDesc rd = p.roi[fb];
+            const int xr = xi - rd.x0, yr = yi - rd.y0;
+            in = xr >= 0 && xr < rd.w && yr >= 0 && yr < rd.h;
+            s = p.frames + rd.off + ((size_t)(in ? yr : 0) * rd.w + (in ? xr : 0)) * 3;
+        } else {
+            s = p.frames + (((size_t)fb * p.FH + yi) * p.FW + xi) * 3;
+        }
+        if (in) {
         o0 = (float)((double)s[0] / 255.0);                // hpe.py:100 (int / 255.0 in f64, cast to f32)
         o1 = (float)((double)s[1] / 255.0);
         o2 = (float)((double)s[2] / 255.0);
+        }
     }
     float* d = p.crops + ((size_t)b * 65536 + pix) * 3;
     d[0] = o0; d[1] = o1; d[2] = o2;

@@ -229,12 +229,22 @@ struct CropParamArgs {
 };
 int launch_crop_params(const CropParamArgs& a, hipStream_t st);
 
+// ROI-only frames (isb_hpe_forward_host): only the source rectangle the crop's homography can reach was copied to the
+// device. Frame b's rectangle [x0, x0 + w) x [y0, y0 + h) sits packed (row pitch w * 3 bytes) at byte offset `off` of
+// WarpArgs.frames. Pixels inside the frame but outside the rectangle cannot be requested by construction (the rectangle
+// bounds the image of the crop square + 2 px); the kernel still treats them as out of range, never as an address.
+struct RoiDesc {
+    int32_t x0, y0, w, h;
+    uint64_t off;
+};
+
 struct WarpArgs {
     const uint8_t* frames;  // [B,FH,FW,3]
     const float* H;         // [B,9]
     float* crops;           // out [B,256,256,3] f32 in [0,1]
     int B, FH, FW;
     int n_aug;              // > 1: crop i is cut from frame i / n_aug (test-time augmentation)
+    const RoiDesc* roi;     // [B] or null: `frames` is the packed ROI image instead of whole frames
 };
 int launch_warp(const WarpArgs& a, hipStream_t st);
 

@@ -154,9 +154,66 @@ def gen_ar_stream(tag: str, L: int, J: int, way: int, n_frames: int, seed: int):
     print(f"ar_stream_{tag}: {len(probs)} calls, probs[0]={probs[0]}")
 
 
+def gen_ar_checkpoint(tag: str, L: int, J: int, way: int, B: int, torch_seed: int):
+    """SURVEY 8f row 3 -- pins the checkpoint converter (isbfsar_amd/weights.state_from_torch). The reference's TRXOS is
+    instantiated with torch's DEFAULT initialisation (seeded), i.e. a state_dict the reference itself produced, in the
+    shape a DISC.pth['model_state_dict'] has (modules/ar/ar.py:17-19): every tensor of it is stored together with the
+    key names of the three dialects such a checkpoint comes in, and with the outputs the same TRXOS computes:
+      plain         the module's own keys (features_extractor.sk.*, transformers.0.*, discriminator.*, post_resnet.l1.*,
+                    the transformers.0.pe.pe buffer)
+      dataparallel  '.module' infixes as left by DataParallel wrappers, stripped by ar.py:18
+      pre_rgb       checkpoints written before the RGB branch: features_extractor.fc1/fc2 (no '.sk' level), no
+                    post_resnet.* -- what utils/rename_torch_layers_and_parameters.py:9-13 migrates (it adds '.sk' and
+                    zero-filled post_resnet tensors; post_resnet is stored zero-filled here too: it is not on the
+                    skeleton path and 2 MB of random numbers would be dead weight in the fixture)"""
+    import json
+    import torch
+
+    _stub_torchvision()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        from modules.ar.utils.model import TRXOS
+        from utils.params import TRXConfig
+    finally:
+        os.chdir(cwd)
+    args = TRXConfig()
+    args.device = "cpu"
+    args.seq_len, args.n_joints, args.way = L, J, way
+    torch.manual_seed(torch_seed)
+    net = TRXOS(args).eval()
+    with torch.no_grad():                       # rename_torch_layers_and_parameters.py:12-13
+        net.post_resnet.l1.weight.zero_()
+        net.post_resnet.l1.bias.zero_()
+    sd = {k: v.detach().numpy().copy() for k, v in net.state_dict().items()}
+    plain = list(sd)
+    dialects = {
+        "plain": {k: k for k in plain},
+        "dataparallel": {k: k.split(".", 1)[0] + ".module." + k.split(".", 1)[1] for k in plain},
+        "pre_rgb": {k: k.replace("features_extractor.sk.", "features_extractor.") for k in plain if not k.startswith("post_resnet.")},
+    }
+    ss = synth.skeleton_windows(way, L, J, seed=torch_seed + 100)
+    q = synth.skeleton_windows(B, L, J, seed=torch_seed + 200)
+    labels = torch.arange(way, dtype=torch.int32)[None]
+    logits, is_true = [], []
+    with torch.no_grad():
+        for b in range(B):
+            o = net({"sk": torch.from_numpy(ss)[None]}, labels, {"sk": torch.from_numpy(q[b:b + 1])})
+            logits.append(o["logits"].numpy()[0])
+            is_true.append(o["is_true"].numpy()[0])
+        qfeat = net.features_extractor["sk"](torch.from_numpy(q)).numpy()
+    rec = {"t::" + k: v for k, v in sd.items()}
+    rec.update(L=L, J=J, way=way, B=B, torch_seed=torch_seed, torch_version=str(torch.__version__),
+               dialects=json.dumps(dialects), ss=ss, q=q, logits=np.stack(logits), is_true=np.stack(is_true), qfeat=qfeat)
+    np.savez_compressed(os.path.join(OUT, f"ar_ckpt_{tag}.npz"), **rec)
+    print(f"ar_ckpt_{tag}: {len(sd)} tensors, {sum(v.size for v in sd.values())} values, logits[0]={rec['logits'][0]} is_true={rec['is_true'].ravel()}")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["ar", "hpe"]
+    which = sys.argv[1:] or ["ar", "hpe", "ckpt"]
     if "ar" in which:
         gen_ar("ref_16_30_5", 16, 30, 5, B=3, seed=0, keep_intermediates=True)
         gen_ar("bl_30_122_60", 30, 122, 60, B=2, seed=1, keep_intermediates=False)
@@ -166,6 +223,8 @@ def main():
         # resolving power: discriminator weights x6 (is_true spans 0.0-1.0 instead of 0.50-0.51) and LayerNorm gain x3
         gen_ar("sharp_16_30_5", 16, 30, 5, B=8, seed=2, keep_intermediates=False, disc_gain=6.0, norm_gain=3.0)
         gen_ar("sharp_30_122_60", 30, 122, 60, B=4, seed=2, keep_intermediates=False, disc_gain=6.0, norm_gain=3.0)
+    if "ckpt" in which or not sys.argv[1:]:
+        gen_ar_checkpoint("ref_16_30_5", 16, 30, 5, B=4, torch_seed=1234)
     if "hpe" in which:
         try:
             from gen_golden_hpe import gen_all

@@ -298,3 +298,24 @@ def test_full_size_properties():
     np.testing.assert_allclose(logits[idx], ref["logits"], rtol=0, atol=ATOL_LOGIT["bf16"])
     np.testing.assert_allclose(is_true[idx], ref["is_true"][:, 0], rtol=0, atol=ATOL_PROB)
     assert np.abs(_softmax(logits).sum(1) - 1).max() < 1e-5
+
+
+@pytest.mark.parametrize("dialect", ["plain", "dataparallel", "pre_rgb"])
+def test_reference_checkpoint_through_converter(golden_dir, dialect):
+    """SURVEY 8f row 3 on the GPU: a state_dict produced by the reference's own TRXOS (torch default init; fixture
+    ar_ckpt_*.npz, three key dialects: ar.py:17-19, rename_torch_layers_and_parameters.py:9-13) -> state_from_torch ->
+    blob -> isb_ar_load_weights -> the logits / open-set score / embedding that TRXOS computed."""
+    import json
+    g = np.load(os.path.join(golden_dir, "ar_ckpt_ref_16_30_5.npz"))
+    tensors = {k[3:]: g[k] for k in g.files if k.startswith("t::")}
+    sd = {new: tensors[plain] for plain, new in json.loads(str(g["dialects"]))[dialect].items()}
+    L, J, way = (int(g[k]) for k in ("L", "J", "way"))
+    state = weights.state_from_torch(sd, keys=set(weights.ar_state_shapes(L, J)))
+    for precision in ("bf16", "bf16x3"):
+        eng = _engine(L, J, way, precision, state=state)
+        eng.set_support(poses=g["ss"])
+        logits, is_true, embed = eng.infer(g["q"], want_embed=True)
+        np.testing.assert_allclose(logits, g["logits"], rtol=0, atol=ATOL_LOGIT[precision])
+        np.testing.assert_allclose(_softmax(logits), _softmax(g["logits"]), rtol=0, atol=ATOL_PROB)
+        np.testing.assert_allclose(is_true, g["is_true"][:, 0], rtol=0, atol=ATOL_PROB)
+        np.testing.assert_allclose(embed, g["qfeat"], rtol=0, atol=ATOL_F32)

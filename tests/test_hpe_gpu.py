@@ -639,3 +639,63 @@ def test_human_pose_estimator_dropin(bbone_state, assets):
     assert tta.engine.warp(frame[None], np.array([cfg.fixed_bbox], np.int32)).shape == (5, 256, 256, 3)
     with pytest.raises(Exception, match="augmentation"):
         tta.estimate(frame)
+
+
+@pytest.mark.parametrize("lanes", ["1", "2"])
+def test_large_micro_batches_are_bit_identical(bbone_state, assets, monkeypatch, lanes):
+    """bench.py's 2048-frame line runs micro-batches of 1024 frames (kMaxMicroBatch), i.e. tensors of up to
+    2^31 bytes where the 32-bit-offset kernels hand over to others. Frames are independent, so 1024-frame micro-batches
+    (one lane: 1024-frame tensors; two lanes: 512) must give the bits of 256-frame micro-batches."""
+    import torch
+    from isbfsar_amd.hpe_engine import HpeEngine
+    monkeypatch.setenv("ISB_HPE_LANES", lanes)
+    n = 1024
+    fr = torch.from_numpy(synth.frames(64, seed=400)).cuda().repeat(n // 64, 1, 1, 1)
+    # 16 copies of 64 frames, each copy with its own boxes: every frame of the batch is a different crop
+    bb = torch.from_numpy(np.concatenate([synth.bboxes(64, seed=401 + i) for i in range(n // 64)])).cuda()
+    outs = []
+    for mb in (1024, 256):
+        e = HpeEngine(device=0, max_batch=mb)
+        try:
+            e.set_joint_map(assets[0], None)
+            e.load_weights(bbone_state)
+            j, v = e.forward(fr, bb)
+            torch.cuda.synchronize()
+            outs.append((j.cpu().numpy(), v.cpu().numpy()))
+        finally:
+            e.close()
+    assert outs[0][1].sum() > n // 2
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("mode", ["2", "1"])
+def test_roi_only_host_input_is_bit_identical(bbone_state, assets, monkeypatch, mode):
+    """isb_hpe_forward_host copies only the source rectangle each crop can reach (ISB_HPE_ROI=2; 1 = whole-width row
+    bands) instead of whole 921 600-byte frames: same bits as whole frames (ISB_HPE_ROI=0) and as the device-pointer
+    entry, also for boxes that touch or leave the frame (the crop's pre-image is then clipped to the frame)."""
+    import torch
+    from isbfsar_amd.hpe_engine import HpeEngine
+    n = 12
+    fr = synth.frames(n, seed=500)
+    bb = synth.bboxes(n, seed=500)
+    bb[0] = (0, 200, 0, 300)            # x1, x2, y1, y2: top-left corner of the frame
+    bb[1] = (440, 639, 180, 479)        # bottom-right corner
+    bb[2] = (0, 639, 0, 479)            # the whole frame
+    bb[3] = (600, 639, 10, 60)          # a sliver at the right edge
+    outs = {}
+    for m in (mode, "0"):
+        monkeypatch.setenv("ISB_HPE_ROI", m)
+        e = HpeEngine(device=0, max_batch=8)       # micro-batches of 8 + 4: the descriptors are indexed per micro-batch
+        try:
+            e.set_joint_map(assets[0], assets[1]["smpl+head_30"]["indices"])
+            e.load_weights(bbone_state)
+            outs[m] = e.forward(fr, bb)
+            if m == mode:
+                j_dev, v_dev = e.forward(torch.from_numpy(fr).cuda(), torch.from_numpy(bb).cuda())
+                torch.cuda.synchronize()
+                outs["dev"] = (j_dev.cpu().numpy(), v_dev.cpu().numpy())
+        finally:
+            e.close()
+    for k in ("0", "dev"):
+        assert np.array_equal(outs[mode][0], outs[k][0]) and np.array_equal(outs[mode][1], outs[k][1]), k
+    assert outs[mode][1].sum() >= n - 4

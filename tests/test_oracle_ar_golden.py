@@ -85,3 +85,33 @@ def test_sliding_window_state_machine(golden_dir):
         k += 1
     assert k == len(g["probs"])
     assert ar.remove("c0") and not ar.remove("c0")
+
+
+def _ckpt_dialects(g):
+    """the reference-produced state_dict of tests/golden/ar_ckpt_*.npz under each of its three key dialects"""
+    import json
+    tensors = {k[3:]: g[k] for k in g.files if k.startswith("t::")}
+    return {name: {new: tensors[plain] for plain, new in keymap.items()} for name, keymap in json.loads(str(g["dialects"])).items()}
+
+
+@pytest.mark.parametrize("dialect", ["plain", "dataparallel", "pre_rgb"])
+def test_converter_on_reference_checkpoint(golden_dir, dialect):
+    """weights.state_from_torch on a state_dict the REFERENCE's TRXOS produced (torch default init,
+    oracle/gen_golden.py::gen_ar_checkpoint) in the three dialects a DISC.pth comes in (ar.py:17-19,
+    rename_torch_layers_and_parameters.py:9-13): the converted weights, run through the oracle, give the outputs that
+    very TRXOS computed."""
+    g = _load(golden_dir, "ar_ckpt_ref_16_30_5.npz")
+    sd = _ckpt_dialects(g)[dialect]
+    if dialect == "dataparallel":
+        assert all(".module." in k for k in sd)
+    if dialect == "pre_rgb":
+        assert not any(k.startswith("post_resnet.") or ".sk." in k for k in sd)
+    L, J, way = (int(g[k]) for k in ("L", "J", "way"))
+    state = weights.state_from_torch(sd, keys=set(weights.ar_state_shapes(L, J)))
+    assert set(state) == set(weights.ar_state_shapes(L, J))           # pe buffer and post_resnet dropped, nothing missing
+    for k, shape in weights.ar_state_shapes(L, J).items():
+        assert state[k].shape == shape and state[k].dtype == np.float32
+    out = TRXOSOracle(state, L, J).forward(g["ss"], way, g["q"])
+    np.testing.assert_allclose(out["logits"], g["logits"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(out["is_true"], g["is_true"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(out["query_features"], g["qfeat"], rtol=0, atol=2e-6)

@@ -253,3 +253,44 @@ def test_bench_rccl_path_with_one_rank():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["world_size"] == 1 and line["value"] > 0 and line["devices"] == ["rank0=cuda:0"]
+
+
+def test_record_gather_behind_the_c_abi_and_in_a_hipgraph():
+    """isb_dist_* (RCCL communicator owned by the library, ncclAllGather on the caller's stream) with the one rank a
+    one-GPU box can hold: the gathered records equal the records bit for bit, eagerly and from a hipGraph that captured
+    the collective together with the kernel producing the records (the arrangement of BASELINE configs[4])."""
+    import torch
+    from isbfsar_amd.dist import RecordGather, all_gather_records, pack_records
+    g = RecordGather(device=0)
+    try:
+        assert (g.rank, g.world) == (0, 1)
+        logits = torch.randn(24, 60, device="cuda")
+        is_true = torch.rand(24, device="cuda")
+        embed = torch.randn(24, 30, 256, device="cuda")
+        rec = pack_records(logits, is_true, embed)
+        out = all_gather_records(rec, gather=g)
+        torch.cuda.synchronize()
+        assert out.data_ptr() != rec.data_ptr() and torch.equal(out, rec)
+        # ragged shards are padded to the largest and trimmed again
+        out2 = all_gather_records(rec[:7], counts=[7], gather=g)
+        torch.cuda.synchronize()
+        assert torch.equal(out2, rec[:7])
+        # captured: producer kernel + collective in ONE graph, replayed on new inputs
+        src = torch.zeros_like(rec)
+        dst = torch.empty_like(rec)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            g.all_gather_into(src * 2.0, dst)              # warm-up outside capture
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=s):
+                g.all_gather_into(src * 2.0, dst)
+        torch.cuda.synchronize()
+        for k in range(3):
+            src.copy_(rec + k)
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(dst, (rec + k) * 2.0)
+    finally:
+        g.close()
