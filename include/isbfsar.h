@@ -275,7 +275,8 @@ int isb_debug_gemm_f32(int32_t device, const float* h_A, const float* h_W, const
  *   h_x bf16 [B,H,H,C], h_w f32 [C,3,3] (taps are rounded to bf16 after the BN scale is folded in, like every
  *   conv weight), stride 1 (pad 1) or 2 (TF SAME: pad bottom/right); out bf16 [B,H/stride,H/stride,C], pooled f32 [B,C].
  *   stride | 0x100: h_x and the taps are fp16; stride | 0x200: out is fp16 (forms of the fp16 stages: stride 1 with both,
- *   stride 2 with 0x200 alone) */
+ *   stride 2 with 0x200 alone); stride | 0x400: the general kernel also on 8 x 8 maps (which otherwise take the LDS-staged
+ *   dwconv3x3_map8_kernel) */
 int isb_debug_dwconv(int32_t device, const uint16_t* h_x, const float* h_w, const float* h_scale, const float* h_shift,
                      int32_t B, int32_t H, int32_t C, int32_t stride, int32_t iters, uint16_t* h_out, float* h_pooled,
                      float* ms_per_iter);

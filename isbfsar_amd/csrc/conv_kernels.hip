@@ -2496,7 +2496,7 @@ int launch_dwconv3x3(const DwArgs& a, hipStream_t st) {
         set_error("dwconv3x3: fp16 forms are stride 1 fp16 -> fp16 and stride 2 bf16 -> fp16 (in_f16=%d out_f16=%d stride=%d)", a.in_f16, a.out_f16, a.stride);
         return ISB_ERR_INVALID;
     }
-    if (!a.se_w1 && a.stride == 1 && a.H == 8 && a.W == 8 && a.OH == 8 && a.OW == 8 && a.pad == 1 && (form == 0 || form == 3) && dw_map8_on()) {
+    if (!a.se_w1 && a.stride == 1 && a.H == 8 && a.W == 8 && a.OH == 8 && a.OW == 8 && a.pad == 1 && (form == 0 || form == 3) && !a.general && dw_map8_on()) {
         // grid.x = dw_slabs(a) = C / 128 slabs here too (16 quads x 16 chunks per workgroup)
         if (form == 3) hipLaunchKernelGGL((dwconv3x3_map8_kernel<true>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((dwconv3x3_map8_kernel<false>), grid, dim3(256), 0, st, a);

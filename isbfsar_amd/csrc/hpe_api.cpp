@@ -56,6 +56,8 @@ struct Lane {
     int ws_B = 0;
     DevBuf H, newK, R, crops, bufX, bufY, bufE, bufD, pooled, semid, gate, feat, logits;
     DevBuf part;                  // split-K partial tiles of the small-M projections (kSplitKBytes)
+    void* X = nullptr;            // the residual stream's current input / output buffers while a forward pass is being enqueued
+    void* Y = nullptr;
 };
 
 }  // namespace
@@ -100,12 +102,16 @@ struct isb_hpe {
     DevBuf hs_frames, hs_bbox, hs_joints, hs_valid;
     int hs_B = 0;
     // ROI-only host input: the warp reads at most the crop square's pre-image, typically 150-480 KB of a 921 600-byte frame.
-    // isb_hpe_forward_host computes the crop homographies first (a 9 KB round trip), bounds each frame's source rectangle on
-    // the host and copies only that (hipMemcpy2DAsync into a packed image). ISB_HPE_ROI: 2 = rectangles (default),
-    // 1 = whole-width row bands (one contiguous copy per frame), 0 = whole frames.
-    int roi_mode = 2;
+    // When the caller's frames are device-mapped pinned memory, isb_hpe_forward_host computes the crop homographies first (a
+    // 9 KB round trip), bounds each frame's source rectangle on the host and ONE gather kernel pulls exactly those rectangles
+    // over PCIe into a packed image (roi_gather_kernel). Measured and dropped: one hipMemcpy2DAsync per frame (2.3 ms EACH from
+    // pinned memory: 608 ms per 256 frames) and one contiguous row-band copy per frame (24.2 ms against 22.9 for whole frames:
+    // 256 copy calls cost more than the bytes they save). ISB_HPE_ROI: 1 = gather (default), 0 = whole frames.
+    int roi_mode = 1;
     DevBuf hs_H, hs_newK, hs_R, hs_roi;
     const RoiDesc* roi_dev = nullptr;   // set for the duration of one isb_hpe_forward_host call
+    const uint8_t* roi_src = nullptr;   // ... with the device address of the caller's mapped host frames: every lane gathers ITS
+                                        // frames on its own stream, so lane 1's rectangles cross PCIe while lane 0 already computes
     // profiling of conv_igemm launches
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
@@ -242,16 +248,24 @@ int gemm(hipStream_t st, const float* A, int lda, const float* W, int ldw, const
     return launch_gemm_f32(g, st);
 }
 
-// crops f32 [B,256,256,3] (device) -> feat f32 [B*64,1280], logits f32 [B*64,288]
-int run_backbone(isb_hpe* h, Lane& L, hipStream_t st, const float* crops, int B) {
+// crops f32 [B,256,256,3] (device) -> feat f32 [B*64,1280], logits f32 [B*64,288], in three pieces so that a caller with
+// several lanes can ENQUEUE them round-robin (backbone_begin, backbone_blocks over block ranges, backbone_end): a lane's ~600
+// launches take the host ~2 ms to submit, and submitted lane after lane the second lane's first kernel would wait that long
+int backbone_begin(isb_hpe* h, Lane& L, hipStream_t st, const float* crops, int B) {
     StemArgs sa{};
     sa.in = crops; sa.w = h->stem_w.as<float>(); sa.bias = h->stem_b.as<float>(); sa.out = L.bufX.as<uint16_t>();
     sa.B = B; sa.H = 256; sa.W = 256;
     ISB_TRY(launch_stem(sa, st));
-    void* X = L.bufX.p;
-    void* Y = L.bufY.p;
-    for (auto& up : h->blocks) {
-        BlockW& b = *up;
+    L.X = L.bufX.p;
+    L.Y = L.bufY.p;
+    return ISB_OK;
+}
+
+int backbone_blocks(isb_hpe* h, Lane& L, hipStream_t st, int B, size_t i0, size_t i1) {
+    void*& X = L.X;
+    void*& Y = L.Y;
+    for (size_t bi = i0; bi < std::min(i1, h->blocks.size()); ++bi) {
+        BlockW& b = *h->blocks[bi];
         const void* res = b.residual ? X : nullptr;
         if (b.fused) {
             if (b.cexp == b.cin) {
@@ -328,6 +342,11 @@ int run_backbone(isb_hpe* h, Lane& L, hipStream_t st, const float* crops, int B)
         }
         std::swap(X, Y);
     }
+    return ISB_OK;
+}
+
+int backbone_end(isb_hpe* h, Lane& L, hipStream_t st, int B) {
+    void* X = L.X;
     ISB_TRY(conv(h, st, h->headconv, X, B, 8, 8, 1, true, nullptr, nullptr, L.feat.p, true));
     if (B == 1 && h->split_k) {
         // one frame: 64 rows x 288 outputs are 5 tiles walking 40 k-tiles each -> 8 K-splits + an in-order reduction
@@ -343,6 +362,12 @@ int run_backbone(isb_hpe* h, Lane& L, hipStream_t st, const float* crops, int B)
     ISB_TRY(gemm(st, L.feat.as<float>(), 1280, h->head_w.as<float>(), 1280, h->head_b.as<float>(), L.logits.as<float>(), 288,
                  B * 64, 288, 1280, GEMM_ACT_NONE));
     return ISB_OK;
+}
+
+int run_backbone(isb_hpe* h, Lane& L, hipStream_t st, const float* crops, int B) {
+    ISB_TRY(backbone_begin(h, L, st, crops, B));
+    ISB_TRY(backbone_blocks(h, L, st, B, 0, h->blocks.size()));
+    return backbone_end(h, L, st, B);
 }
 
 int run_post(isb_hpe* h, Lane& L, hipStream_t st, const float* logits, int B, float* joints, uint8_t* valid, double* dbg,
@@ -409,7 +434,7 @@ extern "C" int isb_hpe_create(const isb_hpe_cfg* cfg, isb_hpe** out) {
     if (const char* e = getenv("ISB_FUSE_BLOCK_CEXP")) h->fuse_block_max_cexp = atoi(e);
     if (cfg->precision == 1) h->f16_from = 7;
     if (const char* e = getenv("ISB_HPE_F16")) h->f16_from = atoi(e) == 0 ? 7 : 5;
-    if (const char* e = getenv("ISB_HPE_ROI")) h->roi_mode = std::max(0, std::min(2, atoi(e)));
+    if (const char* e = getenv("ISB_HPE_ROI")) h->roi_mode = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("ISB_HPE_LANES")) h->n_lanes = std::max(1, std::min(kMaxLanes, atoi(e)));
     ISB_HIP(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
     ISB_HIP(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
@@ -596,12 +621,28 @@ extern "C" int isb_hpe_forward(isb_hpe* h, const uint8_t* d_frames, const int32_
     hipStream_t st = (hipStream_t)stream;   // NULL = the HIP null stream (torch's default stream)
     const int Bm_max = std::min<int>(B, h->cfg.max_batch);
     const size_t fsz = (size_t)h->cfg.height * h->cfg.width * 3;
-    auto run_lane = [&](Lane& L, hipStream_t s, int b0, int Bm) -> int {
-        ISB_TRY(ensure_ws(L, Bm));
-        ISB_TRY(run_crop_params(h, L, s, d_bbox + (size_t)b0 * 4, Bm));
-        if (h->roi_dev) ISB_TRY(run_warp(h, L, s, d_frames, Bm, h->roi_dev + b0));      // packed ROI image: offsets live in the descriptors
-        else ISB_TRY(run_warp(h, L, s, d_frames + (size_t)b0 * fsz, Bm));
-        ISB_TRY(run_backbone(h, L, s, L.crops.as<float>(), Bm));
+    // a lane's pass in phases: 0 = crop parameters, (ROI gather,) warp, stem; 1 .. n = kPhaseBlocks blocks each; last = 640 -> 1280
+    // convolution, pose head, decode + reconstruction
+    constexpr size_t kPhaseBlocks = 6;
+    const int n_phases = 2 + (int)((h->blocks.size() + kPhaseBlocks - 1) / kPhaseBlocks);
+    auto run_phase = [&](Lane& L, hipStream_t s, int b0, int Bm, int ph, int lane_no) -> int {
+        if (ph == 0) {
+            ISB_TRY(ensure_ws(L, Bm));
+            ISB_TRY(run_crop_params(h, L, s, d_bbox + (size_t)b0 * 4, Bm));
+            if (h->roi_dev) {                        // packed ROI image: offsets live in the descriptors
+                // (each lane gathers its own frames on its own stream. Measured and equal: one gather for the whole batch up front,
+                // 19.5 ms per 256 frames; the lanes' gathers one after the other on the link, 19.5-19.7. What is exposed is the
+                // transfer itself: 52 MB at the 20 GB/s a kernel reads mapped host memory, during which at most one lane computes.)
+                (void)lane_no;
+                ISB_TRY(launch_roi_gather(h->roi_src + (size_t)b0 * fsz, h->roi_dev + b0, const_cast<uint8_t*>(d_frames), Bm, h->cfg.height, h->cfg.width, s));
+                ISB_TRY(run_warp(h, L, s, d_frames, Bm, h->roi_dev + b0));
+            } else {
+                ISB_TRY(run_warp(h, L, s, d_frames + (size_t)b0 * fsz, Bm));
+            }
+            return backbone_begin(h, L, s, L.crops.as<float>(), Bm);
+        }
+        if (ph < n_phases - 1) return backbone_blocks(h, L, s, Bm, (size_t)(ph - 1) * kPhaseBlocks, (size_t)ph * kPhaseBlocks);
+        ISB_TRY(backbone_end(h, L, s, Bm));
         return run_post(h, L, s, L.logits.as<float>(), Bm, d_joints + (size_t)b0 * h->n_out * 3, d_valid + b0, nullptr,
                         d_bbox + (size_t)b0 * 4);
     };
@@ -613,19 +654,22 @@ extern "C" int isb_hpe_forward(isb_hpe* h, const uint8_t* d_frames, const int32_
         if (nl >= 2 && Bm >= kMinSplit && !h->prof) {
             const int part = (Bm + nl - 1) / nl;
             ISB_HIP(hipEventRecord(h->fork_ev, st));
-            for (int l = 1; l < nl; ++l) {
-                Lane& L = h->lanes[l];
-                const int lo = l * part, n = std::min(part, Bm - lo);
-                if (n <= 0) break;
-                ISB_HIP(hipStreamWaitEvent(L.side, h->fork_ev, 0));
-                ISB_TRY(run_lane(L, L.side, b0 + lo, n));
-                ISB_HIP(hipEventRecord(h->join_ev[l], L.side));
-            }
-            ISB_TRY(run_lane(h->lanes[0], st, b0, std::min(part, Bm)));
             for (int l = 1; l < nl; ++l)
-                if (l * part < Bm) ISB_HIP(hipStreamWaitEvent(st, h->join_ev[l], 0));
+                if (l * part < Bm) ISB_HIP(hipStreamWaitEvent(h->lanes[l].side, h->fork_ev, 0));
+            // the lanes are fed round-robin, a phase at a time: each stream has work within ~0.2 ms of host time
+            for (int ph = 0; ph < n_phases; ++ph)
+                for (int l = 0; l < nl; ++l) {
+                    const int lo = l * part, n = std::min(part, Bm - lo);
+                    if (n <= 0) break;
+                    ISB_TRY(run_phase(h->lanes[l], l == 0 ? st : h->lanes[l].side, b0 + lo, n, ph, l));
+                }
+            for (int l = 1; l < nl; ++l)
+                if (l * part < Bm) {
+                    ISB_HIP(hipEventRecord(h->join_ev[l], h->lanes[l].side));
+                    ISB_HIP(hipStreamWaitEvent(st, h->join_ev[l], 0));
+                }
         } else {
-            ISB_TRY(run_lane(h->lanes[0], st, b0, Bm));
+            for (int ph = 0; ph < n_phases; ++ph) ISB_TRY(run_phase(h->lanes[0], st, b0, Bm, ph, 0));
         }
     }
     return ISB_OK;
@@ -656,7 +700,17 @@ extern "C" int isb_hpe_forward_host(isb_hpe* h, const uint8_t* frames, const int
     uint8_t* dv = h->hs_valid.as<uint8_t>();
     ISB_HIP(hipMemcpyAsync(db, bbox, (size_t)B * 16, hipMemcpyHostToDevice, st));
     const int FW = h->cfg.width, FH = h->cfg.height;
-    if (h->roi_mode > 0 && B >= kRoiMinBatch) {
+    // the frames as the device sees them, if the caller's buffer is mapped pinned memory (hipHostMalloc / hipHostRegister;
+    // torch.Tensor.pin_memory()): only then can a kernel pull rectangles out of it
+    const uint8_t* frames_mapped = nullptr;
+    if (h->roi_mode > 0 && B >= kRoiMinBatch && FW % 16 == 0) {
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, frames) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer)
+            frames_mapped = static_cast<const uint8_t*>(at.devicePointer);
+        else
+            (void)hipGetLastError();             // pageable memory: not an error, whole frames are copied below
+    }
+    if (frames_mapped) {
         // 1. the crop homographies of the whole batch (the kernel isb_hpe_forward runs again per lane: same inputs, same bits)
         if (h->hs_H.bytes < (size_t)B * 36) {
             ISB_TRY(h->hs_H.alloc((size_t)B * 36));
@@ -696,7 +750,8 @@ extern "C" int isb_hpe_forward_host(isb_hpe* h, const uint8_t* frames, const int
                 y0 = (int)std::max(0.0, std::floor(std::min(ylo, 1e9)) - 2.0);
                 x1 = (int)std::min((double)FW - 1.0, std::ceil(std::max(xhi, -1e9)) + 2.0);
                 y1 = (int)std::min((double)FH - 1.0, std::ceil(std::max(yhi, -1e9)) + 2.0);
-                if (h->roi_mode == 1) { x0 = 0; x1 = FW - 1; }           // whole-width row bands
+                x0 &= ~15;                                              // 16-pixel (48-byte) alignment: whole 16-byte pieces
+                x1 = std::min(FW - 1, x1 | 15);
             }
             RoiDesc& r = roi[b];
             if (x1 < x0 || y1 < y0) { r.x0 = 0; r.y0 = 0; r.w = 0; r.h = 0; r.off = off; continue; }   // the crop misses the frame
@@ -704,20 +759,14 @@ extern "C" int isb_hpe_forward_host(isb_hpe* h, const uint8_t* frames, const int
             off += ((uint64_t)r.w * r.h * 3 + 15) & ~15ull;
         }
         ISB_REQUIRE(off <= h->hs_frames.bytes, ISB_ERR_INVALID, "internal: packed ROI image larger than the frame staging buffer");
-        // 3. the rectangles cross PCIe on the copy stream (row pitch of the source = a frame row)
-        for (int b = 0; b < B; ++b) {
-            const RoiDesc& r = roi[b];
-            if (r.w <= 0) continue;
-            const uint8_t* src = frames + (size_t)b * fsz + ((size_t)r.y0 * FW + r.x0) * 3;
-            if (r.w == FW) ISB_HIP(hipMemcpyAsync(df + r.off, src, (size_t)r.w * r.h * 3, hipMemcpyHostToDevice, h->copy_stream));
-            else ISB_HIP(hipMemcpy2DAsync(df + r.off, (size_t)r.w * 3, src, (size_t)FW * 3, (size_t)r.w * 3, r.h, hipMemcpyHostToDevice, h->copy_stream));
-        }
-        ISB_HIP(hipMemcpyAsync(h->hs_roi.p, roi.data(), (size_t)B * sizeof(RoiDesc), hipMemcpyHostToDevice, h->copy_stream));
-        ISB_HIP(hipEventRecord(h->h2d_ev[0], h->copy_stream));
-        ISB_HIP(hipStreamWaitEvent(st, h->h2d_ev[0], 0));
+        // 3. one gather kernel per lane pulls the rectangles out of the mapped host frames (aligned 16-byte reads over PCIe),
+        // launched by isb_hpe_forward in front of each lane's warp
+        ISB_HIP(hipMemcpyAsync(h->hs_roi.p, roi.data(), (size_t)B * sizeof(RoiDesc), hipMemcpyHostToDevice, st));
         h->roi_dev = h->hs_roi.as<RoiDesc>();
+        h->roi_src = frames_mapped;
         const int rc = isb_hpe_forward(h, df, db, B, dj, dv, st);
         h->roi_dev = nullptr;
+        h->roi_src = nullptr;
         if (rc != ISB_OK) return rc;
         // `roi` and `Hh` must outlive the asynchronous copies that read them: the synchronise below covers it
     } else {
@@ -1191,6 +1240,7 @@ extern "C" int isb_debug_dwconv(int32_t device, const uint16_t* x, const float* 
     return isb::guard([&]() -> int {
         ISB_REQUIRE(x && w && scale && shift && out && pooled && ms_per_iter, ISB_ERR_INVALID, "null argument");
         const int in_f16 = (stride & 0x100) ? 1 : 0, out_f16 = (stride & 0x200) ? 1 : 0;   // fp16 input + taps / fp16 output
+        const int general = (stride & 0x400) ? 1 : 0;                                       // never the 8 x 8-map kernel
         stride &= 0xff;
         ISB_REQUIRE((stride == 1 || stride == 2) && iters >= 1 && B >= 1, ISB_ERR_INVALID, "bad depthwise parameters");
         ISB_HIP(hipSetDevice(device));
@@ -1217,7 +1267,7 @@ extern "C" int isb_debug_dwconv(int32_t device, const uint16_t* x, const float* 
         d.in = dx.as<uint16_t>(); d.w = dw.as<uint16_t>(); d.bias = db.as<float>(); d.out = dout.as<uint16_t>();
         d.pooled = dpool.as<float>(); d.B = B; d.H = H; d.W = H; d.C = C; d.OH = OH; d.OW = OH; d.stride = stride;
         d.pad = stride == 1 ? 1 : 0;
-        d.in_f16 = in_f16; d.out_f16 = out_f16;
+        d.in_f16 = in_f16; d.out_f16 = out_f16; d.general = general;
         ISB_TRY(launch_dwconv3x3(d, nullptr));
         ISB_HIP(hipDeviceSynchronize());
         hipEvent_t e0, e1;

@@ -145,6 +145,45 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs p) {
     d[0] = o0; d[1] = o1; d[2] = o2;
 }
 
+// grid (pieces of 2048 16-byte chunks, B): chunk id -> (row, 16-byte piece of the row). Reads over PCIe pay a microsecond of
+// latency each, so a thread requests all EIGHT of its chunks before it stores the first (one load in flight per thread moved
+// 20 GB/s; the link does more than twice that).
+__global__ __launch_bounds__(256) void roi_gather_kernel(const uint8_t* frames, const RoiDesc* roi, uint8_t* dst, int FH, int FW) {
+    const int b = blockIdx.y;
+    const RoiDesc rd = roi[b];
+    const int cpr = (rd.w * 3) >> 4;                         // 16-byte pieces per row (w % 16 == 0)
+    const int total = cpr * rd.h;
+    const int first = blockIdx.x * 2048 + threadIdx.x;
+    if (first >= total) return;
+    const uint8_t* src = frames + ((size_t)b * FH + rd.y0) * FW * 3 + (size_t)rd.x0 * 3;
+    uint8_t* out = dst + rd.off;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int id = first + 256 * k;
+        const int idc = min(id, total - 1);
+        const int row = idc / cpr, pc = idc - row * cpr;
+        v[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + (size_t)row * FW * 3 + pc * 16));
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int id = first + 256 * k;
+        if (id < total) *reinterpret_cast<u32x4*>(out + (size_t)id * 16) = v[k];
+    }
+}
+
+int launch_roi_gather(const uint8_t* frames_mapped, const RoiDesc* roi, uint8_t* dst, int B, int FH, int FW, hipStream_t st) {
+    if ((FW * 3) % 16 != 0 || FW % 16 != 0) {
+        set_error("roi_gather: frame rows must be multiples of 16 pixels (FW=%d)", FW);
+        return ISB_ERR_INVALID;
+    }
+    const int max_chunks = (FW * 3 / 16) * FH;
+    hipLaunchKernelGGL(roi_gather_kernel, dim3(cdiv(max_chunks, 2048), B), dim3(256), 0, st, frames_mapped, roi, dst, FH, FW);
+    ISB_LAUNCHED("roi_gather", st);
+    return ISB_OK;
+}
+
 int launch_warp(const WarpArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(warp_kernel, dim3(256, a.B), dim3(256), 0, st, a);
     ISB_LAUNCHED("warp", st);

@@ -183,6 +183,7 @@ struct DwArgs {
     const float* se_w1;     // [cse,C] or null
     float* se_part;         // [dw_slabs(a)][B][cse]
     int cse;
+    int general;            // 1: never the 8 x 8-map kernel (tests compare the two forms bit for bit)
     int in_f16, out_f16;    // `in` + `w` / `out` hold fp16 instead of bf16 (ConvArgs.f16); in bf16 -> out fp16 is the block that
                             // enters the fp16 stages
 };
@@ -247,6 +248,10 @@ struct WarpArgs {
     const RoiDesc* roi;     // [B] or null: `frames` is the packed ROI image instead of whole frames
 };
 int launch_warp(const WarpArgs& a, hipStream_t st);
+// ROI gather: frames in device-mapped (pinned) HOST memory -> the packed ROI image in HBM. One launch for the whole batch; every
+// rectangle is 16-pixel aligned in x (48-byte = three 16-byte pieces), so the reads over PCIe are aligned 16-byte lane loads of
+// contiguous row segments. frames_mapped: device address of the host frames [B,FH,FW,3]; roi [B] (device); dst: packed image.
+int launch_roi_gather(const uint8_t* frames_mapped, const RoiDesc* roi, uint8_t* dst, int B, int FH, int FW, hipStream_t st);
 
 struct PostArgs {
     const float* logits;    // [B,8,8,288] pose-head output

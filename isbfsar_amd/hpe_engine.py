@@ -245,10 +245,10 @@ def gemm_f32_debug(A, W, bias=None, a_bias=None, a_add=None, act=0, a_act=0, spl
     return out, ms.value
 
 
-def dwconv_debug(x_bf16, w, scale, shift, stride=1, iters=1, device=0, in_f16=False, out_f16=False):
+def dwconv_debug(x_bf16, w, scale, shift, stride=1, iters=1, device=0, in_f16=False, out_f16=False, general=False):
     """Depthwise 3x3 + SiLU + SE mean through isb_debug_dwconv. x_bf16 uint16 [B,H,H,C], w f32 [C,3,3].
     Returns (out uint16 [B,H/stride,H/stride,C], pooled f32 [B,C], ms_per_launch). in_f16: x and the taps are fp16;
-    out_f16: out is fp16 (DwArgs.in_f16 / out_f16)."""
+    out_f16: out is fp16 (DwArgs.in_f16 / out_f16); general: the general kernel also on 8 x 8 maps."""
     x = np.ascontiguousarray(x_bf16, dtype=np.uint16)
     B, H, _, Cc = x.shape
     f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
@@ -256,7 +256,7 @@ def dwconv_debug(x_bf16, w, scale, shift, stride=1, iters=1, device=0, in_f16=Fa
     pooled = np.empty((B, Cc), np.float32)
     ms = C.c_float()
     _lib.check(_lib.lib().isb_debug_dwconv(device, _ptr(x), _ptr(f(w)), _ptr(f(scale)), _ptr(f(shift)), B, H, Cc,
-                                           stride | (0x100 if in_f16 else 0) | (0x200 if out_f16 else 0),
+                                           stride | (0x100 if in_f16 else 0) | (0x200 if out_f16 else 0) | (0x400 if general else 0),
                                            iters, _ptr(out), _ptr(pooled), C.byref(ms)), "isb_debug_dwconv")
     return out, pooled, ms.value
 

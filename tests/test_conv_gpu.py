@@ -448,3 +448,22 @@ def test_dwconv_f16_forms(form):
     tol = 2.0 ** -10 * np.maximum(0.25, np.abs(ref))
     assert np.all(np.abs(got - ref) <= tol), float(np.abs(got - ref).max())
     np.testing.assert_allclose(pooled, got.reshape(B, -1, Cc).mean(axis=1), rtol=0, atol=2e-5)   # the pool sees the stored values
+
+
+@pytest.mark.parametrize("f16", [False, True])
+@pytest.mark.parametrize("Cc", [2304, 3840, 200])
+def test_dwconv_map8_is_bit_identical(Cc, f16):
+    """8 x 8 maps run on dwconv3x3_map8_kernel (slab staged in LDS once, zero ring for the padding): same taps in the same
+    order as the general kernel -> the same bits, outputs and pooled means (200 channels: a partial last slab)."""
+    from isbfsar_amd.hpe_engine import dwconv_debug, f32_to_f16
+    rng = np.random.default_rng(Cc + int(f16))
+    B = 5
+    x = rng.normal(0, 1, (B, 8, 8, Cc)).astype(np.float32)
+    w = (rng.normal(0, 1, (Cc, 3, 3)) / 3.0).astype(np.float32)
+    scale = rng.uniform(0.8, 1.2, Cc).astype(np.float32)
+    shift = rng.uniform(-0.1, 0.1, Cc).astype(np.float32)
+    xin = f32_to_f16(x) if f16 else f32_to_bf16(x)
+    a, pa, _ = dwconv_debug(xin, w, scale, shift, stride=1, in_f16=f16, out_f16=f16)
+    g, pg, _ = dwconv_debug(xin, w, scale, shift, stride=1, in_f16=f16, out_f16=f16, general=True)
+    assert np.array_equal(a, g) and np.array_equal(pa, pg)
+    assert np.abs(pa).max() > 0

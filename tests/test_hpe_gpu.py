@@ -668,11 +668,11 @@ def test_large_micro_batches_are_bit_identical(bbone_state, assets, monkeypatch,
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
 
 
-@pytest.mark.parametrize("mode", ["2", "1"])
-def test_roi_only_host_input_is_bit_identical(bbone_state, assets, monkeypatch, mode):
-    """isb_hpe_forward_host copies only the source rectangle each crop can reach (ISB_HPE_ROI=2; 1 = whole-width row
-    bands) instead of whole 921 600-byte frames: same bits as whole frames (ISB_HPE_ROI=0) and as the device-pointer
-    entry, also for boxes that touch or leave the frame (the crop's pre-image is then clipped to the frame)."""
+def test_roi_only_host_input_is_bit_identical(bbone_state, assets, monkeypatch):
+    """With frames in device-mapped pinned host memory isb_hpe_forward_host pulls only the source rectangle each crop can
+    reach (one gather kernel over PCIe, ISB_HPE_ROI=1) instead of copying whole 921 600-byte frames: same bits as whole
+    frames (ISB_HPE_ROI=0), as pageable frames and as the device-pointer entry, also for boxes that touch or leave the frame
+    (the crop's pre-image is then clipped to the frame)."""
     import torch
     from isbfsar_amd.hpe_engine import HpeEngine
     n = 12
@@ -682,20 +682,22 @@ def test_roi_only_host_input_is_bit_identical(bbone_state, assets, monkeypatch, 
     bb[1] = (440, 639, 180, 479)        # bottom-right corner
     bb[2] = (0, 639, 0, 479)            # the whole frame
     bb[3] = (600, 639, 10, 60)          # a sliver at the right edge
+    fr_pinned = torch.from_numpy(fr).pin_memory().numpy()
     outs = {}
-    for m in (mode, "0"):
+    for m in ("1", "0"):
         monkeypatch.setenv("ISB_HPE_ROI", m)
         e = HpeEngine(device=0, max_batch=8)       # micro-batches of 8 + 4: the descriptors are indexed per micro-batch
         try:
             e.set_joint_map(assets[0], assets[1]["smpl+head_30"]["indices"])
             e.load_weights(bbone_state)
-            outs[m] = e.forward(fr, bb)
-            if m == mode:
+            outs[m] = e.forward(fr_pinned, bb)
+            if m == "1":
+                outs["pageable"] = e.forward(fr, bb)
                 j_dev, v_dev = e.forward(torch.from_numpy(fr).cuda(), torch.from_numpy(bb).cuda())
                 torch.cuda.synchronize()
                 outs["dev"] = (j_dev.cpu().numpy(), v_dev.cpu().numpy())
         finally:
             e.close()
-    for k in ("0", "dev"):
-        assert np.array_equal(outs[mode][0], outs[k][0]) and np.array_equal(outs[mode][1], outs[k][1]), k
-    assert outs[mode][1].sum() >= n - 4
+    for k in ("0", "pageable", "dev"):
+        assert np.array_equal(outs["1"][0], outs[k][0]) and np.array_equal(outs["1"][1], outs[k][1]), k
+    assert outs["1"][1].sum() >= n - 4
