@@ -103,6 +103,22 @@ int isb_ar_infer(isb_ar* h, const float* d_windows, int32_t B, float* d_logits, 
  * `.cuda()` / `.cpu()` pattern, ar.py:41,77-78 */
 int isb_ar_infer_host(isb_ar* h, const float* h_windows, int32_t B, float* h_logits,
                       float* h_is_true, float* h_embed);
+
+/* Input type (TRXConfig.input_type, utils/params.py:15,81). ISB_AR_INPUT_SKELETON (default): per-frame features = MLP(pose).
+ * ISB_AR_INPUT_HYBRID: features = [PostResNet(ResNet-50 trunk features) | MLP(pose)] = 512 wide (model.py:207-216, 270-277,
+ * 296-316: RGB first); the transformer then takes 512-wide rows (k/v_linear [128,1024], 512-wide positional encoding) and
+ * the blob must also hold post_resnet.l1.{weight,bias}. Call BEFORE isb_ar_load_weights (it invalidates weights and support
+ * set). The trunk features [.., L, 2048] come from isb_rgb_forward (the ResNet-50 engine below) or from the caller. In hybrid
+ * mode isb_ar_set_support takes cached features only ([n, L, 512]); embeddings / support features are 512 wide. */
+#define ISB_AR_INPUT_SKELETON 0
+#define ISB_AR_INPUT_HYBRID 1
+int isb_ar_set_input_type(isb_ar* h, int32_t type);
+/* h_poses [n, L, 3J], h_trunk [n, L, 2048] (host): the support set of ar.py:62-67 with both "imgs" and "poses" */
+int isb_ar_set_support_hybrid(isb_ar* h, const float* h_poses, const float* h_trunk, int32_t n);
+/* isb_ar_infer with d_trunk [B, L, 2048] f32 (device) beside the pose windows; d_embed (optional) [B, L, 512] */
+int isb_ar_infer_hybrid(isb_ar* h, const float* d_windows, const float* d_trunk, int32_t B, float* d_logits, float* d_is_true,
+                        float* d_embed, void* stream);
+
 /* test hook: argmax class per window of the last isb_ar_infer chunk sequence, int32 [B] (model.py:323) */
 int isb_ar_last_chosen(isb_ar* h, int32_t* h_chosen, int32_t B);
 
@@ -295,6 +311,25 @@ int isb_pose_windows(const float* d_joints, int32_t n_cam, int32_t n_frames, int
  * evaluated in float64 like the reference's numpy expression on the float64 pose).
  *   d_joints [n, J, 3] f32 (absolute joints as isb_hpe_forward writes them)    d_distance [n] f32 */
 int isb_pose_distance(const float* d_joints, int32_t n, int32_t J, float* d_distance, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * ResNet-50 trunk of the RGB / hybrid input types: the reference's
+ * nn.Sequential(*list(resnet50(pretrained=True).children())[:-1]) (modules/ar/utils/model.py:270-277), run per frame on the
+ * 224 x 224 person crop main.py:85-92 prepares. Images -> "trunk features" [N, 2048] f32 = the input of PostResNet, which
+ * lives inside isb_ar_infer_hybrid / isb_ar_set_support_hybrid. Public torchvision architecture, BatchNorm folded, bf16
+ * storage / f32 accumulate; neither torchvision nor its weights are in the reference tree: parity unpinned.
+ *   d_images f32 [N,3,224,224] (nchw = 1: the layout main.py:91 produces) or [N,224,224,3] (nchw = 0)
+ *   blob: rgb.conv1.{w,scale,shift}, rgb.layer{1..4}.{i}.conv{1,2,3}.*, rgb.layer{l}.0.downsample.* (isbfsar_amd/resnet50.py) */
+typedef struct isb_rgb isb_rgb;
+typedef struct isb_rgb_cfg {
+    int32_t device;
+    int32_t max_batch;        /* images per internal micro-batch; 0 = 64, clamped to 512 */
+} isb_rgb_cfg;
+int isb_rgb_create(const isb_rgb_cfg* cfg, isb_rgb** out);
+void isb_rgb_destroy(isb_rgb* r);
+int isb_rgb_load_weights(isb_rgb* r, const void* h_blob, size_t nbytes);
+int isb_rgb_forward(isb_rgb* r, const float* d_images, int32_t N, int32_t nchw, float* d_trunk, void* stream);
+int isb_rgb_forward_host(isb_rgb* r, const float* h_images, int32_t N, int32_t nchw, float* h_trunk);
 
 /* ------------------------------------------------------------------------------------------------
  * Multi-GPU: one process per GPU, frames / windows sharded across ranks with no data-path collective

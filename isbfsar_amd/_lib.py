@@ -30,6 +30,10 @@ class isb_hpe_cfg(C.Structure):
                 ("max_batch", C.c_int32), ("n_out_joints", C.c_int32), ("precision", C.c_int32)]
 
 
+class isb_rgb_cfg(C.Structure):
+    _fields_ = [("device", C.c_int32), ("max_batch", C.c_int32)]
+
+
 class isb_det_cfg(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("device", C.c_int32), ("max_batch", C.c_int32)]
 
@@ -51,6 +55,9 @@ SIGNATURES = {
     "isb_ar_infer": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P]),
     "isb_ar_infer_host": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P]),
     "isb_ar_last_chosen": (C.c_int, [_P, _P, C.c_int32]),
+    "isb_ar_set_input_type": (C.c_int, [_P, C.c_int32]),
+    "isb_ar_set_support_hybrid": (C.c_int, [_P, _P, _P, C.c_int32]),
+    "isb_ar_infer_hybrid": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P, _P]),
     "isb_ar_profile": (C.c_int, [_P, C.c_int32]),
     "isb_ar_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "isb_hpe_create": (C.c_int, [C.POINTER(isb_hpe_cfg), C.POINTER(_P)]),
@@ -70,6 +77,11 @@ SIGNATURES = {
     "isb_pose_distance": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
     "isb_hpe_select_person": (C.c_int, [_P, _P, _P, C.c_int32, C.c_float, _P, _P, _P]),
     "isb_hpe_select_person_host": (C.c_int, [_P, _P, _P, C.c_int32, C.c_float, _P, _P]),
+    "isb_rgb_create": (C.c_int, [C.POINTER(isb_rgb_cfg), C.POINTER(_P)]),
+    "isb_rgb_destroy": (None, [_P]),
+    "isb_rgb_load_weights": (C.c_int, [_P, _P, C.c_size_t]),
+    "isb_rgb_forward": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P]),
+    "isb_rgb_forward_host": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
     "isb_dist_unique_id": (C.c_int, [_P]),
     "isb_dist_create": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P)]),
     "isb_dist_destroy": (None, [_P]),

@@ -28,7 +28,7 @@ SOURCES = [
     "ar_api.cpp",
 ]
 # optional units appear as they are written
-for _extra in ("hpe_kernels.hip", "conv_kernels.hip", "conv_ws.hip", "hpe_api.cpp", "det_kernels.hip", "det_api.cpp", "dist_api.cpp"):
+for _extra in ("hpe_kernels.hip", "conv_kernels.hip", "conv_ws.hip", "hpe_api.cpp", "det_kernels.hip", "det_api.cpp", "dist_api.cpp", "rgb_kernels.hip", "rgb_api.cpp"):
     if os.path.exists(os.path.join(CSRC, _extra)):
         SOURCES.append(_extra)
 

@@ -13,6 +13,13 @@ using namespace isb;
 struct isb_ar {
     isb_ar_cfg cfg{};
     int L = 0, J = 0, D3 = 0, H = 0, T = 0, NT = 0, Tp = 0;
+    // input type (TRXConfig.input_type, utils/params.py:15,81): skeleton -> per-frame features = MLP(pose) [256]; hybrid ->
+    // [PostResNet(ResNet-50 trunk features) 256 | MLP(pose) 256] = 512 (model.py:296-303: RGB first). Din = the transformer's
+    // input width (trans_linear_in_dim): positional encoding, tuple Linear and the feature caches follow it.
+    bool hybrid = false;
+    int Din = 256;
+    DevBuf wpost, bpost;          // post_resnet.l1 (model.py:207-216)
+    DevBuf trunk;                 // per-chunk workspace: nothing (trunk features arrive from the caller); support-side staging
     int n = 0;                    // live classes
     bool weights = false, support = false;
     bool x3 = false, online = false;
@@ -47,7 +54,7 @@ int ensure_ws(isb_ar* h, int Bc) {
     h->ws_B = 0;                  // failure-atomic: published again only after every allocation succeeded
     ISB_TRY(h->win.alloc(B * L * h->D3 * 4));
     ISB_TRY(h->h1.alloc(B * L * h->H * 4));
-    ISB_TRY(h->qfeat.alloc(B * L * 256 * 4));
+    ISB_TRY(h->qfeat.alloc(B * L * h->Din * 4));
     ISB_TRY(h->proj.alloc(B * L * 512 * 4));
     ISB_TRY(h->KqF.alloc(B * h->NT * 4096 * 2));
     ISB_TRY(h->VqF.alloc(B * h->NT * 16 * 64 * 16));       // f32 V of the query tuples, 16 KiB per 32-tuple tile
@@ -74,19 +81,28 @@ int gemm(hipStream_t st, const float* A, int lda, const float* W, int ldw, const
 
 // skeleton MLP (model.py:164-180) + tuple projections of (features + PE) (model.py:26,75-78)
 int features_and_proj(isb_ar* h, hipStream_t st, const float* d_poses, int items, float* d_feat,
-                      float* d_h1, float* d_proj) {
-    const int M = items * h->L;
+                      float* d_h1, float* d_proj, const float* d_trunk = nullptr) {
+    const int M = items * h->L, Din = h->Din;
     ISB_TRY(gemm(st, d_poses, h->D3, h->w1.as<float>(), h->D3, h->b1.as<float>(), d_h1, h->H, M, h->H,
                  h->D3, GEMM_ACT_RELU));
-    ISB_TRY(gemm(st, d_h1, h->H, h->w2.as<float>(), h->H, h->b2.as<float>(), d_feat, 256, M, 256, h->H,
+    // the skeleton features fill columns [Din - 256, Din) of the feature rows (hybrid: behind the RGB features)
+    ISB_TRY(gemm(st, d_h1, h->H, h->w2.as<float>(), h->H, h->b2.as<float>(), d_feat + (Din - 256), Din, M, 256, h->H,
                  GEMM_ACT_RELU));
+    if (h->hybrid) {
+        // PostResNet (model.py:207-216): Linear(ReLU(trunk)), columns [0, 256) (model.py:296-303 appends RGB first)
+        GemmF32Args g{};
+        g.A = d_trunk; g.lda = 2048; g.W = h->wpost.as<float>(); g.ldw = 2048; g.bias = h->bpost.as<float>();
+        g.C = d_feat; g.ldc = Din; g.M = M; g.N = 256; g.K = 2048; g.add_period = 1; g.act = GEMM_ACT_NONE;
+        g.a_act = GEMM_ACT_RELU;
+        ISB_TRY(launch_gemm_f32(g, st));
+    }
     (void)d_proj;
     return ISB_OK;
 }
 
 int project(isb_ar* h, hipStream_t st, const float* d_feat, int items, float* d_proj) {
-    return gemm(st, d_feat, 256, h->wcat.as<float>(), 256, nullptr, d_proj, 512, items * h->L, 512, 256,
-                GEMM_ACT_NONE, h->pe.as<float>(), 256, h->L);
+    return gemm(st, d_feat, h->Din, h->wcat.as<float>(), h->Din, nullptr, d_proj, 512, items * h->L, 512, h->Din,
+                GEMM_ACT_NONE, h->pe.as<float>(), h->Din, h->L);
 }
 
 }  // namespace
@@ -145,9 +161,10 @@ extern "C" int isb_ar_load_weights(isb_ar* h, const void* blob, size_t nbytes) {
     ISB_TRY(blob_get(m, "features_extractor.sk.fc1.bias", H, 1, &b1));
     ISB_TRY(blob_get(m, "features_extractor.sk.fc2.weight", 256, H, &w2));
     ISB_TRY(blob_get(m, "features_extractor.sk.fc2.bias", 256, 1, &b2));
-    ISB_TRY(blob_get(m, "transformers.0.k_linear.weight", 128, 512, &wk));
+    const uint32_t Din = (uint32_t)h->Din;
+    ISB_TRY(blob_get(m, "transformers.0.k_linear.weight", 128, 2 * Din, &wk));
     ISB_TRY(blob_get(m, "transformers.0.k_linear.bias", 128, 1, &bk));
-    ISB_TRY(blob_get(m, "transformers.0.v_linear.weight", 128, 512, &wv));
+    ISB_TRY(blob_get(m, "transformers.0.v_linear.weight", 128, 2 * Din, &wv));
     ISB_TRY(blob_get(m, "transformers.0.v_linear.bias", 128, 1, &bv));
     ISB_TRY(blob_get(m, "transformers.0.norm_k.weight", 128, 1, &g));
     ISB_TRY(blob_get(m, "transformers.0.norm_k.bias", 128, 1, &be));
@@ -164,16 +181,23 @@ extern "C" int isb_ar_load_weights(isb_ar* h, const void* blob, size_t nbytes) {
     ISB_TRY(upload(h->b1, b1->data, b1->numel() * 4));
     ISB_TRY(upload(h->w2, w2->data, w2->numel() * 4));
     ISB_TRY(upload(h->b2, b2->data, b2->numel() * 4));
-    // factorised tuple Linear: rows [Ak | Bk | Av | Bv], each [128,256]
-    std::vector<float> wcat(512 * 256);
+    // factorised tuple Linear: rows [Ak | Bk | Av | Bv], each [128,Din]
+    std::vector<float> wcat((size_t)512 * Din);
     for (int o = 0; o < 128; ++o)
-        for (int k = 0; k < 256; ++k) {
-            wcat[(size_t)(o)*256 + k] = wk->data[(size_t)o * 512 + k];
-            wcat[(size_t)(128 + o) * 256 + k] = wk->data[(size_t)o * 512 + 256 + k];
-            wcat[(size_t)(256 + o) * 256 + k] = wv->data[(size_t)o * 512 + k];
-            wcat[(size_t)(384 + o) * 256 + k] = wv->data[(size_t)o * 512 + 256 + k];
+        for (uint32_t k = 0; k < Din; ++k) {
+            wcat[(size_t)(o)*Din + k] = wk->data[(size_t)o * 2 * Din + k];
+            wcat[(size_t)(128 + o) * Din + k] = wk->data[(size_t)o * 2 * Din + Din + k];
+            wcat[(size_t)(256 + o) * Din + k] = wv->data[(size_t)o * 2 * Din + k];
+            wcat[(size_t)(384 + o) * Din + k] = wv->data[(size_t)o * 2 * Din + Din + k];
         }
     ISB_TRY(upload(h->wcat, wcat.data(), wcat.size() * 4));
+    if (h->hybrid) {
+        const BlobTensor *wp, *bp;
+        ISB_TRY(blob_get(m, "post_resnet.l1.weight", 256, 2048, &wp));
+        ISB_TRY(blob_get(m, "post_resnet.l1.bias", 256, 1, &bp));
+        ISB_TRY(upload(h->wpost, wp->data, wp->numel() * 4));
+        ISB_TRY(upload(h->bpost, bp->data, 256 * 4));
+    }
     ISB_TRY(upload(h->bk, bk->data, 128 * 4));
     ISB_TRY(upload(h->bv, bv->data, 128 * 4));
     ISB_TRY(upload(h->gamma, g->data, 128 * 4));
@@ -187,15 +211,15 @@ extern "C" int isb_ar_load_weights(isb_ar* h, const void* blob, size_t nbytes) {
     ISB_TRY(upload(h->wf3, wf3->data, 64 * 4));
     ISB_TRY(upload(h->bf3, bf3->data, 4));
 
-    // positional table, first L rows, computed in f32 like model.py:17-23 (scale 0.1)
-    std::vector<float> pe((size_t)L * 256);
-    const float c = (float)(-(std::log(10000.0) / 256.0));
+    // positional table, first L rows, computed in f32 like model.py:17-23 (scale 0.1); d_model = trans_linear_in_dim
+    std::vector<float> pe((size_t)L * Din);
+    const float c = (float)(-(std::log(10000.0) / (double)Din));
     for (uint32_t pos = 0; pos < L; ++pos)
-        for (int i = 0; i < 128; ++i) {
+        for (uint32_t i = 0; i < Din / 2; ++i) {
             const float div = expf((float)(2 * i) * c);
             const float ang = (float)pos * div;
-            pe[(size_t)pos * 256 + 2 * i] = sinf(ang) * 0.1f;
-            pe[(size_t)pos * 256 + 2 * i + 1] = cosf(ang) * 0.1f;
+            pe[(size_t)pos * Din + 2 * i] = sinf(ang) * 0.1f;
+            pe[(size_t)pos * Din + 2 * i + 1] = cosf(ang) * 0.1f;
         }
     ISB_TRY(upload(h->pe, pe.data(), pe.size() * 4));
 
@@ -227,8 +251,39 @@ extern "C" int isb_ar_load_weights(isb_ar* h, const void* blob, size_t nbytes) {
     });
 }
 
+static int set_support_impl(isb_ar* h, const float* poses, const float* trunk, const float* features, int32_t n);
+
+extern "C" int isb_ar_set_input_type(isb_ar* h, int32_t type) {
+    return isb::guard([&]() -> int {
+    ISB_REQUIRE(h, ISB_ERR_INVALID, "null handle");
+    ISB_REQUIRE(type == ISB_AR_INPUT_SKELETON || type == ISB_AR_INPUT_HYBRID, ISB_ERR_INVALID, "unknown input type %d", type);
+    h->hybrid = type == ISB_AR_INPUT_HYBRID;
+    h->Din = h->hybrid ? 512 : 256;
+    h->weights = false;            // the tuple Linear's width and the feature caches depend on it: load the weights again
+    h->support = false;
+    h->ws_B = 0;
+    return ISB_OK;
+    });
+}
+
 extern "C" int isb_ar_set_support(isb_ar* h, const float* poses, const float* features, int32_t n) {
     return isb::guard([&]() -> int {
+    ISB_REQUIRE(h, ISB_ERR_INVALID, "null handle");
+    ISB_REQUIRE(!(h->hybrid && poses), ISB_ERR_STATE, "hybrid input type: raw support data goes through isb_ar_set_support_hybrid (poses + trunk features)");
+    return set_support_impl(h, poses, nullptr, features, n);
+    });
+}
+
+extern "C" int isb_ar_set_support_hybrid(isb_ar* h, const float* poses, const float* trunk, int32_t n) {
+    return isb::guard([&]() -> int {
+    ISB_REQUIRE(h && poses && trunk, ISB_ERR_INVALID, "null argument");
+    ISB_REQUIRE(h->hybrid, ISB_ERR_STATE, "isb_ar_set_support_hybrid needs isb_ar_set_input_type(ISB_AR_INPUT_HYBRID)");
+    return set_support_impl(h, poses, trunk, nullptr, n);
+    });
+}
+
+static int set_support_impl(isb_ar* h, const float* poses, const float* trunk, const float* features, int32_t n) {
+    {
     ISB_REQUIRE(h, ISB_ERR_INVALID, "null handle");
     ISB_REQUIRE(h->weights, ISB_ERR_STATE, "isb_ar_set_support before isb_ar_load_weights");
     ISB_REQUIRE((poses != nullptr) != (features != nullptr), ISB_ERR_INVALID,
@@ -239,16 +294,17 @@ extern "C" int isb_ar_set_support(isb_ar* h, const float* poses, const float* fe
     h->support = false;           // failure-atomic: the caches below are being replaced; isb_ar_infer refuses the handle
     h->n = 0;                     // until this call has succeeded
     const size_t rows = (size_t)n * h->L;
-    ISB_TRY(h->s_feat.alloc(rows * 256 * 4));
+    ISB_TRY(h->s_feat.alloc(rows * h->Din * 4));
     ISB_TRY(h->s_proj.alloc(rows * 512 * 4));
     if (poses) {
-        DevBuf dp, dh1;
+        DevBuf dp, dh1, dt;
         ISB_TRY(upload(dp, poses, rows * h->D3 * 4));
         ISB_TRY(dh1.alloc(rows * h->H * 4));
-        ISB_TRY(features_and_proj(h, st, dp.as<float>(), n, h->s_feat.as<float>(), dh1.as<float>(), nullptr));
+        if (h->hybrid) ISB_TRY(upload(dt, trunk, rows * 2048 * 4));
+        ISB_TRY(features_and_proj(h, st, dp.as<float>(), n, h->s_feat.as<float>(), dh1.as<float>(), nullptr, h->hybrid ? dt.as<float>() : nullptr));
         ISB_HIP(hipStreamSynchronize(st));
     } else {
-        ISB_HIP(hipMemcpy(h->s_feat.p, features, rows * 256 * 4, hipMemcpyHostToDevice));
+        ISB_HIP(hipMemcpy(h->s_feat.p, features, rows * h->Din * 4, hipMemcpyHostToDevice));
     }
     ISB_TRY(project(h, st, h->s_feat.as<float>(), n, h->s_proj.as<float>()));
     const size_t img = (size_t)n * h->NT * 4096 * 2;
@@ -274,7 +330,7 @@ extern "C" int isb_ar_set_support(isb_ar* h, const float* poses, const float* fe
     h->n = n;
     h->support = true;
     return ISB_OK;
-    });
+    }
 }
 
 extern "C" int isb_ar_get_support_features(isb_ar* h, float* out) {
@@ -282,14 +338,35 @@ extern "C" int isb_ar_get_support_features(isb_ar* h, float* out) {
     ISB_REQUIRE(h && out, ISB_ERR_INVALID, "null argument");
     ISB_REQUIRE(h->support, ISB_ERR_STATE, "no support set installed");
     ISB_HIP(hipSetDevice(h->cfg.device));
-    ISB_HIP(hipMemcpy(out, h->s_feat.p, (size_t)h->n * h->L * 256 * 4, hipMemcpyDeviceToHost));
+    ISB_HIP(hipMemcpy(out, h->s_feat.p, (size_t)h->n * h->L * h->Din * 4, hipMemcpyDeviceToHost));
     return ISB_OK;
     });
 }
 
+static int infer_impl(isb_ar* h, const float* d_windows, const float* d_trunk, int32_t B, float* d_logits, float* d_is_true,
+                      float* d_embed, void* stream);
+
 extern "C" int isb_ar_infer(isb_ar* h, const float* d_windows, int32_t B, float* d_logits, float* d_is_true,
                             float* d_embed, void* stream) {
     return isb::guard([&]() -> int {
+    ISB_REQUIRE(h, ISB_ERR_INVALID, "null handle");
+    ISB_REQUIRE(!h->hybrid, ISB_ERR_STATE, "hybrid input type: use isb_ar_infer_hybrid (windows + trunk features)");
+    return infer_impl(h, d_windows, nullptr, B, d_logits, d_is_true, d_embed, stream);
+    });
+}
+
+extern "C" int isb_ar_infer_hybrid(isb_ar* h, const float* d_windows, const float* d_trunk, int32_t B, float* d_logits,
+                                   float* d_is_true, float* d_embed, void* stream) {
+    return isb::guard([&]() -> int {
+    ISB_REQUIRE(h && d_trunk, ISB_ERR_INVALID, "null argument");
+    ISB_REQUIRE(h->hybrid, ISB_ERR_STATE, "isb_ar_infer_hybrid needs isb_ar_set_input_type(ISB_AR_INPUT_HYBRID)");
+    return infer_impl(h, d_windows, d_trunk, B, d_logits, d_is_true, d_embed, stream);
+    });
+}
+
+static int infer_impl(isb_ar* h, const float* d_windows, const float* d_trunk, int32_t B, float* d_logits, float* d_is_true,
+                      float* d_embed, void* stream) {
+    {
     ISB_REQUIRE(h && d_windows && d_logits && d_is_true, ISB_ERR_INVALID, "null argument");
     ISB_REQUIRE(B >= 1, ISB_ERR_INVALID, "batch %d < 1", B);
     ISB_REQUIRE(h->weights && h->support, ISB_ERR_STATE, "isb_ar_infer needs weights and a support set");
@@ -305,9 +382,9 @@ extern "C" int isb_ar_infer(isb_ar* h, const float* d_windows, int32_t B, float*
     for (int b0 = 0; b0 < B; b0 += Bc_max) {
         const int Bc = std::min(Bc_max, B - b0);
         const float* win = d_windows + (size_t)b0 * L * h->D3;
-        float* feat = d_embed ? d_embed + (size_t)b0 * L * 256 : h->qfeat.as<float>();
+        float* feat = d_embed ? d_embed + (size_t)b0 * L * h->Din : h->qfeat.as<float>();
         int32_t* chosen = h->chosen.as<int32_t>() + b0;
-        ISB_TRY(features_and_proj(h, st, win, Bc, feat, h->h1.as<float>(), nullptr));
+        ISB_TRY(features_and_proj(h, st, win, Bc, feat, h->h1.as<float>(), nullptr, d_trunk ? d_trunk + (size_t)b0 * L * 2048 : nullptr));
         ISB_TRY(project(h, st, feat, Bc, h->proj.as<float>()));
 
         ArTupleArgs ta{};
@@ -384,7 +461,7 @@ extern "C" int isb_ar_infer(isb_ar* h, const float* d_windows, int32_t B, float*
         ISB_TRY(launch_ar_disc_tail(da, st));
     }
     return ISB_OK;
-    });
+    }
 }
 
 extern "C" int isb_ar_infer_host(isb_ar* h, const float* windows, int32_t B, float* logits, float* is_true,
@@ -400,12 +477,12 @@ extern "C" int isb_ar_infer_host(isb_ar* h, const float* windows, int32_t B, flo
     ISB_TRY(dw.alloc(wbytes));
     ISB_TRY(dl.alloc((size_t)B * h->n * 4));
     ISB_TRY(di.alloc((size_t)B * 4));
-    if (embed) ISB_TRY(de.alloc((size_t)B * h->L * 256 * 4));
+    if (embed) ISB_TRY(de.alloc((size_t)B * h->L * h->Din * 4));
     ISB_HIP(hipMemcpyAsync(dw.p, windows, wbytes, hipMemcpyHostToDevice, st));
     ISB_TRY(isb_ar_infer(h, dw.as<float>(), B, dl.as<float>(), di.as<float>(), embed ? de.as<float>() : nullptr, st));
     ISB_HIP(hipMemcpyAsync(logits, dl.p, (size_t)B * h->n * 4, hipMemcpyDeviceToHost, st));
     ISB_HIP(hipMemcpyAsync(is_true, di.p, (size_t)B * 4, hipMemcpyDeviceToHost, st));
-    if (embed) ISB_HIP(hipMemcpyAsync(embed, de.p, (size_t)B * h->L * 256 * 4, hipMemcpyDeviceToHost, st));
+    if (embed) ISB_HIP(hipMemcpyAsync(embed, de.p, (size_t)B * h->L * h->Din * 4, hipMemcpyDeviceToHost, st));
     ISB_HIP(hipStreamSynchronize(st));
     return ISB_OK;
     });

@@ -92,7 +92,8 @@ __device__ __forceinline__ float silu_fast(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
 
-// activation codes (ConvArgs.act): 0 none, 1 SiLU (the pose backbone), 2 Mish, 3 LeakyReLU(0.1) (the YOLOv4 detector)
+// activation codes (ConvArgs.act): 0 none, 1 SiLU (the pose backbone), 2 Mish, 3 LeakyReLU(0.1) (the YOLOv4 detector),
+// 4 ReLU (the ResNet-50 of the RGB / hybrid action-recognition branch)
 __device__ __forceinline__ float mish_fast(float x) {
     // x * tanh(softplus(x)) with n = e^x: tanh(ln(1 + n)) = n (n + 2) / (n (n + 2) + 2); one v_exp + one v_rcp.
     // n is clamped so that n (n + 2) stays finite (for x > 20 the factor is 1 to f32 precision anyway)
@@ -101,7 +102,7 @@ __device__ __forceinline__ float mish_fast(float x) {
     return x * w * __builtin_amdgcn_rcpf(w + 2.0f);
 }
 __device__ __forceinline__ float act_other(int act, float x) {     // act >= 2 (wave-uniform)
-    return act == 2 ? mish_fast(x) : (x > 0.f ? x : 0.1f * x);
+    return act == 2 ? mish_fast(x) : (act == 4 ? fmaxf(x, 0.f) : (x > 0.f ? x : 0.1f * x));
 }
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;

@@ -96,13 +96,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
                     if constexpr (BIAS_LDS) bs = *reinterpret_cast<const float4*>(lds + bias_off + nl * 4);
                     else bs = *reinterpret_cast<const float4*>(p.bias + n);
                     v0 += bs.x; v1 += bs.y; v2 += bs.z; v3 += bs.w;
-                    if (p.act == 1) { v0 = silu_fast(v0); v1 = silu_fast(v1); v2 = silu_fast(v2); v3 = silu_fast(v3); }
-                    else if (p.act) { v0 = act_other(p.act, v0); v1 = act_other(p.act, v1); v2 = act_other(p.act, v2); v3 = act_other(p.act, v3); }
+                    const int act_now = p.act_after_res ? 0 : p.act;
+                    if (act_now == 1) { v0 = silu_fast(v0); v1 = silu_fast(v1); v2 = silu_fast(v2); v3 = silu_fast(v3); }
+                    else if (act_now) { v0 = act_other(act_now, v0); v1 = act_other(act_now, v1); v2 = act_other(act_now, v2); v3 = act_other(act_now, v3); }
                     if (p.res && mok) {       // (requesting all residual pieces up front measured 5-7 % slower, twice)
                         const uint2 rr = *reinterpret_cast<const uint2*>(p.res + (size_t)m * p.Cout + n);
                         v0 += T16<F16>::lo(rr.x); v1 += T16<F16>::hi(rr.x);
                         v2 += T16<F16>::lo(rr.y); v3 += T16<F16>::hi(rr.y);
                     }
+                    if (p.act_after_res && p.act) { v0 = act_other(p.act, v0); v1 = act_other(p.act, v1); v2 = act_other(p.act, v2); v3 = act_other(p.act, v3); }
                 }
                 uint2 pk;
                 pk.x = (uint32_t)T16<F16>::from_f32(v0) | ((uint32_t)T16<F16>::from_f32(v1) << 16);
@@ -1841,6 +1843,10 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
         }
     }
     const bool is_g1 = (v >= 131 && v <= 153) || (v >= 191 && v <= 197);
+    if (a.act_after_res && (a.act < 2 || a.out_f32 || aa.splits > 1 || v == 171 || (v >= 181 && v <= 188) || !ISB_EPI_SHARED)) {
+        set_error("conv_igemm: act_after_res takes act 2-4 on the kernels with the shared bf16 epilogue (variant %d)", v);
+        return ISB_ERR_INVALID;
+    }
     if (a.f16 && !(v == 131 || v == 132 || v == 138 || v == 141 || v == 144 || v == 146 || v == 147 || v == 149 || v == 185 || v == 186)) {
         set_error("conv_igemm: fp16 operands are implemented by variants 131 / 132 / 138, 141 / 144 / 146 / 147 / 149 and 185 / 186 (got %d)", v);
         return ISB_ERR_INVALID;

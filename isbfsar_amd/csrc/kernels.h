@@ -126,7 +126,8 @@ struct ConvArgs {
     void* out;              // bf16 (or f32 when out_f32) [M,Cout]
     int B, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad;
     int M, K;
-    int act;                // 1 = SiLU
+    int act;                // 0 none, 1 SiLU, 2 Mish, 3 LeakyReLU(0.1), 4 ReLU
+    int act_after_res;      // 1: out = act(conv + bias + res) (a ResNet bottleneck's tail) instead of act(conv + bias) + res; shared epilogue only
     int out_f32;
     // in / w / res / out (unless out_f32) hold IEEE fp16 instead of bf16: the two 8x8 stages and the 640 -> 1280 convolution of
     // the pose backbone under isb_hpe_cfg.precision 0. Implemented by the gemm1x1 variants the 8x8 stages
@@ -270,6 +271,18 @@ int launch_select_person(const float* boxes, const float* confs, int B, int n_an
                          int32_t* bbox, uint8_t* found, hipStream_t st);
 int launch_pose_windows(const float* joints, int n_cam, int n_frames, int J, int L, float* windows, hipStream_t st);
 int launch_pose_distance(const float* joints, int n, int J, float* distance, hipStream_t st);
+
+// ---------------------------------------------------------------- rgb_kernels.hip (ResNet-50 trunk of the hybrid AR branch)
+struct RgbStemArgs {
+    const float* in;        // f32 images: [N,3,H,W] (nchw = 1, what main.py:91 hands over) or [N,H,W,3]
+    const float* w;         // f32 [64][7][7][3], BN scale folded
+    const float* bias;      // [64] folded-BN shift
+    uint16_t* out;          // bf16 [N,H/2,W/2,64], ReLU applied
+    int N, H, W, nchw;
+};
+int launch_rgb_stem(const RgbStemArgs& a, hipStream_t st);
+int launch_maxpool3x3s2(const uint16_t* in, uint16_t* out, int N, int H, int W, int C, hipStream_t st);   // padding 1
+int launch_avgpool(const uint16_t* in, float* out, int N, int HW, int C, hipStream_t st);                 // -> f32 [N,C]
 
 // ---------------------------------------------------------------- det_kernels.hip (YOLOv4 person detector)
 int launch_det_preprocess(const uint8_t* frames, int B, int FH, int FW, float* out, hipStream_t st);

@@ -31,14 +31,24 @@ class ArEngine:
     (reference modules/ar/utils/model.py:291-328) for B windows sharing one support set."""
 
     def __init__(self, seq_len: int, n_joints: int, way_max: int, device: int = 0,
-                 precision: Union[int, str] = "bf16", max_batch: int = 1024):
+                 precision: Union[int, str] = "bf16", max_batch: int = 1024, input_type: str = "skeleton"):
+        """input_type (TRXConfig.input_type): "skeleton" (features = MLP(pose), 256 wide) or "hybrid" (features =
+        [PostResNet(ResNet-50 trunk) | MLP(pose)], 512 wide; set_support / infer then also take trunk features
+        [.., L, 2048], e.g. from RgbEngine)."""
         prec = {"bf16": _lib.ISB_AR_PREC_BF16, "bf16x3": _lib.ISB_AR_PREC_BF16X3}.get(precision, precision)
+        if input_type not in ("skeleton", "hybrid"):
+            raise ValueError(f"input_type {input_type!r}: 'skeleton' or 'hybrid' (the reference's 'rgb' type is inconsistent with "
+                             "its own model: utils/params.py:81 sizes the transformer for 1000-wide features, model.py:274-277 makes 256)")
         self.L, self.J, self.way_max, self.device = seq_len, n_joints, way_max, device
         self.precision = "bf16x3" if prec == _lib.ISB_AR_PREC_BF16X3 else "bf16"
+        self.input_type = input_type
+        self.d_in = 512 if input_type == "hybrid" else 256
         self.n = 0
         self._h = C.c_void_p()
         cfg = _lib.isb_ar_cfg(seq_len, n_joints, way_max, device, prec, max_batch)
         _lib.check(_lib.lib().isb_ar_create(C.byref(cfg), C.byref(self._h)), "isb_ar_create")
+        if input_type == "hybrid":
+            _lib.check(_lib.lib().isb_ar_set_input_type(self._h, 1), "isb_ar_set_input_type")
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -60,29 +70,41 @@ class ArEngine:
         self.n = 0
 
     # -- support set ---------------------------------------------------------------------
-    def set_support(self, poses: Optional[np.ndarray] = None, features: Optional[np.ndarray] = None):
+    def set_support(self, poses: Optional[np.ndarray] = None, features: Optional[np.ndarray] = None,
+                    trunk: Optional[np.ndarray] = None):
+        """poses [n,L,3J] (hybrid: with trunk [n,L,2048]) or cached features [n,L,d_in]"""
         if (poses is None) == (features is None):
-            raise ValueError("give exactly one of poses [n,L,3J] / features [n,L,256]")
+            raise ValueError(f"give exactly one of poses [n,L,3J] / features [n,L,{self.d_in}]")
         if poses is not None:
             poses = _f32c(poses)
             n = poses.shape[0]
             _f32c(poses, (n, self.L, 3 * self.J))
+            if self.input_type == "hybrid":
+                if trunk is None:
+                    raise ValueError("hybrid input type: poses need the RGB trunk features [n,L,2048] beside them")
+                trunk = _f32c(trunk, (n, self.L, 2048))
+                _lib.check(_lib.lib().isb_ar_set_support_hybrid(self._h, _ptr(poses), _ptr(trunk), n), "isb_ar_set_support_hybrid")
+                self.n = n
+                return
         else:
             features = _f32c(features)
             n = features.shape[0]
-            _f32c(features, (n, self.L, 256))
+            _f32c(features, (n, self.L, self.d_in))
         _lib.check(_lib.lib().isb_ar_set_support(self._h, _ptr(poses), _ptr(features), n), "isb_ar_set_support")
         self.n = n
 
     def support_features(self) -> np.ndarray:
-        out = np.empty((self.n, self.L, 256), np.float32)
+        out = np.empty((self.n, self.L, self.d_in), np.float32)
         _lib.check(_lib.lib().isb_ar_get_support_features(self._h, _ptr(out)), "isb_ar_get_support_features")
         return out
 
     # -- inference -----------------------------------------------------------------------
-    def infer(self, windows, want_embed: bool = False):
+    def infer(self, windows, want_embed: bool = False, trunk=None):
         """windows [B,L,3J]: numpy -> numpy results; torch CUDA tensor -> torch CUDA results
-        (asynchronous on the current stream). Returns (logits [B,n], is_true [B], embed|None)."""
+        (asynchronous on the current stream). Returns (logits [B,n], is_true [B], embed|None).
+        hybrid input type: trunk [B,L,2048] (same kind of array as windows) beside the windows; embed is 512 wide."""
+        if self.input_type == "hybrid":
+            return self._infer_hybrid(windows, trunk, want_embed)
         if isinstance(windows, np.ndarray):
             w = _f32c(windows)
             B = w.shape[0]
@@ -110,6 +132,28 @@ class ArEngine:
         _lib.check(_lib.lib().isb_ar_infer(self._h, w.data_ptr(), B, logits.data_ptr(), is_true.data_ptr(),
                                            embed.data_ptr() if want_embed else None, C.c_void_p(stream)),
                    "isb_ar_infer")
+        return logits, is_true, embed
+
+    def _infer_hybrid(self, windows, trunk, want_embed):
+        import torch
+        if trunk is None:
+            raise ValueError("hybrid input type: infer() needs trunk [B,L,2048]")
+        host = isinstance(windows, np.ndarray)
+        dev = torch.device("cuda", self.device)
+        w = (torch.from_numpy(_f32c(windows)).to(dev) if host else windows).contiguous().float()
+        t = (torch.from_numpy(_f32c(trunk)).to(dev) if isinstance(trunk, np.ndarray) else trunk).contiguous().float()
+        B = w.shape[0]
+        if tuple(w.shape) != (B, self.L, 3 * self.J) or tuple(t.shape) != (B, self.L, 2048):
+            raise ValueError(f"expected [B,{self.L},{3 * self.J}] and [B,{self.L},2048], got {tuple(w.shape)} {tuple(t.shape)}")
+        logits = torch.empty((B, self.n), dtype=torch.float32, device=dev)
+        is_true = torch.empty((B,), dtype=torch.float32, device=dev)
+        embed = torch.empty((B, self.L, 512), dtype=torch.float32, device=dev) if want_embed else None
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(_lib.lib().isb_ar_infer_hybrid(self._h, w.data_ptr(), t.data_ptr(), B, logits.data_ptr(), is_true.data_ptr(),
+                                                  embed.data_ptr() if want_embed else None, C.c_void_p(stream)), "isb_ar_infer_hybrid")
+        if host:
+            torch.cuda.synchronize(dev)
+            return logits.cpu().numpy(), is_true.cpu().numpy(), None if embed is None else embed.cpu().numpy()
         return logits, is_true, embed
 
     def last_chosen(self, B: int) -> np.ndarray:

@@ -74,14 +74,21 @@ def uniform(name: str, shape: Tuple[int, ...], lo: float, hi: float, seed: int =
 #   TemporalCrossTransformer modules/ar/utils/model.py:31-57
 #   Discriminator            modules/ar/utils/model.py:183-192, sized at :283-285
 # --------------------------------------------------------------------------------------
-def ar_state_shapes(seq_len: int, n_joints: int, d_in: int = 256, d_out: int = 128) -> "OrderedDict[str, Tuple[int, ...]]":
+def ar_state_shapes(seq_len: int, n_joints: int, d_in: int = 256, d_out: int = 128, hybrid: bool = False) -> "OrderedDict[str, Tuple[int, ...]]":
+    """hybrid (TRXConfig.input_type == "hybrid", utils/params.py:81): per-frame features = [PostResNet(rgb trunk) 256 | skeleton MLP 256],
+    so the transformer's input width is 512 and post_resnet.l1 (model.py:207-216) is on the path."""
     L, J = seq_len, n_joints
     T = L * (L - 1) // 2
+    if hybrid:
+        d_in = 512
     s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    if hybrid:
+        s["post_resnet.l1.weight"] = (256, 2048)
+        s["post_resnet.l1.bias"] = (256,)
     s["features_extractor.sk.fc1.weight"] = (6 * J, 3 * J)
     s["features_extractor.sk.fc1.bias"] = (6 * J,)
-    s["features_extractor.sk.fc2.weight"] = (d_in, 6 * J)
-    s["features_extractor.sk.fc2.bias"] = (d_in,)
+    s["features_extractor.sk.fc2.weight"] = (256, 6 * J)
+    s["features_extractor.sk.fc2.bias"] = (256,)
     s["transformers.0.k_linear.weight"] = (d_out, 2 * d_in)
     s["transformers.0.k_linear.bias"] = (d_out,)
     s["transformers.0.v_linear.weight"] = (d_out, 2 * d_in)
@@ -100,7 +107,7 @@ def ar_state_shapes(seq_len: int, n_joints: int, d_in: int = 256, d_out: int = 1
 
 
 def make_ar_state(seq_len: int, n_joints: int, seed: int = 0, gain: float = 1.0, disc_gain: float = 1.0,
-                  norm_gain: float = 1.0) -> "OrderedDict[str, np.ndarray]":
+                  norm_gain: float = 1.0, hybrid: bool = False) -> "OrderedDict[str, np.ndarray]":
     """Deterministic TRXOS (skeleton) weights: U(-g/sqrt(fan_in), g/sqrt(fan_in)) like
     torch's Linear default; LayerNorm gamma in [0.8,1.2], beta in [-0.1,0.1] so that the
     affine part of ``norm_k`` (model.py:46) is exercised.
@@ -110,7 +117,7 @@ def make_ar_state(seq_len: int, n_joints: int, seed: int = 0, gain: float = 1.0,
     the synthetic windows, so a wrong ``diff`` shows. ``norm_gain`` multiplies ``norm_k.weight`` (a trained
     LayerNorm gain: sharper tuple attention, model.py:46,101-109)."""
     out: "OrderedDict[str, np.ndarray]" = OrderedDict()
-    shapes = ar_state_shapes(seq_len, n_joints)
+    shapes = ar_state_shapes(seq_len, n_joints, hybrid=hybrid)
     for name, shape in shapes.items():
         if name.endswith("norm_k.weight"):
             out[name] = uniform(name, shape, 0.8, 1.2, seed)
@@ -177,7 +184,7 @@ def unpack_blob(blob: bytes) -> "OrderedDict[str, np.ndarray]":
     return out
 
 
-def state_from_torch(state_dict: Mapping[str, "object"], keys: Iterable[str] | None = None) -> Dict[str, np.ndarray]:
+def state_from_torch(state_dict: Mapping[str, "object"], keys: Iterable[str] | None = None, hybrid: bool = False) -> Dict[str, np.ndarray]:
     """Convert a torch ``state_dict`` (e.g. the reference's ``DISC.pth['model_state_dict']``,
     ``modules/ar/ar.py:17-19``) into the numpy mapping ``pack_blob`` takes.
 
@@ -187,14 +194,15 @@ def state_from_torch(state_dict: Mapping[str, "object"], keys: Iterable[str] | N
       ``utils/rename_torch_layers_and_parameters.py:11`` (``features_extractor`` -> ``features_extractor.sk``):
       the same rename is applied here to keys that do not carry the ``.sk`` level yet;
     * ``post_resnet.*`` (RGB branch, zero-filled by that script, lines 12-13) is not on the skeleton path and
-      is dropped."""
+      is dropped -- unless ``hybrid``: then ``post_resnet.l1.*`` is kept (it is on the hybrid path; the ResNet-50 trunk under
+      ``features_extractor.rgb.*`` goes through ``resnet50.state_from_torch`` into the RGB engine's own blob)."""
     out = {}
     for k, v in state_dict.items():
         k2 = k.replace(".module", "")
         # the RGB branch is not on the skeleton path: drop it BEFORE the rename below would hide its prefix
-        if k2.startswith("post_resnet.") or k2.startswith("features_extractor.rgb."):
+        if k2.startswith("features_extractor.rgb.") or (k2.startswith("post_resnet.") and not hybrid):
             continue
-        if k2.startswith("features_extractor.") and not k2.startswith("features_extractor.sk."):
+        if k2.startswith("features_extractor.") and not k2.startswith("features_extractor.sk.") and not k2.startswith("post_resnet."):
             k2 = "features_extractor.sk." + k2[len("features_extractor."):]
         if keys is not None and k2 not in keys:
             continue

@@ -64,6 +64,30 @@ class TRXOSOracle:
         return np.maximum(_linear(h, w["features_extractor.sk.fc2.weight"],
                                   w["features_extractor.sk.fc2.bias"]), 0)
 
+    # -- model.py:207-216 (PostResNet) + model.py:296-303 / 309-316 (feature concat, RGB first): input_type "hybrid"
+    def post_resnet(self, trunk: np.ndarray) -> np.ndarray:
+        """trunk [..., 2048] = output of the ResNet-50 trunk (global average pool) -> [..., 256]"""
+        w = self.w
+        return _linear(np.maximum(trunk.astype(self.dtype), 0), w["post_resnet.l1.weight"], w["post_resnet.l1.bias"])
+
+    def features(self, poses: np.ndarray, trunk: Optional[np.ndarray] = None) -> np.ndarray:
+        """skeleton: MLP(poses) [.., L, 256]; hybrid: [PostResNet(trunk) | MLP(poses)] [.., L, 512]"""
+        sk = self.mlp(poses)
+        if trunk is None:
+            return sk
+        return np.concatenate([self.post_resnet(trunk), sk], axis=-1)
+
+    def forward_hybrid(self, ss_poses, ss_trunk, n_classes: int, q_poses, q_trunk, ss_features=None) -> Dict[str, np.ndarray]:
+        """TRXOS.forward with query_data = {"rgb", "sk"} (model.py:291-328), the RGB side given as trunk features [.., L, 2048]"""
+        assert self.d_in == 512
+        q_feats = self.features(q_poses, q_trunk)
+        if ss_features is None:
+            ss_features = self.features(ss_poses, ss_trunk)
+        logits, diffs = self.cross_transformer(np.asarray(ss_features, self.dtype), n_classes, q_feats)
+        chosen = np.argmax(logits, axis=1)
+        is_true = self.discriminator(diffs[np.arange(q_poses.shape[0]), chosen])
+        return {"logits": logits, "is_true": is_true, "support_features": ss_features, "query_features": q_feats, "chosen": chosen}
+
     # -- model.py:65-84
     def tuples_kv(self, feats: np.ndarray):
         """feats [..., L, 256] (pre-PE) -> K [..., T, 128] (LayerNorm'ed), V [..., T, 128]."""

@@ -154,6 +154,77 @@ def gen_ar_stream(tag: str, L: int, J: int, way: int, n_frames: int, seed: int):
     print(f"ar_stream_{tag}: {len(probs)} calls, probs[0]={probs[0]}")
 
 
+def gen_ar_hybrid(tag: str, L: int, J: int, way: int, B: int, seed: int):
+    """SURVEY 8f row 4 tail -- the HYBRID input type (TRXConfig.input_type = "hybrid", utils/params.py:81: transformer input 512):
+    the reference's TRXOS with `{"rgb", "sk"}` inputs (model.py:270-277, 296-316). torchvision is not installed, so
+    `resnet50(pretrained=True)` (model.py:275) is a stand-in trunk of the same interface -- children = [1x1 conv 3 -> 2048,
+    global average pool, fc]; TRXOS drops the last child exactly as it does for the real network -- which pins everything
+    AFTER the trunk: PostResNet (ReLU + Linear 2048 -> 256), the [rgb | sk] concatenation order, the 512-wide positional
+    encoding and tuple Linear, the discriminator. The ResNet-50 itself stays unpinned (oracle/resnet50_oracle.py). The
+    fixture stores the trunk's outputs (the [.., L, 2048] tensors the HIP path takes from its own ResNet-50 engine)."""
+    import torch
+
+    _stub_torchvision()
+
+    class StandInTrunk(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv1 = torch.nn.Conv2d(3, 2048, 1, bias=False)
+            self.avgpool = torch.nn.AdaptiveAvgPool2d(1)
+            self.fc = torch.nn.Linear(2048, 10)
+
+    sys.modules["torchvision.models"].resnet50 = lambda pretrained=True: StandInTrunk()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        import modules.ar.utils.model as ref_model
+        from utils.params import TRXConfig
+    finally:
+        os.chdir(cwd)
+    ref_model.resnet50 = sys.modules["torchvision.models"].resnet50      # model.py:6 bound the name at import time
+    args = TRXConfig()
+    args.device = "cpu"
+    args.input_type = "hybrid"
+    args.trans_linear_in_dim = 512                                      # utils/params.py:81
+    args.seq_len, args.n_joints, args.way = L, J, way
+    torch.manual_seed(seed)
+    net = ref_model.TRXOS(args).eval()
+    state = weights.make_ar_state(L, J, seed=seed, hybrid=True)
+    sd = net.state_dict()
+    new = {k: (torch.from_numpy(np.array(state[k])) if k in state else v) for k, v in sd.items()}
+    for k in state:
+        assert k in sd and tuple(sd[k].shape) == state[k].shape, k
+    net.load_state_dict(new)
+    ss = synth.skeleton_windows(way, L, J, seed=seed + 100)
+    q = synth.skeleton_windows(B, L, J, seed=seed + 200)
+    rng = np.random.default_rng(seed)
+    ss_img = rng.normal(0, 1, (way, L, 3, 8, 8)).astype(np.float32)
+    q_img = rng.normal(0, 1, (B, L, 3, 8, 8)).astype(np.float32)
+    labels = torch.arange(way, dtype=torch.int32)[None]
+    with torch.no_grad():
+        trunk = net.features_extractor["rgb"]
+        ss_trunk = trunk(torch.from_numpy(ss_img).reshape(-1, 3, 8, 8)).reshape(way, L, -1).numpy()
+        q_trunk = trunk(torch.from_numpy(q_img).reshape(-1, 3, 8, 8)).reshape(B, L, -1).numpy()
+        logits, is_true, qfeat = [], [], []
+        for b in range(B):
+            o = net({"rgb": torch.from_numpy(ss_img)[None], "sk": torch.from_numpy(ss)[None]}, labels,
+                    {"rgb": torch.from_numpy(q_img[b:b + 1]), "sk": torch.from_numpy(q[b:b + 1])})
+            logits.append(o["logits"].numpy()[0])
+            is_true.append(o["is_true"].numpy()[0])
+            sf = o["support_features"].numpy()[0]
+            if b == 0:      # cached-feature call (ar.py:56-61) equals the raw call
+                o2 = net(None, labels, {"rgb": torch.from_numpy(q_img[b:b + 1]), "sk": torch.from_numpy(q[b:b + 1])},
+                         ss_features=o["support_features"])
+                assert np.array_equal(o2["logits"].numpy(), o["logits"].numpy())
+    np.savez_compressed(os.path.join(OUT, f"ar_hybrid_{tag}.npz"), L=L, J=J, way=way, B=B, seed=seed,
+                        ss_trunk=ss_trunk, q_trunk=q_trunk,
+                        ss_digest=digest(ss), q_digest=digest(q), logits=np.stack(logits), is_true=np.stack(is_true),
+                        support_features=sf)
+    print(f"ar_hybrid_{tag}: logits[0]={logits[0]} is_true={np.stack(is_true).ravel()} trunk |max|={np.abs(q_trunk).max():.3f}")
+
+
 def gen_ar_checkpoint(tag: str, L: int, J: int, way: int, B: int, torch_seed: int):
     """SURVEY 8f row 3 -- pins the checkpoint converter (isbfsar_amd/weights.state_from_torch). The reference's TRXOS is
     instantiated with torch's DEFAULT initialisation (seeded), i.e. a state_dict the reference itself produced, in the
@@ -213,7 +284,7 @@ def gen_ar_checkpoint(tag: str, L: int, J: int, way: int, B: int, torch_seed: in
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["ar", "hpe", "ckpt"]
+    which = sys.argv[1:] or ["ar", "hpe", "ckpt", "hybrid"]
     if "ar" in which:
         gen_ar("ref_16_30_5", 16, 30, 5, B=3, seed=0, keep_intermediates=True)
         gen_ar("bl_30_122_60", 30, 122, 60, B=2, seed=1, keep_intermediates=False)
@@ -223,6 +294,8 @@ def main():
         # resolving power: discriminator weights x6 (is_true spans 0.0-1.0 instead of 0.50-0.51) and LayerNorm gain x3
         gen_ar("sharp_16_30_5", 16, 30, 5, B=8, seed=2, keep_intermediates=False, disc_gain=6.0, norm_gain=3.0)
         gen_ar("sharp_30_122_60", 30, 122, 60, B=4, seed=2, keep_intermediates=False, disc_gain=6.0, norm_gain=3.0)
+    if "hybrid" in which:
+        gen_ar_hybrid("16_30_5", 16, 30, 5, B=3, seed=4)
     if "ckpt" in which or not sys.argv[1:]:
         gen_ar_checkpoint("ref_16_30_5", 16, 30, 5, B=4, torch_seed=1234)
     if "hpe" in which:

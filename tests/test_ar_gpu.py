@@ -319,3 +319,31 @@ def test_reference_checkpoint_through_converter(golden_dir, dialect):
         np.testing.assert_allclose(_softmax(logits), _softmax(g["logits"]), rtol=0, atol=ATOL_PROB)
         np.testing.assert_allclose(is_true, g["is_true"][:, 0], rtol=0, atol=ATOL_PROB)
         np.testing.assert_allclose(embed, g["qfeat"], rtol=0, atol=ATOL_F32)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+def test_hybrid_input_type_matches_reference_golden(golden_dir, precision):
+    """input_type "hybrid" (SURVEY 8f row 4 tail; model.py:207-216, 270-277, 296-316): PostResNet on the RGB trunk features,
+    [rgb | sk] features, 512-wide transformer input -- against what the reference's TRXOS computed with a stand-in trunk
+    (oracle/gen_golden.py::gen_ar_hybrid); raw support data and cached support features give the same bits."""
+    from isbfsar_amd.engine import ArEngine
+    g = np.load(os.path.join(golden_dir, "ar_hybrid_16_30_5.npz"))
+    L, J, way, B, seed = (int(g[k]) for k in ("L", "J", "way", "B", "seed"))
+    ss = synth.skeleton_windows(way, L, J, seed=seed + 100)
+    q = synth.skeleton_windows(B, L, J, seed=seed + 200)
+    eng = ArEngine(L, J, way, device=0, precision=precision, input_type="hybrid")
+    eng.load_weights(weights.make_ar_state(L, J, seed=seed, hybrid=True))
+    eng.set_support(poses=ss, trunk=g["ss_trunk"])
+    logits, is_true, embed = eng.infer(q, want_embed=True, trunk=g["q_trunk"])
+    np.testing.assert_allclose(logits, g["logits"], rtol=0, atol=ATOL_LOGIT[precision])
+    np.testing.assert_allclose(_softmax(logits), _softmax(g["logits"]), rtol=0, atol=ATOL_PROB)
+    np.testing.assert_allclose(is_true, g["is_true"][:, 0], rtol=0, atol=ATOL_PROB)
+    sf = eng.support_features()
+    assert sf.shape == (way, L, 512) and embed.shape == (B, L, 512)
+    np.testing.assert_allclose(sf, g["support_features"], rtol=0, atol=ATOL_F32)
+    eng.set_support(features=sf)
+    logits2, is_true2, _ = eng.infer(q, trunk=g["q_trunk"])
+    assert np.array_equal(logits2, logits) and np.array_equal(is_true2, is_true)
+    # the skeleton-only calls are refused on a hybrid handle, loudly
+    with pytest.raises(Exception):
+        eng.set_support(poses=ss)

@@ -115,3 +115,23 @@ def test_converter_on_reference_checkpoint(golden_dir, dialect):
     np.testing.assert_allclose(out["logits"], g["logits"], rtol=0, atol=2e-5)
     np.testing.assert_allclose(out["is_true"], g["is_true"], rtol=0, atol=2e-6)
     np.testing.assert_allclose(out["query_features"], g["qfeat"], rtol=0, atol=2e-6)
+
+
+def test_trxos_oracle_hybrid_matches_reference(golden_dir):
+    """input_type "hybrid" (utils/params.py:81, model.py:270-277, 296-316): PostResNet on the RGB trunk's features, the
+    [rgb | sk] concatenation, 512-wide transformer input -- against the reference's TRXOS run with a stand-in trunk
+    (oracle/gen_golden.py::gen_ar_hybrid); the fixture carries the trunk outputs."""
+    g = _load(golden_dir, "ar_hybrid_16_30_5.npz")
+    L, J, way, B, seed = (int(g[k]) for k in ("L", "J", "way", "B", "seed"))
+    state = weights.make_ar_state(L, J, seed=seed, hybrid=True)
+    assert state["transformers.0.k_linear.weight"].shape == (128, 1024) and state["post_resnet.l1.weight"].shape == (256, 2048)
+    ss = synth.skeleton_windows(way, L, J, seed=seed + 100)
+    q = synth.skeleton_windows(B, L, J, seed=seed + 200)
+    assert _digest(ss) == str(g["ss_digest"]) and _digest(q) == str(g["q_digest"])
+    net = TRXOSOracle(state, L, J, d_in=512)
+    out = net.forward_hybrid(ss, g["ss_trunk"], way, q, g["q_trunk"])
+    np.testing.assert_allclose(out["logits"], g["logits"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(out["is_true"], g["is_true"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(out["support_features"], g["support_features"], rtol=0, atol=2e-6)
+    out2 = net.forward_hybrid(None, None, way, q, g["q_trunk"], ss_features=out["support_features"])
+    assert np.array_equal(out2["logits"], out["logits"])
