@@ -2366,33 +2366,40 @@ __global__ __launch_bounds__(256) void dwconv3x3_pool_kernel(DwArgs p) {
     }
 }
 
-// 8 x 8 maps (the last two stages: 2304 / 3840 channels, 31 of the 57 depthwise launches). On these the kernel above moves
-// its bytes at 3.5 TB/s against 5.3 on the 16 x 16 maps: a workgroup's working set is 16 KiB (one sample x 128 channels), but its
-// threads request it 4.5 times over through the texture path (six 16-byte columns x three rows per four outputs), and only a
-// few hundred bytes per thread are ever in flight. Here the slab goes to LDS ONCE, as 64 fully coalesced 256-byte pixel rows
-// (every thread has its four 16-byte loads in flight at the start), inside a ring of zero pixels -- TF-SAME padding becomes
-// data -- and the taps read LDS (conflict-free: the 16 lanes of a ds_read_b128 group cover one pixel's 256 bytes). Same tap
-// order, same accumulators, same pool order as dwconv3x3_pool_kernel<1>: bit-identical (tested).
-template <bool F16>
-__global__ __launch_bounds__(256) void dwconv3x3_map8_kernel(DwArgs p) {
-    __shared__ __attribute__((aligned(16))) uint4 tile[10 * 10 * 16];     // [y + 1][x + 1][chunk of 8 channels]
-    __shared__ float red[16][129];
+// Whole-sample maps of 8 x 8 and 16 x 16 pixels at stride 1 (stages 3-6: 54 of the 61 depthwise launches). On these the kernel
+// above moved its bytes at 3.5 TB/s (5.0-5.5 on the two stride-2 launches): a workgroup's working set is 16-32 KiB (one sample x
+// 128 / 64 channels), but its threads request it 4.5 times over through the texture path (six 16-byte columns x three rows per
+// four outputs), and only a few hundred bytes per thread are ever in flight. Here the slab goes to LDS ONCE, as fully coalesced
+// 256- / 128-byte pixel rows (every thread has its 4 / 8 16-byte loads in flight at the start), inside a ring of zero pixels --
+// TF-SAME padding becomes data -- and the taps read LDS (conflict-free: the 16 lanes of a ds_read_b128 group cover whole
+// pixels). Same thread <-> (pixel quad, channel chunk) map, same tap order, same accumulators and pool order as
+// dwconv3x3_pool_kernel<1>: bit-identical (tested). 8 x 8: 3.5 -> 4.7 TB/s.
+template <bool F16, int HW>
+__global__ __launch_bounds__(256) void dwconv3x3_map_kernel(DwArgs p) {
+    constexpr int NQ = HW * HW / 4;                        // pixel quads per sample
+    constexpr int PQ = NQ >= 32 ? 32 : NQ;                 // quad slots in the workgroup (16 on 8 x 8 maps)
+    constexpr int CH = 256 / PQ;                           // 8-channel chunks per workgroup: 16 (128 channels) / 8 (64 channels)
+    constexpr int TW = HW + 2;                             // tile width with the zero ring
+    constexpr int NLD = HW * HW * CH / 256;                // 16-byte loads per thread: 4 / 8
+    constexpr int QPR = HW / 4;                            // quads per row
+    __shared__ __attribute__((aligned(16))) uint4 tile[TW * TW * CH];     // [y + 1][x + 1][chunk]
+    __shared__ float red[PQ][CH * 8 + 1];
     const int tid = threadIdx.x;
-    const int cl = tid & 15, pq = tid >> 4;                 // chunk, pixel quad (row pq >> 1, columns 4 (pq & 1) ..)
-    const int b = blockIdx.y, c0 = blockIdx.x * 128;
+    const int cl = tid % CH, pq = tid / CH;
+    const int b = blockIdx.y, c0 = blockIdx.x * (CH * 8);
     const int c = c0 + cl * 8;
     const bool cok = c < p.C;
-    // the slab: pixel px = idx >> 4, chunk idx & 15 -- sixteen consecutive threads fetch one pixel's 256 contiguous bytes
-    uint4 ld[4];
+    // the slab: pixel px = idx / CH, chunk idx % CH -- CH consecutive threads fetch one pixel's contiguous bytes
+    uint4 ld[NLD];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int idx = tid + 256 * k, px = idx >> 4, ch = idx & 15;
-        ld[k] = (c0 + ch * 8 < p.C) ? *reinterpret_cast<const uint4*>(p.in + ((size_t)b * 64 + px) * p.C + c0 + ch * 8) : make_uint4(0, 0, 0, 0);
+    for (int k = 0; k < NLD; ++k) {
+        const int idx = tid + 256 * k, px = idx / CH, ch = idx % CH;
+        ld[k] = (c0 + ch * 8 < p.C) ? *reinterpret_cast<const uint4*>(p.in + ((size_t)b * (HW * HW) + px) * p.C + c0 + ch * 8) : make_uint4(0, 0, 0, 0);
     }
-    for (int i = tid; i < 36 * 16; i += 256) {              // the ring of zero pixels
-        const int q = i >> 4, ch = i & 15;
-        const int y = q < 10 ? 0 : (q < 20 ? 9 : 1 + ((q - 20) >> 1)), x = q < 10 ? q : (q < 20 ? q - 10 : ((q - 20) & 1) * 9);
-        tile[(y * 10 + x) * 16 + ch] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < (4 * HW + 4) * CH; i += 256) {   // the ring of zero pixels: top row, bottom row, left / right columns
+        const int q = i / CH, ch = i % CH;
+        const int y = q < TW ? 0 : (q < 2 * TW ? TW - 1 : 1 + ((q - 2 * TW) >> 1)), x = q < TW ? q : (q < 2 * TW ? q - TW : ((q - 2 * TW) & 1) * (TW - 1));
+        tile[(y * TW + x) * CH + ch] = make_uint4(0, 0, 0, 0);
     }
     uint32_t wlo[9][4], whi[9][4];
     float bias[8], psum[8];
@@ -2413,68 +2420,70 @@ __global__ __launch_bounds__(256) void dwconv3x3_map8_kernel(DwArgs p) {
         bias[0] = s0.x; bias[1] = s0.y; bias[2] = s0.z; bias[3] = s0.w; bias[4] = s1.x; bias[5] = s1.y; bias[6] = s1.z; bias[7] = s1.w;
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int idx = tid + 256 * k, px = idx >> 4, ch = idx & 15;
-        tile[(((px >> 3) + 1) * 10 + (px & 7) + 1) * 16 + ch] = ld[k];
+    for (int k = 0; k < NLD; ++k) {
+        const int idx = tid + 256 * k, px = idx / CH, ch = idx % CH;
+        tile[((px / HW + 1) * TW + (px % HW) + 1) * CH + ch] = ld[k];
     }
     __syncthreads();
     if (cok) {
-        const int oy = pq >> 1, ox0 = (pq & 1) * 4;
-        float acc[4][8];
+        for (int q = pq; q < NQ; q += PQ) {
+            const int oy = q / QPR, ox0 = (q - oy * QPR) * 4;
+            float acc[4][8];
 #pragma unroll
-        for (int o = 0; o < 4; ++o)
+            for (int o = 0; o < 4; ++o)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[o][e] = bias[e];
+                for (int e = 0; e < 8; ++e) acc[o][e] = bias[e];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            uint4 v[6];
+            for (int ky = 0; ky < 3; ++ky) {
+                uint4 v[6];
 #pragma unroll
-            for (int col = 0; col < 6; ++col) v[col] = tile[((oy + ky) * 10 + ox0 + col) * 16 + cl];
+                for (int col = 0; col < 6; ++col) v[col] = tile[((oy + ky) * TW + ox0 + col) * CH + cl];
 #pragma unroll
-            for (int col = 0; col < 6; ++col) {
-                const uint32_t x[4] = {v[col].x, v[col].y, v[col].z, v[col].w};
+                for (int col = 0; col < 6; ++col) {
+                    const uint32_t x[4] = {v[col].x, v[col].y, v[col].z, v[col].w};
 #pragma unroll
-                for (int o = 0; o < 4; ++o) {
-                    const int kx = col - o;
-                    if (kx >= 0 && kx < 3) {
+                    for (int o = 0; o < 4; ++o) {
+                        const int kx = col - o;
+                        if (kx >= 0 && kx < 3) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            acc[o][2 * e] = T16<F16>::dot2(x[e], wlo[ky * 3 + kx][e], acc[o][2 * e]);
-                            acc[o][2 * e + 1] = T16<F16>::dot2(x[e], whi[ky * 3 + kx][e], acc[o][2 * e + 1]);
+                            for (int e = 0; e < 4; ++e) {
+                                acc[o][2 * e] = T16<F16>::dot2(x[e], wlo[ky * 3 + kx][e], acc[o][2 * e]);
+                                acc[o][2 * e + 1] = T16<F16>::dot2(x[e], whi[ky * 3 + kx][e], acc[o][2 * e + 1]);
+                            }
                         }
                     }
                 }
             }
-        }
 #pragma unroll
-        for (int o = 0; o < 4; ++o) {
-            uint32_t pk[4];
+            for (int o = 0; o < 4; ++o) {
+                uint32_t pk[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const uint16_t lo = T16<F16>::from_f32(silu_fast(acc[o][2 * e])), hi = T16<F16>::from_f32(silu_fast(acc[o][2 * e + 1]));
-                pk[e] = (uint32_t)lo | ((uint32_t)hi << 16);
-                psum[2 * e] = T16<F16>::dot2(pk[e], one_lo, psum[2 * e]);
-                psum[2 * e + 1] = T16<F16>::dot2(pk[e], one_hi, psum[2 * e + 1]);
+                for (int e = 0; e < 4; ++e) {
+                    const uint16_t lo = T16<F16>::from_f32(silu_fast(acc[o][2 * e])), hi = T16<F16>::from_f32(silu_fast(acc[o][2 * e + 1]));
+                    pk[e] = (uint32_t)lo | ((uint32_t)hi << 16);
+                    psum[2 * e] = T16<F16>::dot2(pk[e], one_lo, psum[2 * e]);
+                    psum[2 * e + 1] = T16<F16>::dot2(pk[e], one_hi, psum[2 * e + 1]);
+                }
+                *reinterpret_cast<uint4*>(p.out + (((size_t)b * (HW * HW) + oy * HW + ox0 + o) * p.C + c)) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
             }
-            *reinterpret_cast<uint4*>(p.out + (((size_t)b * 64 + oy * 8 + ox0 + o) * p.C + c)) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
         }
     }
     if (p.pooled) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) red[pq][cl * 8 + e] = psum[e];
         __syncthreads();
-        if (tid < 128) {
+        if (tid < CH * 8) {
             const int cc = c0 + tid;
             if (cc < p.C) {
                 float t = 0.f;
-                for (int s2 = 0; s2 < 16; ++s2) t += red[s2][tid];
-                p.pooled[(size_t)b * p.C + cc] = t / 64.0f;
+                for (int s2 = 0; s2 < PQ; ++s2) t += red[s2][tid];
+                p.pooled[(size_t)b * p.C + cc] = t / (float)(HW * HW);
             }
         }
     }
 }
 
-static bool dw_map8_on() {          // ISB_DW_MAP8=0: the general kernel on 8 x 8 maps too (A/B switch)
+static bool dw_map8_on() {          // ISB_DW_MAP8=0: the general kernel on 8 x 8 / 16 x 16 maps too (A/B switch)
     static const bool on = [] { const char* e = getenv("ISB_DW_MAP8"); return !e || atoi(e) != 0; }();
     return on;
 }
@@ -2502,11 +2511,17 @@ int launch_dwconv3x3(const DwArgs& a, hipStream_t st) {
         set_error("dwconv3x3: fp16 forms are stride 1 fp16 -> fp16 and stride 2 bf16 -> fp16 (in_f16=%d out_f16=%d stride=%d)", a.in_f16, a.out_f16, a.stride);
         return ISB_ERR_INVALID;
     }
-    if (!a.se_w1 && a.stride == 1 && a.H == 8 && a.W == 8 && a.OH == 8 && a.OW == 8 && a.pad == 1 && (form == 0 || form == 3) && !a.general && dw_map8_on()) {
-        // grid.x = dw_slabs(a) = C / 128 slabs here too (16 quads x 16 chunks per workgroup)
-        if (form == 3) hipLaunchKernelGGL((dwconv3x3_map8_kernel<true>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((dwconv3x3_map8_kernel<false>), grid, dim3(256), 0, st, a);
-        ISB_LAUNCHED("dwconv3x3_map8", st);
+    if (!a.se_w1 && a.stride == 1 && a.H == a.W && (a.H == 8 || a.H == 16) && a.OH == a.H && a.OW == a.W && a.pad == 1 && (form == 0 || form == 3) &&
+        !a.general && dw_map8_on()) {
+        // grid.x = dw_slabs(a): slabs of 128 (8 x 8 maps) / 64 (16 x 16 maps) channels, as in the general kernel
+        if (a.H == 8) {
+            if (form == 3) hipLaunchKernelGGL((dwconv3x3_map_kernel<true, 8>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((dwconv3x3_map_kernel<false, 8>), grid, dim3(256), 0, st, a);
+        } else {
+            if (form == 3) hipLaunchKernelGGL((dwconv3x3_map_kernel<true, 16>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((dwconv3x3_map_kernel<false, 16>), grid, dim3(256), 0, st, a);
+        }
+        ISB_LAUNCHED("dwconv3x3_map", st);
         return ISB_OK;
     }
     if (a.se_w1) {

@@ -451,14 +451,14 @@ def test_dwconv_f16_forms(form):
 
 
 @pytest.mark.parametrize("f16", [False, True])
-@pytest.mark.parametrize("Cc", [2304, 3840, 200])
-def test_dwconv_map8_is_bit_identical(Cc, f16):
-    """8 x 8 maps run on dwconv3x3_map8_kernel (slab staged in LDS once, zero ring for the padding): same taps in the same
-    order as the general kernel -> the same bits, outputs and pooled means (200 channels: a partial last slab)."""
+@pytest.mark.parametrize("HW,Cc", [(8, 2304), (8, 3840), (8, 200), (16, 768), (16, 1344), (16, 200)])
+def test_dwconv_map8_is_bit_identical(HW, Cc, f16):
+    """8 x 8 and 16 x 16 maps run on dwconv3x3_map_kernel (slab staged in LDS once, zero ring for the padding): same taps in
+    the same order as the general kernel -> the same bits, outputs and pooled means (200 channels: a partial last slab)."""
     from isbfsar_amd.hpe_engine import dwconv_debug, f32_to_f16
-    rng = np.random.default_rng(Cc + int(f16))
+    rng = np.random.default_rng(Cc + int(f16) + HW)
     B = 5
-    x = rng.normal(0, 1, (B, 8, 8, Cc)).astype(np.float32)
+    x = rng.normal(0, 1, (B, HW, HW, Cc)).astype(np.float32)
     w = (rng.normal(0, 1, (Cc, 3, 3)) / 3.0).astype(np.float32)
     scale = rng.uniform(0.8, 1.2, Cc).astype(np.float32)
     shift = rng.uniform(-0.1, 0.1, Cc).astype(np.float32)
