@@ -1792,10 +1792,17 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
         //   * a single frame (M <= 2048) needs many small workgroups: 64-row tiles.
         const bool g1 = a.KH == 1 && a.stride == 1 && a.pad == 0 && a.zeros;
         const int ohw = a.OH * a.OW;
+        const bool c3 = !a.gate && a.KH == 3 && a.KW == 3 && ((a.stride == 1 && a.pad == 1) || (a.stride == 2 && a.pad == 0)) &&
+                        (size_t)a.B * a.H * a.W * a.Cin * 2 + (size_t)(a.W + 1) * a.Cin * 2 < 0x7ffffff0ull;
         if (a.M <= 2048 && a.Cout >= 64) {
             if (g1 && !a.gate) v = 138;
             else if (g1 && a.gate && ohw % 64 == 0) v = 147;
             else v = (!a.gate && a.zeros) ? 64 : 75;
+        } else if (a.M <= 8192 && a.Cout >= 128 && a.Cout % 128 == 0 && !a.gate && !a.f16 && (c3 || g1) &&
+                   (long)cdiv(a.M, 128) * cdiv(a.Cout, 128) < 384) {
+            // a few thousand rows (the detector's 8 x 8 / 16 x 16 maps at 64 frames, the ResNet-50's 7 x 7 and 14 x 14 maps): 128-row
+            // tiles would leave most CUs idle -- 64 x 128 tiles of 4 waves double the workgroups
+            v = c3 ? 168 : 150;
         } else if (g1 && !a.gate && !a.res && !a.out_f32 && a.act <= 1 && a.splits <= 1 && wsreg_on() && (!a.f16 || (a.Cin == 384 && wsreg_on() >= 184)) &&
                    (a.Cin == 96 || a.Cin == 192 || a.Cin == 224 || (a.Cin == 384 && wsreg_on() != 183 && wsreg_on() != 1840)) && a.Cout % 32 == 0 && a.M >= 64 * 128 &&
                    (size_t)a.M * a.Cin * 2 < 0xffffffffull) {
@@ -2093,6 +2100,8 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
         case 164: ISB_CONV_LAUNCH_C3(2, 2, 4, 2); break;   // 256 x 128
         case 165: ISB_CONV_LAUNCH_C3(1, 2, 8, 1); break;   // 256 x  64
         case 166: ISB_CONV_LAUNCH_C3(2, 3, 4, 2); break;   // 256 x 192
+        case 168: ISB_CONV_LAUNCH_C3(1, 2, 2, 2); break;   //  64 x 128, 4 waves: small-M launches (the detector's 8 x 8 / 16 x 16 maps)
+        case 169: ISB_CONV_LAUNCH_C3(1, 1, 2, 2); break;   //  64 x  64
 #undef ISB_CONV_LAUNCH_C3
 #define ISB_CONV_LAUNCH_G1G(TM, TN, WGM, WGN) ISB_CONV_LAUNCH_G1GN(TM, TN, WGM, WGN, 2)
 #define ISB_CONV_LAUNCH_G1GN(TM, TN, WGM, WGN, NBUF_) ISB_CONV_LAUNCH_G1GT(TM, TN, WGM, WGN, NBUF_, false)

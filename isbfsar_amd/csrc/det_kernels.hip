@@ -12,6 +12,12 @@ namespace isb {
 
 __device__ __forceinline__ float bf2f_d(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
 __device__ __forceinline__ uint16_t f2bf_d(float x) { return __builtin_bit_cast(uint16_t, (__bf16)x); }
+// x * tanh(softplus(x)) with n = e^x: tanh(ln(1 + n)) = n (n + 2) / (n (n + 2) + 2)  (conv_common.h mish_fast)
+__device__ __forceinline__ float mish_stem(float x) {
+    const float n = __builtin_amdgcn_exp2f(1.4426950408889634f * fminf(x, 20.0f));
+    const float w = n * (n + 2.0f);
+    return x * w * __builtin_amdgcn_rcpf(w + 2.0f);
+}
 
 // ------------------------------------------------------------------------------------------
 // area resize: output pixel (oy, ox) = area-weighted mean of the source rectangle [oy sy, (oy + 1) sy) x [ox sx, (ox + 1) sx),
@@ -80,9 +86,10 @@ __global__ __launch_bounds__(256) void det_stem_kernel(StemArgs p) {
             a0 = fmaf(x[k], p.w[co * 27 + k], a0);
             a1 = fmaf(x[k], p.w[(co + 1) * 27 + k], a1);
         }
-        // Mish with the exact library functions (one launch per frame batch: not a hot spot)
-        a0 = a0 * tanhf(a0 > 20.f ? a0 : log1pf(expf(a0)));
-        a1 = a1 * tanhf(a1 > 20.f ? a1 : log1pf(expf(a1)));
+        // Mish as every other layer computes it (one v_exp + one v_rcp; with the exact library functions -- expf, log1pf, tanhf
+        // per output -- this launch took 570 us per 64 frames, 12 % of the detector)
+        a0 = mish_stem(a0);
+        a1 = mish_stem(a1);
         o[co >> 1] = (uint32_t)f2bf_d(a0) | ((uint32_t)f2bf_d(a1) << 16);
     }
     uint4* dst = reinterpret_cast<uint4*>(p.out + idx * 32);
@@ -192,33 +199,40 @@ int launch_spp(const uint16_t* in, uint16_t* out, int B, int H, int W, int C, hi
 //   boxes (x1, y1, x2, y2) = (bx - bw / 2, by - bh / 2, x1 + bw, y1 + bh);  confs = sigmoid(cls) * sigmoid(obj)
 // box index inside the scale = a * H * W + y * W + x. thread = (b, a, cell).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void yolo_decode_kernel(const float* map, int B, int H, int W, int ldm, float aw0, float ah0, float aw1,
+// thread = (box row, piece): piece 0 writes the box, pieces 1..20 four class confidences each (one thread per row walked 85
+// strided channels and 84 exponentials: 116 us for the 32 x 32 scale at 64 frames)
+__global__ __launch_bounds__(256) void yolo_decode_kernel(const float* map, int B, int H, int W, int ldm, float aw0, float ah0, float aw1,
                                                           float ah1, float aw2, float ah2, float sxy, float* boxes, float* confs,
                                                           int n_boxes, int box_off) {
-    const int idx = blockIdx.x * 128 + threadIdx.x;
-    if (idx >= B * 3 * H * W) return;
-    const int cell = idx % (H * W), a = (idx / (H * W)) % 3, b = idx / (3 * H * W);
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int piece = (int)(gid % 21);
+    const size_t idx = gid / 21;
+    if (idx >= (size_t)B * 3 * H * W) return;
+    const int cell = (int)(idx % (H * W)), a = (int)((idx / (H * W)) % 3), b = (int)(idx / ((size_t)3 * H * W));
     const int y = cell / W, x = cell - y * W;
     const float* t = map + ((size_t)b * H * W + cell) * ldm + a * 85;
     auto sig = [](float v) { return 1.0f / (1.0f + expf(-v)); };
-    const float aw = a == 0 ? aw0 : (a == 1 ? aw1 : aw2), ah = a == 0 ? ah0 : (a == 1 ? ah1 : ah2);
-    const float off = 0.5f * (sxy - 1.0f);
-    const float bx = (sig(t[0]) * sxy - off + (float)x) / (float)W;
-    const float by = (sig(t[1]) * sxy - off + (float)y) / (float)H;
-    const float bw = expf(t[2]) * aw / (float)W;
-    const float bh = expf(t[3]) * ah / (float)H;
-    const float x1 = bx - bw * 0.5f, y1 = by - bh * 0.5f;
     const size_t row = (size_t)b * n_boxes + box_off + (size_t)a * H * W + cell;
-    *reinterpret_cast<float4*>(boxes + row * 4) = make_float4(x1, y1, x1 + bw, y1 + bh);
+    if (piece == 0) {
+        const float aw = a == 0 ? aw0 : (a == 1 ? aw1 : aw2), ah = a == 0 ? ah0 : (a == 1 ? ah1 : ah2);
+        const float off = 0.5f * (sxy - 1.0f);
+        const float bx = (sig(t[0]) * sxy - off + (float)x) / (float)W;
+        const float by = (sig(t[1]) * sxy - off + (float)y) / (float)H;
+        const float bw = expf(t[2]) * aw / (float)W;
+        const float bh = expf(t[3]) * ah / (float)H;
+        const float x1 = bx - bw * 0.5f, y1 = by - bh * 0.5f;
+        *reinterpret_cast<float4*>(boxes + row * 4) = make_float4(x1, y1, x1 + bw, y1 + bh);
+        return;
+    }
     const float det = sig(t[4]);
-    float* c = confs + row * 80;
-    for (int k = 0; k < 80; k += 4)
-        *reinterpret_cast<float4*>(c + k) = make_float4(sig(t[5 + k]) * det, sig(t[6 + k]) * det, sig(t[7 + k]) * det, sig(t[8 + k]) * det);
+    const int k = (piece - 1) * 4;
+    *reinterpret_cast<float4*>(confs + row * 80 + k) = make_float4(sig(t[5 + k]) * det, sig(t[6 + k]) * det, sig(t[7 + k]) * det, sig(t[8 + k]) * det);
 }
 
 int launch_yolo_decode(const float* map, int B, int H, int W, int ldm, const float* anchors_wh, float sxy, float* boxes, float* confs,
                        int n_boxes, int box_off, hipStream_t st) {
-    hipLaunchKernelGGL(yolo_decode_kernel, dim3(cdiv(B * 3 * H * W, 128)), dim3(128), 0, st, map, B, H, W, ldm, anchors_wh[0], anchors_wh[1],
+    const size_t total = (size_t)B * 3 * H * W * 21;
+    hipLaunchKernelGGL(yolo_decode_kernel, dim3((unsigned)cdivz(total, 256)), dim3(256), 0, st, map, B, H, W, ldm, anchors_wh[0], anchors_wh[1],
                        anchors_wh[2], anchors_wh[3], anchors_wh[4], anchors_wh[5], sxy, boxes, confs, n_boxes, box_off);
     ISB_LAUNCHED("yolo_decode", st);
     return ISB_OK;

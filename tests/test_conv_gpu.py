@@ -50,7 +50,7 @@ CASES = [
     (3, 8, 288, 384, 1, 1, 0, True, True),        # 9 k-steps, ragged M
 ]
 G1 = [131, 132, 133, 134, 135, 136, 137, 138, 139]   # lean 1x1 GEMM kernels
-C3 = [161, 162, 163, 164, 165, 166]                  # lean 3x3 kernels (buffer-addressed A operand)
+C3 = [161, 162, 163, 164, 165, 166, 168, 169]                  # lean 3x3 kernels (buffer-addressed A operand)
 GATED_DMA = [81, 82, 83, 84, 85, 86, 91, 92, 93, 94, 95, 96, 111, 112, 113, 114, 115, 116, 141, 142, 143, 144, 145, 146, 147, 148,
              191, 193, 194, 196, 197]      # 19x: three k-step buffers, counted waits
 K64 = [101, 102, 103, 104, 105, 106, 107, 108, 111, 112, 113, 114, 115, 116]
