@@ -4,33 +4,40 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 echo "== bench lines"
-for w in pipeline hpe ar stream; do
-  timeout -k 10 400 python bench.py --workload $w $( [ $w = stream ] && echo "--steps 300 --warmup 20" ) > gpurun_out/bench_$w.log 2>&1
+for w in pipeline hpe ar stream det; do
+  timeout -k 10 400 python bench.py --workload $w $( [ $w = stream ] && echo "--steps 300 --warmup 20" ) $( [ $w != pipeline ] && echo "--min-gpu-seconds 0" ) > gpurun_out/bench_$w.log 2>&1
   tail -1 gpurun_out/bench_$w.log > gpurun_out/bench_$w.json
   python3 -c "import json;d=json.load(open('gpurun_out/bench_$w.json'));print('$w',d['value'],d['unit'],d['ms_per_step'],'ms',d['roofline']['achieved'],d['roofline']['frac'],d['cpu_baseline']['value'] if d.get('cpu_baseline') else None, d.get('parity'))"
 done
 echo "== extra lines: AR in bf16x3 (the reference arithmetic is fp32), pose stage from pinned host frames, configs[3] at its full single-GPU batch"
-timeout -k 10 300 python bench.py --workload ar --precision bf16x3 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/bench_ar_bf16x3.json
-timeout -k 10 300 python bench.py --workload hpe --host-input --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/bench_hpe_host.json
-timeout -k 10 400 python bench.py --workload pipeline --batch 2048 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/bench_pipe_b2048.json
-for f in ar_bf16x3 hpe_host pipe_b2048; do python3 -c "import json;d=json.load(open('gpurun_out/bench_$f.json'));print('$f',d['value'],d['unit'],d['ms_per_step'],'ms')"; done
+timeout -k 10 300 python bench.py --workload ar --precision bf16x3 --no-cpu-baseline --min-gpu-seconds 0 2>/dev/null | tail -1 > gpurun_out/bench_ar_bf16x3.json
+timeout -k 10 300 python bench.py --workload hpe --host-input --no-cpu-baseline --min-gpu-seconds 0 2>/dev/null | tail -1 > gpurun_out/bench_hpe_host.json
+ISB_HPE_ROI=0 timeout -k 10 300 python bench.py --workload hpe --host-input --no-cpu-baseline --min-gpu-seconds 0 2>/dev/null | tail -1 > gpurun_out/bench_hpe_host_wholeframes.json
+ISB_HPE_F16=0 timeout -k 10 300 python bench.py --workload hpe --min-gpu-seconds 0 2>/dev/null | tail -1 > gpurun_out/bench_hpe_bf16_everywhere.json
+timeout -k 10 400 python bench.py --workload pipeline --batch 2048 --steps 3 --warmup 1 --no-cpu-baseline --no-extras --min-gpu-seconds 0 2>/dev/null | tail -1 > gpurun_out/bench_pipe_b2048.json
+timeout -k 10 300 python tools/estimate_latency.py > gpurun_out/estimate_latency.json 2>gpurun_out/estimate_latency.err || true
+for f in ar_bf16x3 hpe_host hpe_host_wholeframes hpe_bf16_everywhere pipe_b2048; do python3 -c "import json;d=json.load(open('gpurun_out/bench_$f.json'));print('$f',d['value'],d['unit'],d['ms_per_step'],'ms')"; done
 echo "== kernel stats (pipeline)"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_pipe -o run -- python3 bench.py --workload pipeline --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/prof_pipe.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_pipe -o run -- python3 bench.py --workload pipeline --steps 5 --warmup 2 --no-cpu-baseline --no-extras --min-gpu-seconds 0 > gpurun_out/prof_pipe.log 2>&1
 echo "== kernel stats (hpe, one lane: every convolution launch is a 256-frame launch, as in bench.py's roofline pass)"
-ISB_HPE_LANES=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_hpe1 -o run -- python3 bench.py --workload hpe --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/prof_hpe1.log 2>&1
+ISB_HPE_LANES=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_hpe1 -o run -- python3 bench.py --workload hpe --steps 5 --warmup 2 --no-cpu-baseline --min-gpu-seconds 0 > gpurun_out/prof_hpe1.log 2>&1
 python3 tools/family_avg.py gpurun_out/prof_hpe1/run_kernel_stats.csv gpurun_out/bench_hpe.json
 python3 tools/layer_breakdown.py gpurun_out/prof_hpe1/run_kernel_trace.csv > gpurun_out/layer_breakdown.txt 2>&1 || true
+python3 tools/dw_breakdown.py gpurun_out/prof_hpe1/run_kernel_trace.csv > gpurun_out/dw_breakdown.txt 2>&1 || true
+echo "== kernel stats (det)"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_det -o run -- python3 bench.py --workload det --steps 5 --warmup 2 --no-cpu-baseline --min-gpu-seconds 0 > gpurun_out/prof_det.log 2>&1
+python3 tools/det_breakdown.py gpurun_out/prof_det/run_kernel_trace.csv > gpurun_out/det_breakdown.txt 2>&1 || true
 echo "== kernel stats (ar)"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_ar -o run -- python3 bench.py --workload ar --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/prof_ar.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_ar -o run -- python3 bench.py --workload ar --steps 3 --warmup 1 --no-cpu-baseline --min-gpu-seconds 0 > gpurun_out/prof_ar.log 2>&1
 echo "== PMC traffic"
-ISB_HPE_LANES=1 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o run -- python3 bench.py --workload hpe --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_fetch.log 2>&1
-ISB_HPE_LANES=1 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o run -- python3 bench.py --workload hpe --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_write.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_ar_fetch -o run -- python3 bench.py --workload ar --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_ar_fetch.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_ar_write -o run -- python3 bench.py --workload ar --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_ar_write.log 2>&1
+ISB_HPE_LANES=1 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o run -- python3 bench.py --workload hpe --steps 1 --warmup 1 --no-cpu-baseline --no-extras --min-gpu-seconds 0 > gpurun_out/pmc_fetch.log 2>&1
+ISB_HPE_LANES=1 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o run -- python3 bench.py --workload hpe --steps 1 --warmup 1 --no-cpu-baseline --no-extras --min-gpu-seconds 0 > gpurun_out/pmc_write.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_ar_fetch -o run -- python3 bench.py --workload ar --steps 1 --warmup 1 --no-cpu-baseline --no-extras --min-gpu-seconds 0 > gpurun_out/pmc_ar_fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_ar_write -o run -- python3 bench.py --workload ar --steps 1 --warmup 1 --no-cpu-baseline --no-extras --min-gpu-seconds 0 > gpurun_out/pmc_ar_write.log 2>&1
 python3 tools/collect_traffic.py gpurun_out/pmc_fetch/run_counter_collection.csv gpurun_out/pmc_write/run_counter_collection.csv gpurun_out/traffic.json gpurun_out/pmc_ar_fetch/run_counter_collection.csv gpurun_out/pmc_ar_write/run_counter_collection.csv
 echo "== PMC matrix-pipe utilisation (SQ counters + GRBM_GUI_ACTIVE, own passes)"
-ISB_HPE_LANES=1 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_mfma_hpe -o run -- python3 bench.py --workload hpe --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_mfma_hpe.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_mfma_ar -o run -- python3 bench.py --workload ar --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_mfma_ar.log 2>&1
+ISB_HPE_LANES=1 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_mfma_hpe -o run -- python3 bench.py --workload hpe --steps 1 --warmup 1 --no-cpu-baseline --no-extras --min-gpu-seconds 0 > gpurun_out/pmc_mfma_hpe.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_mfma_ar -o run -- python3 bench.py --workload ar --steps 1 --warmup 1 --no-cpu-baseline --no-extras --min-gpu-seconds 0 > gpurun_out/pmc_mfma_ar.log 2>&1
 python3 tools/collect_mfma.py gpurun_out/mfma_hpe.json gpurun_out/pmc_mfma_hpe/run_counter_collection.csv
 python3 tools/collect_mfma.py gpurun_out/mfma_ar.json gpurun_out/pmc_mfma_ar/run_counter_collection.csv
 echo done
