@@ -71,7 +71,17 @@ def test_network_and_decode_vs_oracle(det, state):
     b_o, c_o = YoloV4Oracle.decode(ref_maps)
     dc = np.abs(confs - c_o)
     print(f"detector end to end: max|d conf|={dc.max():.2e} mean|d conf|={dc.mean():.2e} max|d box|={np.abs(boxes - b_o).max():.2e}")
-    assert dc.max() < 0.15 and dc.mean() < 2e-3
+    # conf = sigmoid(cls) * sigmoid(obj): sigmoid' <= 1/4 and both factors <= 1, so every confidence can move by at most a quarter
+    # of the error of the two logits it is made of -- the map error (bounded above) carried through, element by element,
+    # instead of a flat ceiling
+    bound = []
+    for m, r, hw in zip(maps, ref_maps, (32, 16, 8)):
+        d = np.abs(m - r).reshape(2, hw * hw, 3, 85)                      # [b, cell, anchor, channel]
+        bd = 0.25 * (d[..., 5:] + d[..., 4:5])                            # [b, cell, anchor, 80]
+        bound.append(bd.transpose(0, 2, 1, 3).reshape(2, 3 * hw * hw, 80))   # box row = anchor * H * W + cell
+    bound = np.concatenate(bound, axis=1)
+    assert np.all(dc <= bound + 1e-5), float((dc - bound).max())
+    assert dc.mean() < 2e-3
     # drift of the bf16 network against the pure-fp32 definition (informative)
     f32 = YoloV4Oracle(state, "f32").raw_heads(img)
     print("detector maps, bf16 HIP vs fp32 definition: rel L2 =",
