@@ -1025,6 +1025,139 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_dma_kernel(ConvArgs p)
 }
 
 // -------------------------------------------------------------------------------------------
+// SE-gated projection with LOADER WAVES (round 3; variants 155 / 156): the 8 x 8 stages' 2304 -> 384 and 3840 -> 640 GEMMs.
+// Their k loops are bound by what a CU receives from L2 (EXPERIMENTS.md: FLOP per byte of the tile against 127): the 64 x 192
+// tiles of gemm1x1_dma_kernel cap the matrix pipe at 38 %. A CU's share of these layers is 24 576 outputs; the tile that
+// moves the fewest bytes for them is 128 x 192 (320 rows per k-step instead of 2 x 256), ONE workgroup per CU -- which the
+// tile kernel cannot use, because with nobody beside it every DMA-issue stall (~90 cycles per 1-KiB piece, in the issuing
+// wave's stream), every landing wait and its epilogue are exposed. Here the workgroup has 8 CONSUMER waves (fragment reads,
+// gate, MFMAs: nothing else in their stream) and 4 LOADER waves that only issue LDS-DMA, NB - 1 k-steps ahead through a ring
+// of NB buffers, and wait (counted vmcnt) for the k-step the consumers take next; all twelve meet at ONE barrier per k-step.
+// The loaders end after the loop (an ended wave is no longer a party to s_barrier); the consumers run the shared epilogue.
+// Same LDS images, fragment reads, gate arithmetic and k order as gemm1x1_dma_kernel<.., GATE = 1>: bit-identical (tested).
+// -------------------------------------------------------------------------------------------
+template <int TN, bool F16>
+__global__ __launch_bounds__(768) void gemm1x1_lw_kernel(ConvArgs p) {
+    constexpr int WGM = 4, WGN = 2, NCW = WGM * WGN, NLW = 4;          // consumer / loader waves
+    constexpr int BM = 32 * WGM, BN = 32 * TN * WGN;
+    constexpr int PIECES = (BM + BN) / 16, PPL = PIECES / NLW;         // 1-KiB pieces per k-step, per loader
+    static_assert(PIECES % NLW == 0, "pieces split evenly over the loaders (immediate vmcnt)");
+    constexpr int BUF = (BM + BN) * ROWB;
+    // the loop runs on PAIRS of k-steps (one barrier per 64 channels: the twelve waves' meeting costs as much as a k-step's
+    // MFMAs): ring of NP pair buffers, NP - 1 pairs in flight
+    constexpr int NP = TN <= 3 ? 3 : 2;                                // 120 / 112 KiB
+    constexpr int PBUF = 2 * BUF;
+    constexpr int GATE_OFF = NP * PBUF;
+    unsigned char* const lds = conv_lds_dyn;
+    const int bias_off = p.grid_bias_off;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    int m0, n0;
+    if (!conv_tile_origin(p, BM, BN, m0, n0)) return;
+    const int npair = p.Cin / (2 * CK);                                // launcher: Cin % 64 == 0
+    const int ohw = p.OH * p.OW;
+    // gate rows of the tile's samples + the bias row: staged by everybody with ordinary loads / one DMA, published by the first barrier
+    {
+        const int s_first = m0 / ohw;
+        const int ns = min(m0 + BM - 1, p.M - 1) / ohw - s_first + 1;
+        const float* src = p.gate + (size_t)s_first * p.Cin;
+        float* dst = reinterpret_cast<float*>(lds + GATE_OFF);
+        for (int idx = tid * 4; idx < ns * p.Cin; idx += 768 * 4)
+            *reinterpret_cast<float4*>(dst + idx) = *reinterpret_cast<const float4*>(src + idx);
+    }
+    if (wave >= NCW) {
+        // ---------------------------------------------------------------- loader waves
+        const int lw = wave - NCW;
+        uint32_t voff[PPL];
+        uint32_t ldst[PPL];
+#pragma unroll
+        for (int s = 0; s < PPL; ++s) {
+            const int piece = lw + NLW * s;                           // rows 16 piece .. + 15 of the [A rows | B rows] image
+            const int row = 16 * piece + (lane >> 2);
+            const int logical = (lane & 3) ^ ((row >> 2) & 3);
+            if (row < BM) voff[s] = (uint32_t)min(m0 + row, p.M - 1) * (uint32_t)(p.Cin * 2) + logical * 16;
+            else voff[s] = (uint32_t)min(n0 + row - BM, p.Cout - 1) * (uint32_t)(p.Cin * 2) + logical * 16;
+            ldst[s] = piece * 1024;
+        }
+        if (lw == 0) {
+#pragma unroll
+            for (int o = 0; o < BN / 4; o += 64)
+                if (lane + o < BN / 4)
+                    dma16_s(p.bias, (uint32_t)min(n0 + (lane + o) * 4, p.Cout - 4) * 4, (uint32_t)(uintptr_t)(lds_ptr_t)lds + bias_off + o * 16);
+        }
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)lds;
+        const unsigned char* a_base = reinterpret_cast<const unsigned char*>(p.in);
+        const unsigned char* b_base = reinterpret_cast<const unsigned char*>(p.w);
+        auto issue = [&](int pr) {                                    // pair pr (k-steps 2 pr, 2 pr + 1) into pair buffer pr % NP
+            const uint32_t boff = lds0 + (uint32_t)(pr % NP) * PBUF;
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int s = 0; s < PPL; ++s) {
+                    const bool is_a = 16 * (lw + NLW * s) < BM;
+                    dma16_s((is_a ? a_base : b_base) + (size_t)(2 * pr + half) * (CK * 2), voff[s], boff + half * BUF + ldst[s]);
+                }
+        };
+        // prologue: NP - 1 pairs in flight; pair 0 landed before the first barrier
+        for (int t = 0; t < NP - 1; ++t)
+            if (t < npair) issue(t);
+        if (min(NP - 1, npair) >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPL) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                               // gates, bias, pair 0 visible to the consumers
+        for (int pr = 0; pr < npair; ++pr) {
+            // pair buffer (pr - 1) % NP was released by the barrier that ended iteration pr - 1 (at pr = 0 it is still empty)
+            if (pr + NP - 1 < npair) issue(pr + NP - 1);
+            // pair pr + 1 has to have landed before the barrier; the newer one (NP = 3) may fly
+            const int newest = min(npair - 1, pr + NP - 1);
+            if (newest - (pr + 1) >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPL) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        return;                                                        // the consumers finish alone
+    }
+    // -------------------------------------------------------------------- consumer waves
+    const int wm = wave / WGN, wn = wave % WGN;
+    f32x16 acc[1][TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[0][j][e] = 0.f;
+    int a_sw[2], b_sw[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        a_sw[ks] = swz(wm * 32 + r, 2 * ks + h);
+        b_sw[ks] = BM * ROWB + swz(wn * TN * 32 + r, 2 * ks + h);
+    }
+    const int s_first = m0 / ohw;
+    const int g_row = (min(m0 + wm * 32 + r, p.M - 1) / ohw - s_first) * p.Cin + 8 * h;
+    __syncthreads();                                                   // (the loaders' first barrier; also publishes this wave's gate rows)
+    for (int pr = 0; pr < npair; ++pr) {
+        const unsigned char* bufp = lds + (pr % NP) * PBUF;
+        // the four 16-channel steps of the pair: all A fragments and gate rows first (one LDS round trip), then per step the B
+        // fragments and the MFMAs
+        uint4 af[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            af[q] = *reinterpret_cast<const uint4*>(bufp + (q >> 1) * BUF + a_sw[q & 1]);
+            const float* gs = reinterpret_cast<const float*>(lds + GATE_OFF) + g_row + pr * (2 * CK) + q * 16;
+            const float4 g0 = *reinterpret_cast<const float4*>(gs), g1 = *reinterpret_cast<const float4*>(gs + 4);
+            af[q] = T16<F16>::gate8(af[q], g0, g1);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint4 bfr[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const uint4*>(bufp + (q >> 1) * BUF + b_sw[q & 1] + j * 2048);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[0][j] = T16<F16>::mfma32(bfr[j], af[q], acc[0][j]);
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+    conv_epilogue<1, TN, WGM, WGN, true, F16>(p, acc, lds, m0, n0, wm, wn, r, h, tid, bias_off);
+}
+
+// -------------------------------------------------------------------------------------------
 // 3x3 convolutions (stride 1 pad 1, or stride 2 with TF-SAME bottom/right padding) with the same lean k loop as
 // gemm1x1_dma_kernel. The A operand is addressed as a RAW BUFFER: a lane's byte offset is fixed (its output pixel,
 // window origin), the filter tap and channel block are one SCALAR offset per k-step, and padding costs no data
@@ -1818,6 +1951,14 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
             // the 8 x 8 stages: 128-row tiles leave at most one workgroup per CU (a half-batch lane: half the CUs);
             // 64 x 192 tiles of 4 waves measured +14 % (384 outputs) and +41 % (640 outputs) at 8192 rows
             const long wgs128 = (long)cdiv(a.M, 128) * cdiv(a.Cout, a.Cout % 320 == 0 ? 320 : 192);
+            static const bool lw_on = [] { const char* e = getenv("ISB_LW"); return !e || atoi(e) != 0; }();   // A/B switch
+            if (lw_on && ohw == 64 && a.M >= 4096 && a.Cin % 64 == 0 && a.Cin >= 256 && a.splits <= 1 && !a.out_f32 &&
+                (a.Cout % 192 == 0 || a.Cout % 320 == 0) && (size_t)a.M * a.Cin * 2 < 0xffffffffull &&
+                2 * a.Cin * 4 + (a.Cout % 192 == 0 || a.M < 16384 ? 6 * 320 : 4 * 448) * 64 + 2048 <= 160 * 1024) {
+                // the 8 x 8 stages: 128-row tiles with loader waves, one workgroup per CU (gemm1x1_lw_kernel; bit-identical).
+                // 2304 -> 384: 53.7 vs 60.3 us at 256 frames, 39.6 vs 46.7 at 128; 3840 -> 640: 113.7 vs 123.0 / 76.0 vs 84.1
+                v = (a.Cout % 192 == 0 || a.M < 16384) ? 155 : 156;
+            } else
             if (ohw % 64 == 0 && a.Cout % 64 == 0 && ((a.Cout % 192 == 0 && wgs128 <= 256) || (a.Cout % 320 == 0 && wgs128 < 256))) v = 146;
             else if (a.Cout % 320 == 0) v = 144;       // 128 x 320
             else if (a.Cout == 224) v = 143;           // 128 x 224
@@ -1854,7 +1995,7 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
         set_error("conv_igemm: act_after_res takes act 2-4 on the kernels with the shared bf16 epilogue (variant %d)", v);
         return ISB_ERR_INVALID;
     }
-    if (a.f16 && !(v == 131 || v == 132 || v == 138 || v == 141 || v == 144 || v == 146 || v == 147 || v == 149 || v == 185 || v == 186)) {
+    if (a.f16 && !(v == 131 || v == 132 || v == 138 || v == 141 || v == 144 || v == 146 || v == 147 || v == 149 || v == 155 || v == 156 || v == 185 || v == 186)) {
         set_error("conv_igemm: fp16 operands are implemented by variants 131 / 132 / 138, 141 / 144 / 146 / 147 / 149 and 185 / 186 (got %d)", v);
         return ISB_ERR_INVALID;
     }
@@ -2180,6 +2321,39 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
         case 196: ISB_CONV_LAUNCH_G1GN(1, 3, 2, 2, 3); break;   //  64 x 192
         case 197: ISB_CONV_LAUNCH_G1GN(1, 2, 2, 2, 3); break;   //  64 x 128
         case 153: ISB_CONV_LAUNCH_G1G(1, 6, 8, 1); break;   // 256 x 192, eight waves
+        case 155: case 156: {                                // 128 x 192 / 128 x 320 with loader waves (gemm1x1_lw_kernel), one workgroup per CU
+            const int tn = v == 155 ? 3 : 5, bn = 64 * tn, nb = tn <= 3 ? 6 : 4;      // k-step buffers (= 2 x the ring's pair buffers)
+            const int ohw_ = a.OH * a.OW;
+            if (!a.gate || a.KH != 1 || a.stride != 1 || a.pad != 0 || (ohw_ % 128 != 0 && 128 % ohw_ != 0) || a.splits > 1 || a.out_f32 ||
+                a.Cout % 64 != 0 || a.Cin % 64 != 0 || a.Cin < 256 || (size_t)a.M * a.Cin * 2 >= 0xffffffffull) {
+                set_error("conv_igemm: variants 155 / 156 are gated 1x1 GEMMs (Cin %% 64 == 0, >= 256) on sample-aligned 128-row tiles, bf16 / fp16 output");
+                return ISB_ERR_INVALID;
+            }
+            const int ns = 128 > ohw_ ? 128 / ohw_ : 1;
+            const int ring = nb * (128 + bn) * ROWB + ns * a.Cin * 4;
+            const int stage = 128 * (bn * 2 + 16);
+            aa.grid_bias_off = ring > stage ? ring : stage;
+            const int bytes = aa.grid_bias_off + bn * 4;
+            if (bytes > 160 * 1024) {
+                set_error("conv_igemm: variant %d needs %d bytes of LDS (K = %d)", v, bytes, a.Cin);
+                return ISB_ERR_INVALID;
+            }
+            const dim3 g = conv_grid(aa, 128, bn);
+#define ISB_LW_GO(TN_, F16_)                                                                                             \
+    do {                                                                                                                 \
+        auto kern = gemm1x1_lw_kernel<TN_, F16_>;                                                                        \
+        static int attr_bytes = 0;                                                                                       \
+        if (bytes > attr_bytes) {                                                                                        \
+            ISB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));          \
+            attr_bytes = bytes;                                                                                          \
+        }                                                                                                                \
+        hipLaunchKernelGGL(kern, g, dim3(768), bytes, st, aa);                                                           \
+    } while (0)
+            if (v == 155) { if (a.f16) ISB_LW_GO(3, true); else ISB_LW_GO(3, false); }
+            else { if (a.f16) ISB_LW_GO(5, true); else ISB_LW_GO(5, false); }
+#undef ISB_LW_GO
+            break;
+        }
 #undef ISB_CONV_LAUNCH_G1G
 #undef ISB_CONV_LAUNCH_G1GH
 #undef ISB_CONV_LAUNCH_G1GN

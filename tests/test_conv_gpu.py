@@ -385,7 +385,7 @@ F16_CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [0, 131, 132, 138, 141, 144, 146, 147, 185, 186, 3147, 2138])
+@pytest.mark.parametrize("variant", [0, 131, 132, 138, 141, 144, 146, 147, 155, 156, 185, 186, 3147, 2138])
 @pytest.mark.parametrize("case", F16_CASES)
 def test_conv_f16_operands(case, variant):
     """fp16 operands (ConvArgs.f16, isb_hpe_cfg.precision 0: the 8x8 stages): x / weights / residual / output in IEEE
@@ -395,7 +395,7 @@ def test_conv_f16_operands(case, variant):
     tv = variant % 1000
     if tv in (131, 132, 138, 185, 186) and use_gate:
         pytest.skip("un-gated kernels")
-    if tv in (141, 144, 146, 147) and not use_gate:
+    if tv in (141, 144, 146, 147, 155, 156) and not use_gate:
         pytest.skip("gated kernels")
     if tv in (185, 186) and (Cin != 384 or not act):
         pytest.skip("weights-stationary fp16 form: K = 384 with SiLU")
@@ -467,3 +467,25 @@ def test_dwconv_map8_is_bit_identical(HW, Cc, f16):
     g, pg, _ = dwconv_debug(xin, w, scale, shift, stride=1, in_f16=f16, out_f16=f16, general=True)
     assert np.array_equal(a, g) and np.array_equal(pa, pg)
     assert np.abs(pa).max() > 0
+
+
+@pytest.mark.parametrize("f16", [False, True])
+@pytest.mark.parametrize("shape", [(9, 2304, 384, 155), (5, 3840, 640, 156), (3, 1344, 384, 155), (2, 2304, 640, 156), (1, 768, 192, 155)])
+def test_gated_projection_with_loader_waves_is_bit_identical(shape, f16):
+    """gemm1x1_lw_kernel (variants 155 / 156: 128-row tiles, 8 consumer + 4 loader waves, one barrier per k-step) against the
+    tile kernel 146 / 144 on the 8 x 8 stages' projections: same LDS images, gate arithmetic and k order -> the same bits
+    (ragged M: 9 / 5 / 3 frames of 64 rows do not fill the last 128-row tile)."""
+    from isbfsar_amd.hpe_engine import f32_to_f16
+    B, Cin, Cout, v = shape
+    rng = np.random.default_rng(Cin + Cout + B)
+    x = rng.normal(0, 1, (B, 8, 8, Cin)).astype(np.float32)
+    w = (rng.normal(0, 1, (Cout, 1, 1, Cin)) / np.sqrt(Cin)).astype(np.float32)
+    scale = rng.uniform(0.8, 1.2, Cout).astype(np.float32)
+    shift = rng.uniform(-0.1, 0.1, Cout).astype(np.float32)
+    res = rng.normal(0, 1, (B, 8, 8, Cout)).astype(np.float32)
+    gate = rng.uniform(0.1, 0.9, (B, Cin)).astype(np.float32)
+    cvt = f32_to_f16 if f16 else f32_to_bf16
+    a, _ = conv_debug(cvt(x), w, scale, shift, 1, 1, 0, cvt(res), gate, variant=v, f16=f16)
+    ref_v = 146 if Cout % 192 == 0 else 144
+    b, _ = conv_debug(cvt(x), w, scale, shift, 1, 1, 0, cvt(res), gate, variant=ref_v, f16=f16)
+    assert np.array_equal(a, b)
