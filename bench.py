@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--host-input", action="store_true",
                     help="hpe workload: frames start in (pinned) HOST memory each step, isb_hpe_forward_host copies them (PCIe-inclusive "
                          "rate: the reference's Runner pattern; never the headline value)")
+    ap.add_argument("--pipelined", action="store_true",
+                    help="with --host-input: two pinned capture buffers and two batches in flight (isb_hpe_submit_host / "
+                         "isb_hpe_wait_host): batch k + 1's PCIe transfer hides behind batch k's kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="items per CPU-baseline iteration (0 = the workload's default)")
     ap.add_argument("--cpu-iters", type=int, default=10, help="timed CPU-baseline iterations (median reported; BASELINE.md 4)")

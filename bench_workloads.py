@@ -184,14 +184,26 @@ class HpeWorkload(_HpeBase):
         self._setup_hpe(args, rank, dev)
         self.world = world
         self.host_input = bool(getattr(args, "host_input", False))
+        self.pipelined = bool(getattr(args, "pipelined", False)) and self.host_input
         if self.host_input:          # pinned host frames: what a capture thread would hand over (utils/input.py -> main.py:74)
             self.frames_pinned = self.torch.from_numpy(self.frames_host).pin_memory().numpy()
+        if self.pipelined:           # two capture buffers, two batches in flight: submit batch k + 1, then wait for batch k
+            self.frames_pinned2 = self.torch.from_numpy(self.frames_host).pin_memory().numpy()
+            self.k = 0
+            self.inflight = 0
 
     def units_per_step(self):
         return self.B
 
     def step(self):
-        if self.host_input:          # H2D of the frames + kernels + D2H of the poses + synchronise, inside the step
+        if self.pipelined:           # steady state: one submit + one wait per step
+            self.hpe.submit((self.frames_pinned, self.frames_pinned2)[self.k & 1], self.bbox_host)
+            self.k += 1
+            self.inflight += 1
+            if self.inflight == 2:
+                self.out = self.hpe.wait()
+                self.inflight -= 1
+        elif self.host_input:        # H2D of the frames + kernels + D2H of the poses + synchronise, inside the step
             self.out = self.hpe.forward(self.frames_pinned, self.bbox_host)
         else:
             self.out = self.hpe.forward(self.frames, self.bbox)
@@ -209,8 +221,9 @@ class HpeWorkload(_HpeBase):
     def config(self, world):
         return {"workload": f"BASELINE configs[1]: B={self.B} synthetic 640x480 frames/GPU, HPE only "
                             "(homography crop, EfficientNetV2-L bf16, head, decode, reconstruction)"
-                            + (" -- frames in pinned HOST memory, H2D + D2H inside the step (isb_hpe_forward_host)" if self.host_input else ""),
-                "input": "host (pinned)" if self.host_input else "resident in HBM",
+                            + (" -- frames in pinned HOST memory, H2D + D2H inside the step (isb_hpe_forward_host)" if self.host_input else "")
+                            + ("; two batches in flight (isb_hpe_submit_host / isb_hpe_wait_host)" if self.pipelined else ""),
+                "input": ("host (pinned), two batches in flight" if self.pipelined else "host (pinned)") if self.host_input else "resident in HBM",
                 "per_gpu_batch": self.B, "n_joints": self.J, "parallelism": f"dp{world}"}
 
 

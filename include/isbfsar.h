@@ -177,6 +177,17 @@ int isb_hpe_forward(isb_hpe* h, const uint8_t* d_frames, const int32_t* d_bbox, 
                     uint8_t* d_valid, void* stream);
 int isb_hpe_forward_host(isb_hpe* h, const uint8_t* h_frames, const int32_t* h_bbox, int32_t B, float* h_joints,
                          uint8_t* h_valid);
+/* The same call split in two for a caller that has batch k + 1 in hand while batch k computes (no counterpart in the
+ * reference, whose Runner copies and waits inside one call, utils/tensorrt_runner.py:64-77):
+ *   isb_hpe_submit_host  enqueues everything -- frames H2D on the copy engine (the handle's copy stream), the pose pass behind
+ *                        it, results D2H into pinned staging -- and returns; h_frames (PINNED memory, else the call blocks for
+ *                        the copy), h_joints and h_valid must stay valid until the matching wait;
+ *   isb_hpe_wait_host    blocks until the OLDEST outstanding submission is finished and writes its h_joints / h_valid.
+ * Up to two submissions may be in flight (a third submit first finishes the oldest, writing its results then). Submissions run
+ * in order on the handle's stream: batch k + 1's transfer hides behind batch k's kernels, and the lanes go from batch to batch
+ * without draining. Results are the bits isb_hpe_forward_host gives. ISB_ERR_STATE from wait when nothing is outstanding. */
+int isb_hpe_submit_host(isb_hpe* h, const uint8_t* h_frames, const int32_t* h_bbox, int32_t B, float* h_joints, uint8_t* h_valid);
+int isb_hpe_wait_host(isb_hpe* h);
 
 /* detector post-processing, hpe.py:59-79 + misc.py:64-107: YOLOv4 export tensors
  *   d_boxes [B,4032,1,4] f32 (x1,y1,x2,y2 normalised), d_confs [B,4032,80] f32
@@ -296,6 +307,11 @@ int isb_debug_gemm_f32(int32_t device, const float* h_A, const float* h_W, const
 int isb_debug_dwconv(int32_t device, const uint16_t* h_x, const float* h_w, const float* h_scale, const float* h_shift,
                      int32_t B, int32_t H, int32_t C, int32_t stride, int32_t iters, uint16_t* h_out, float* h_pooled,
                      float* ms_per_iter);
+/* the same launch with the squeeze-excite FC1 riding in it (DwArgs.se_w1): h_se_w1 f32 [cse,C], cse <= 160;
+ *   h_se_part f32 [*n_parts][B][cse] receives each channel slab's partial sums (room for 32 slabs), *n_parts their count */
+int isb_debug_dwconv_fc1(int32_t device, const uint16_t* h_x, const float* h_w, const float* h_scale, const float* h_shift,
+                         int32_t B, int32_t H, int32_t C, int32_t stride, int32_t iters, uint16_t* h_out, float* h_pooled,
+                         float* ms_per_iter, const float* h_se_w1, int32_t cse, float* h_se_part, int32_t* n_parts);
 
 /* ------------------------------------------------------------------------------------------
  * Glue between the two stages (main.py:102-105 + ar.py:42-50): root-centre every pose on joint 0,

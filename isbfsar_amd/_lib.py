@@ -66,6 +66,8 @@ SIGNATURES = {
     "isb_hpe_set_joint_map": (C.c_int, [_P, _P, _P, C.c_int32]),
     "isb_hpe_forward": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P]),
     "isb_hpe_forward_host": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P]),
+    "isb_hpe_submit_host": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P]),
+    "isb_hpe_wait_host": (C.c_int, [_P]),
     "isb_hpe_set_augmentations": (C.c_int, [_P, C.c_int32, _P, _P]),
     "isb_hpe_crop_params_host": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P]),
     "isb_hpe_warp_host": (C.c_int, [_P, _P, _P, C.c_int32, _P]),
@@ -99,6 +101,8 @@ SIGNATURES = {
     "isb_debug_fused_mb": (C.c_int, [C.c_int32] + [_P] * 8 + [C.c_int32] * 7 + [_P, C.POINTER(C.c_float)]),
     "isb_debug_gemm_f32": (C.c_int, [C.c_int32] + [_P] * 5 + [C.c_int32] * 10 + [_P, C.POINTER(C.c_float)]),
     "isb_debug_dwconv": (C.c_int, [C.c_int32] + [_P] * 4 + [C.c_int32] * 5 + [_P, _P, C.POINTER(C.c_float)]),
+    "isb_debug_dwconv_fc1": (C.c_int, [C.c_int32] + [_P] * 4 + [C.c_int32] * 5 + [_P, _P, C.POINTER(C.c_float), _P, C.c_int32, _P,
+                                       C.POINTER(C.c_int32)]),
     "isb_debug_conv": (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, _P] + [C.c_int32] * 10 + [_P, C.POINTER(C.c_float)]),
 }
 # NOTE: every entry point must be listed here BEFORE the first lib() call: a function without

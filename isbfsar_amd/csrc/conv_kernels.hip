@@ -1036,16 +1036,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_dma_kernel(ConvArgs p)
 // The loaders end after the loop (an ended wave is no longer a party to s_barrier); the consumers run the shared epilogue.
 // Same LDS images, fragment reads, gate arithmetic and k order as gemm1x1_dma_kernel<.., GATE = 1>: bit-identical (tested).
 // -------------------------------------------------------------------------------------------
-template <int TN, bool F16>
-__global__ __launch_bounds__(768) void gemm1x1_lw_kernel(ConvArgs p) {
-    constexpr int WGM = 4, WGN = 2, NCW = WGM * WGN, NLW = 4;          // consumer / loader waves
+// WGM x WGN consumer waves of 32 x (32 TN) sub-tiles + 4 loader waves; NP pair buffers in the ring
+template <int WGM, int WGN, int TN, int NP, bool F16>
+__global__ __launch_bounds__(64 * (WGM * WGN + 4)) void gemm1x1_lw_kernel(ConvArgs p) {
+    constexpr int NCW = WGM * WGN, NLW = 4;                            // consumer / loader waves
+    constexpr int NTH = 64 * (NCW + NLW);
     constexpr int BM = 32 * WGM, BN = 32 * TN * WGN;
-    constexpr int PIECES = (BM + BN) / 16, PPL = PIECES / NLW;         // 1-KiB pieces per k-step, per loader
-    static_assert(PIECES % NLW == 0, "pieces split evenly over the loaders (immediate vmcnt)");
-    constexpr int BUF = (BM + BN) * ROWB;
+    constexpr int PIECES = ((BM + BN) / 16 + NLW - 1) / NLW * NLW, PPL = PIECES / NLW;   // 1-KiB pieces per k-step (B rows padded
+    constexpr int BUF = PIECES * 16 * ROWB;                            // up to whole rounds of the loaders: immediate vmcnt), per loader
     // the loop runs on PAIRS of k-steps (one barrier per 64 channels: the twelve waves' meeting costs as much as a k-step's
     // MFMAs): ring of NP pair buffers, NP - 1 pairs in flight
-    constexpr int NP = TN <= 3 ? 3 : 2;                                // 120 / 112 KiB
     constexpr int PBUF = 2 * BUF;
     constexpr int GATE_OFF = NP * PBUF;
     unsigned char* const lds = conv_lds_dyn;
@@ -1063,7 +1063,7 @@ __global__ __launch_bounds__(768) void gemm1x1_lw_kernel(ConvArgs p) {
         const int ns = min(m0 + BM - 1, p.M - 1) / ohw - s_first + 1;
         const float* src = p.gate + (size_t)s_first * p.Cin;
         float* dst = reinterpret_cast<float*>(lds + GATE_OFF);
-        for (int idx = tid * 4; idx < ns * p.Cin; idx += 768 * 4)
+        for (int idx = tid * 4; idx < ns * p.Cin; idx += NTH * 4)
             *reinterpret_cast<float4*>(dst + idx) = *reinterpret_cast<const float4*>(src + idx);
     }
     if (wave >= NCW) {
@@ -2321,36 +2321,39 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
         case 196: ISB_CONV_LAUNCH_G1GN(1, 3, 2, 2, 3); break;   //  64 x 192
         case 197: ISB_CONV_LAUNCH_G1GN(1, 2, 2, 2, 3); break;   //  64 x 128
         case 153: ISB_CONV_LAUNCH_G1G(1, 6, 8, 1); break;   // 256 x 192, eight waves
-        case 155: case 156: {                                // 128 x 192 / 128 x 320 with loader waves (gemm1x1_lw_kernel), one workgroup per CU
-            const int tn = v == 155 ? 3 : 5, bn = 64 * tn, nb = tn <= 3 ? 6 : 4;      // k-step buffers (= 2 x the ring's pair buffers)
+        case 155: case 156: {                                // loader-wave GEMMs (gemm1x1_lw_kernel), one workgroup per CU:
+            // 155: 128 x 192, 156: 128 x 320 (the gated projections of the 8 x 8 stages)
+            const int bm = 128, bn = v == 155 ? 192 : 320;
+            const int np_ = v == 155 ? 3 : 2;
+            const int pieces = (((bm + bn) / 16 + 3) / 4) * 4;
             const int ohw_ = a.OH * a.OW;
-            if (!a.gate || a.KH != 1 || a.stride != 1 || a.pad != 0 || (ohw_ % 128 != 0 && 128 % ohw_ != 0) || a.splits > 1 || a.out_f32 ||
+            if (!a.gate || a.KH != 1 || a.stride != 1 || a.pad != 0 || (ohw_ % bm != 0 && bm % ohw_ != 0) || a.splits > 1 || a.out_f32 ||
                 a.Cout % 64 != 0 || a.Cin % 64 != 0 || a.Cin < 256 || (size_t)a.M * a.Cin * 2 >= 0xffffffffull) {
                 set_error("conv_igemm: variants 155 / 156 are gated 1x1 GEMMs (Cin %% 64 == 0, >= 256) on sample-aligned 128-row tiles, bf16 / fp16 output");
                 return ISB_ERR_INVALID;
             }
-            const int ns = 128 > ohw_ ? 128 / ohw_ : 1;
-            const int ring = nb * (128 + bn) * ROWB + ns * a.Cin * 4;
-            const int stage = 128 * (bn * 2 + 16);
+            const int ns = bm > ohw_ ? bm / ohw_ : 1;
+            const int ring = np_ * 2 * pieces * 16 * ROWB + ns * a.Cin * 4;
+            const int stage = bm * (bn * 2 + 16);
             aa.grid_bias_off = ring > stage ? ring : stage;
             const int bytes = aa.grid_bias_off + bn * 4;
             if (bytes > 160 * 1024) {
                 set_error("conv_igemm: variant %d needs %d bytes of LDS (K = %d)", v, bytes, a.Cin);
                 return ISB_ERR_INVALID;
             }
-            const dim3 g = conv_grid(aa, 128, bn);
-#define ISB_LW_GO(TN_, F16_)                                                                                             \
+            const dim3 g = conv_grid(aa, bm, bn);
+#define ISB_LW_GO(WGM_, WGN_, TN_, NP_, F16_)                                                                            \
     do {                                                                                                                 \
-        auto kern = gemm1x1_lw_kernel<TN_, F16_>;                                                                        \
+        auto kern = gemm1x1_lw_kernel<WGM_, WGN_, TN_, NP_, F16_>;                                                       \
         static int attr_bytes = 0;                                                                                       \
         if (bytes > attr_bytes) {                                                                                        \
             ISB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));          \
             attr_bytes = bytes;                                                                                          \
         }                                                                                                                \
-        hipLaunchKernelGGL(kern, g, dim3(768), bytes, st, aa);                                                           \
+        hipLaunchKernelGGL(kern, g, dim3(64 * (WGM_ * WGN_ + 4)), bytes, st, aa);                                        \
     } while (0)
-            if (v == 155) { if (a.f16) ISB_LW_GO(3, true); else ISB_LW_GO(3, false); }
-            else { if (a.f16) ISB_LW_GO(5, true); else ISB_LW_GO(5, false); }
+            if (v == 155) { if (a.f16) ISB_LW_GO(4, 2, 3, 3, true); else ISB_LW_GO(4, 2, 3, 3, false); }
+            else { if (a.f16) ISB_LW_GO(4, 2, 5, 2, true); else ISB_LW_GO(4, 2, 5, 2, false); }
 #undef ISB_LW_GO
             break;
         }
@@ -2557,7 +2560,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_pool_kernel(DwArgs p) {
 // TF-SAME padding becomes data -- and the taps read LDS (conflict-free: the 16 lanes of a ds_read_b128 group cover whole
 // pixels). Same thread <-> (pixel quad, channel chunk) map, same tap order, same accumulators and pool order as
 // dwconv3x3_pool_kernel<1>: bit-identical (tested). 8 x 8: 3.5 -> 4.7 TB/s.
-template <bool F16, int HW>
+template <bool F16, int HW, bool FC1 = false>
 __global__ __launch_bounds__(256) void dwconv3x3_map_kernel(DwArgs p) {
     constexpr int NQ = HW * HW / 4;                        // pixel quads per sample
     constexpr int PQ = NQ >= 32 ? 32 : NQ;                 // quad slots in the workgroup (16 on 8 x 8 maps)
@@ -2567,6 +2570,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_map_kernel(DwArgs p) {
     constexpr int QPR = HW / 4;                            // quads per row
     __shared__ __attribute__((aligned(16))) uint4 tile[TW * TW * CH];     // [y + 1][x + 1][chunk]
     __shared__ float red[PQ][CH * 8 + 1];
+    __shared__ __attribute__((aligned(16))) float pmean[FC1 ? 128 : 4];
     const int tid = threadIdx.x;
     const int cl = tid % CH, pq = tid / CH;
     const int b = blockIdx.y, c0 = blockIdx.x * (CH * 8);
@@ -2654,13 +2658,45 @@ __global__ __launch_bounds__(256) void dwconv3x3_map_kernel(DwArgs p) {
     if (p.pooled) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) red[pq][cl * 8 + e] = psum[e];
+        // FC1: this slab's rows of the squeeze-excite weights, requested before the pool sums meet (same thread <-> (row, channel)
+        // map, same sums as dwconv3x3_pool_kernel's: bit-identical partials)
+        const int sub = tid & 31, grp = tid >> 5;
+        bool fc_ok = false;
+        float4 wv[FC1 ? 20 : 1];
+        if constexpr (FC1) {
+            fc_ok = sub * 4 < min(CH * 8, p.C - c0);
+#pragma unroll
+            for (int q = 0; q < 20; ++q) {
+                const int j = grp + 8 * q;
+                wv[q] = (fc_ok && j < p.cse) ? *reinterpret_cast<const float4*>(p.se_w1 + (size_t)j * p.C + c0 + sub * 4)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
         __syncthreads();
         if (tid < CH * 8) {
             const int cc = c0 + tid;
+            float mean = 0.f;
             if (cc < p.C) {
                 float t = 0.f;
                 for (int s2 = 0; s2 < PQ; ++s2) t += red[s2][tid];
-                p.pooled[(size_t)b * p.C + cc] = t / (float)(HW * HW);
+                mean = t / (float)(HW * HW);
+                p.pooled[(size_t)b * p.C + cc] = mean;
+            }
+            if constexpr (FC1) pmean[tid] = mean;
+        }
+        if constexpr (FC1) {
+            __syncthreads();
+            const float4 pv = fc_ok ? *reinterpret_cast<const float4*>(&pmean[sub * 4]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float racc[20], rup[20];
+#pragma unroll
+            for (int q = 0; q < 20; ++q)
+                racc[q] = row16_sum(fmaf(pv.w, wv[q].w, fmaf(pv.z, wv[q].z, fmaf(pv.y, wv[q].y, pv.x * wv[q].x))));
+#pragma unroll
+            for (int q = 0; q < 20; ++q) rup[q] = __shfl_xor(racc[q], 16, 64);
+#pragma unroll
+            for (int q = 0; q < 20; ++q) {
+                const int j = grp + 8 * q;
+                if (sub == 0 && j < p.cse) p.se_part[((size_t)blockIdx.x * p.B + b) * p.cse + j] = racc[q] + rup[q];
             }
         }
     }
@@ -2694,16 +2730,17 @@ int launch_dwconv3x3(const DwArgs& a, hipStream_t st) {
         set_error("dwconv3x3: fp16 forms are stride 1 fp16 -> fp16 and stride 2 bf16 -> fp16 (in_f16=%d out_f16=%d stride=%d)", a.in_f16, a.out_f16, a.stride);
         return ISB_ERR_INVALID;
     }
-    if (!a.se_w1 && a.stride == 1 && a.H == a.W && (a.H == 8 || a.H == 16) && a.OH == a.H && a.OW == a.W && a.pad == 1 && (form == 0 || form == 3) &&
+    if (a.stride == 1 && a.H == a.W && (a.H == 8 || a.H == 16) && a.OH == a.H && a.OW == a.W && a.pad == 1 && (form == 0 || form == 3) &&
         !a.general && dw_map8_on()) {
         // grid.x = dw_slabs(a): slabs of 128 (8 x 8 maps) / 64 (16 x 16 maps) channels, as in the general kernel
-        if (a.H == 8) {
-            if (form == 3) hipLaunchKernelGGL((dwconv3x3_map_kernel<true, 8>), grid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((dwconv3x3_map_kernel<false, 8>), grid, dim3(256), 0, st, a);
-        } else {
-            if (form == 3) hipLaunchKernelGGL((dwconv3x3_map_kernel<true, 16>), grid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((dwconv3x3_map_kernel<false, 16>), grid, dim3(256), 0, st, a);
-        }
+#define ISB_DW_MAP(F16_, HW_)                                                                                            \
+    do {                                                                                                                 \
+        if (a.se_w1) hipLaunchKernelGGL((dwconv3x3_map_kernel<F16_, HW_, true>), grid, dim3(256), 0, st, a);             \
+        else hipLaunchKernelGGL((dwconv3x3_map_kernel<F16_, HW_, false>), grid, dim3(256), 0, st, a);                    \
+    } while (0)
+        if (a.H == 8) { if (form == 3) ISB_DW_MAP(true, 8); else ISB_DW_MAP(false, 8); }
+        else { if (form == 3) ISB_DW_MAP(true, 16); else ISB_DW_MAP(false, 16); }
+#undef ISB_DW_MAP
         ISB_LAUNCHED("dwconv3x3_map", st);
         return ISB_OK;
     }

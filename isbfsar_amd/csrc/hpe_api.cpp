@@ -109,6 +109,22 @@ struct isb_hpe {
     // 256 copy calls cost more than the bytes they save). ISB_HPE_ROI: 1 = gather (default), 0 = whole frames.
     int roi_mode = 1;
     DevBuf hs_H, hs_newK, hs_R, hs_roi;
+    // isb_hpe_submit_host / isb_hpe_wait_host: up to two host batches in flight. A slot owns its device staging, pinned result
+    // buffers and events; the frames of batch k + 1 cross PCIe on the copy engine (copy_stream) while batch k computes, and the
+    // lanes run batch after batch without a drain in between (what the device-pointer entry does for a resident caller)
+    struct HostSlot {
+        DevBuf frames, bbox, joints, valid;
+        void* pin = nullptr;            // hipHostMalloc: [B * n_out * 12 bytes of joints | B bytes of valid]
+        size_t pin_bytes = 0;
+        std::vector<int32_t> boxes;     // the host copy the asynchronous upload reads
+        hipEvent_t h2d = nullptr, done = nullptr;
+        float* user_joints = nullptr;
+        uint8_t* user_valid = nullptr;
+        int B = 0, cap = 0;
+        bool busy = false;
+    };
+    HostSlot slot[2];
+    int sub_head = 0, sub_tail = 0;     // next slot to fill / oldest outstanding one
     const RoiDesc* roi_dev = nullptr;   // set for the duration of one isb_hpe_forward_host call
     const uint8_t* roi_src = nullptr;   // ... with the device address of the caller's mapped host frames: every lane gathers ITS
                                         // frames on its own stream, so lane 1's rectangles cross PCIe while lane 0 already computes
@@ -439,6 +455,10 @@ extern "C" int isb_hpe_create(const isb_hpe_cfg* cfg, isb_hpe** out) {
     ISB_HIP(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
     ISB_HIP(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
     for (auto& e : h->h2d_ev) ISB_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& sl : h->slot) {
+        ISB_HIP(hipEventCreateWithFlags(&sl.h2d, hipEventDisableTiming));
+        ISB_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    }
     for (int l = 1; l < kMaxLanes; ++l) {
         ISB_HIP(hipStreamCreateWithFlags(&h->lanes[l].side, hipStreamNonBlocking));
         ISB_HIP(hipEventCreateWithFlags(&h->join_ev[l], hipEventDisableTiming));
@@ -463,6 +483,11 @@ extern "C" void isb_hpe_destroy(isb_hpe* h) {
     }
     if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+    for (auto& sl : h->slot) {
+        if (sl.h2d) (void)hipEventDestroy(sl.h2d);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.pin) (void)hipHostFree(sl.pin);
+    }
     for (auto& e : h->h2d_ev)
         if (e) (void)hipEventDestroy(e);
     delete h;
@@ -676,6 +701,71 @@ extern "C" int isb_hpe_forward(isb_hpe* h, const uint8_t* d_frames, const int32_
     });
 }
 
+// the frames as the device sees them, if the caller's buffer is mapped pinned memory (hipHostMalloc / hipHostRegister;
+// torch.Tensor.pin_memory()): only then can a kernel pull rectangles out of it. Null: pageable memory, whole frames are copied.
+static const uint8_t* mapped_frames(isb_hpe* h, const uint8_t* frames, int B) {
+    if (!(h->roi_mode > 0 && B >= kRoiMinBatch && h->cfg.width % 16 == 0)) return nullptr;
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, frames) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer)
+        return static_cast<const uint8_t*>(at.devicePointer);
+    (void)hipGetLastError();                     // pageable memory: not an error
+    return nullptr;
+}
+
+// per frame the source rectangle its crop can reach (device bbox d_bbox -> crop homographies -> a 9-KB round trip -> host bounds);
+// `off` = bytes of the packed image. Synchronises `st`.
+static int host_rois(isb_hpe* h, const int32_t* db, int B, hipStream_t st, std::vector<RoiDesc>& roi, uint64_t& off) {
+    const int FW = h->cfg.width, FH = h->cfg.height;
+    // 1. the crop homographies of the whole batch (the kernel isb_hpe_forward runs again per lane: same inputs, same bits)
+    if (h->hs_H.bytes < (size_t)B * 36) {
+        ISB_TRY(h->hs_H.alloc((size_t)B * 36));
+        ISB_TRY(h->hs_newK.alloc((size_t)B * 72));
+        ISB_TRY(h->hs_R.alloc((size_t)B * 72));
+    }
+    if (h->hs_roi.bytes < (size_t)B * sizeof(RoiDesc)) ISB_TRY(h->hs_roi.alloc((size_t)B * sizeof(RoiDesc)));
+    CropParamArgs ca{};
+    ca.bbox = db;
+    for (int i = 0; i < 9; ++i) ca.K[i] = h->K[i];
+    ca.H = h->hs_H.as<float>(); ca.newK = h->hs_newK.as<double>(); ca.R = h->hs_R.as<double>(); ca.B = B;
+    ISB_TRY(launch_crop_params(ca, st));
+    std::vector<float> Hh((size_t)B * 9);
+    ISB_HIP(hipMemcpyAsync(Hh.data(), h->hs_H.p, (size_t)B * 36, hipMemcpyDeviceToHost, st));
+    ISB_HIP(hipStreamSynchronize(st));
+    // 2. per frame: the bounding rectangle of the crop square's image under H. The map is projective with a positive
+    // denominator over the square, so the square's image is the convex hull of its corners' images; + 2 px for the
+    // float32 evaluation and the truncation in the kernel. Degenerate H -> the whole frame.
+    roi.assign(B, RoiDesc{});
+    off = 0;
+    for (int b = 0; b < B; ++b) {
+        const float* Hb = Hh.data() + (size_t)b * 9;
+        double xlo = 1e30, xhi = -1e30, ylo = 1e30, yhi = -1e30;
+        bool ok = std::isfinite(Hb[8]) && Hb[8] != 0.f;
+        for (int c = 0; c < 4 && ok; ++c) {
+            const double x = (c & 1) ? 255.0 : 0.0, y = (c & 2) ? 255.0 : 0.0, h8 = Hb[8];
+            const double k = Hb[6] / h8 * x + Hb[7] / h8 * y + 1.0;
+            if (!(k > 1e-6)) { ok = false; break; }
+            const double xs = (Hb[0] / h8 * x + Hb[1] / h8 * y + Hb[2] / h8) / k;
+            const double ys = (Hb[3] / h8 * x + Hb[4] / h8 * y + Hb[5] / h8) / k;
+            if (!std::isfinite(xs) || !std::isfinite(ys)) { ok = false; break; }
+            xlo = std::min(xlo, xs); xhi = std::max(xhi, xs); ylo = std::min(ylo, ys); yhi = std::max(yhi, ys);
+        }
+        int x0 = 0, x1 = FW - 1, y0 = 0, y1 = FH - 1;
+        if (ok) {
+            x0 = (int)std::max(0.0, std::floor(std::min(xlo, 1e9)) - 2.0);
+            y0 = (int)std::max(0.0, std::floor(std::min(ylo, 1e9)) - 2.0);
+            x1 = (int)std::min((double)FW - 1.0, std::ceil(std::max(xhi, -1e9)) + 2.0);
+            y1 = (int)std::min((double)FH - 1.0, std::ceil(std::max(yhi, -1e9)) + 2.0);
+            x0 &= ~15;                                              // 16-pixel (48-byte) alignment: whole 16-byte pieces
+            x1 = std::min(FW - 1, x1 | 15);
+        }
+        RoiDesc& r = roi[b];
+        if (x1 < x0 || y1 < y0) { r.x0 = 0; r.y0 = 0; r.w = 0; r.h = 0; r.off = off; continue; }   // the crop misses the frame
+        r.x0 = x0; r.y0 = y0; r.w = x1 - x0 + 1; r.h = y1 - y0 + 1; r.off = off;
+        off += ((uint64_t)r.w * r.h * 3 + 15) & ~15ull;
+    }
+    return ISB_OK;
+}
+
 extern "C" int isb_hpe_forward_host(isb_hpe* h, const uint8_t* frames, const int32_t* bbox, int32_t B, float* joints,
                                     uint8_t* valid) {
     return isb::guard([&]() -> int {
@@ -699,65 +789,11 @@ extern "C" int isb_hpe_forward_host(isb_hpe* h, const uint8_t* frames, const int
     float* dj = h->hs_joints.as<float>();
     uint8_t* dv = h->hs_valid.as<uint8_t>();
     ISB_HIP(hipMemcpyAsync(db, bbox, (size_t)B * 16, hipMemcpyHostToDevice, st));
-    const int FW = h->cfg.width, FH = h->cfg.height;
-    // the frames as the device sees them, if the caller's buffer is mapped pinned memory (hipHostMalloc / hipHostRegister;
-    // torch.Tensor.pin_memory()): only then can a kernel pull rectangles out of it
-    const uint8_t* frames_mapped = nullptr;
-    if (h->roi_mode > 0 && B >= kRoiMinBatch && FW % 16 == 0) {
-        hipPointerAttribute_t at{};
-        if (hipPointerGetAttributes(&at, frames) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer)
-            frames_mapped = static_cast<const uint8_t*>(at.devicePointer);
-        else
-            (void)hipGetLastError();             // pageable memory: not an error, whole frames are copied below
-    }
+    const uint8_t* frames_mapped = mapped_frames(h, frames, B);
     if (frames_mapped) {
-        // 1. the crop homographies of the whole batch (the kernel isb_hpe_forward runs again per lane: same inputs, same bits)
-        if (h->hs_H.bytes < (size_t)B * 36) {
-            ISB_TRY(h->hs_H.alloc((size_t)B * 36));
-            ISB_TRY(h->hs_newK.alloc((size_t)B * 72));
-            ISB_TRY(h->hs_R.alloc((size_t)B * 72));
-            ISB_TRY(h->hs_roi.alloc((size_t)B * sizeof(RoiDesc)));
-        }
-        CropParamArgs ca{};
-        ca.bbox = db;
-        for (int i = 0; i < 9; ++i) ca.K[i] = h->K[i];
-        ca.H = h->hs_H.as<float>(); ca.newK = h->hs_newK.as<double>(); ca.R = h->hs_R.as<double>(); ca.B = B;
-        ISB_TRY(launch_crop_params(ca, st));
-        std::vector<float> Hh((size_t)B * 9);
-        ISB_HIP(hipMemcpyAsync(Hh.data(), h->hs_H.p, (size_t)B * 36, hipMemcpyDeviceToHost, st));
-        ISB_HIP(hipStreamSynchronize(st));
-        // 2. per frame: the bounding rectangle of the crop square's image under H. The map is projective with a positive
-        // denominator over the square, so the square's image is the convex hull of its corners' images; + 2 px for the
-        // float32 evaluation and the truncation in the kernel. Degenerate H -> the whole frame.
-        std::vector<RoiDesc> roi(B);
+        std::vector<RoiDesc> roi;
         uint64_t off = 0;
-        for (int b = 0; b < B; ++b) {
-            const float* Hb = Hh.data() + (size_t)b * 9;
-            double xlo = 1e30, xhi = -1e30, ylo = 1e30, yhi = -1e30;
-            bool ok = std::isfinite(Hb[8]) && Hb[8] != 0.f;
-            for (int c = 0; c < 4 && ok; ++c) {
-                const double x = (c & 1) ? 255.0 : 0.0, y = (c & 2) ? 255.0 : 0.0, h8 = Hb[8];
-                const double k = Hb[6] / h8 * x + Hb[7] / h8 * y + 1.0;
-                if (!(k > 1e-6)) { ok = false; break; }
-                const double xs = (Hb[0] / h8 * x + Hb[1] / h8 * y + Hb[2] / h8) / k;
-                const double ys = (Hb[3] / h8 * x + Hb[4] / h8 * y + Hb[5] / h8) / k;
-                if (!std::isfinite(xs) || !std::isfinite(ys)) { ok = false; break; }
-                xlo = std::min(xlo, xs); xhi = std::max(xhi, xs); ylo = std::min(ylo, ys); yhi = std::max(yhi, ys);
-            }
-            int x0 = 0, x1 = FW - 1, y0 = 0, y1 = FH - 1;
-            if (ok) {
-                x0 = (int)std::max(0.0, std::floor(std::min(xlo, 1e9)) - 2.0);
-                y0 = (int)std::max(0.0, std::floor(std::min(ylo, 1e9)) - 2.0);
-                x1 = (int)std::min((double)FW - 1.0, std::ceil(std::max(xhi, -1e9)) + 2.0);
-                y1 = (int)std::min((double)FH - 1.0, std::ceil(std::max(yhi, -1e9)) + 2.0);
-                x0 &= ~15;                                              // 16-pixel (48-byte) alignment: whole 16-byte pieces
-                x1 = std::min(FW - 1, x1 | 15);
-            }
-            RoiDesc& r = roi[b];
-            if (x1 < x0 || y1 < y0) { r.x0 = 0; r.y0 = 0; r.w = 0; r.h = 0; r.off = off; continue; }   // the crop misses the frame
-            r.x0 = x0; r.y0 = y0; r.w = x1 - x0 + 1; r.h = y1 - y0 + 1; r.off = off;
-            off += ((uint64_t)r.w * r.h * 3 + 15) & ~15ull;
-        }
+        ISB_TRY(host_rois(h, db, B, st, roi, off));
         ISB_REQUIRE(off <= h->hs_frames.bytes, ISB_ERR_INVALID, "internal: packed ROI image larger than the frame staging buffer");
         // 3. one gather kernel per lane pulls the rectangles out of the mapped host frames (aligned 16-byte reads over PCIe),
         // launched by isb_hpe_forward in front of each lane's warp
@@ -792,6 +828,67 @@ extern "C" int isb_hpe_forward_host(isb_hpe* h, const uint8_t* frames, const int
     ISB_HIP(hipMemcpyAsync(valid, dv, (size_t)B, hipMemcpyDeviceToHost, st));
     ISB_HIP(hipStreamSynchronize(st));
     return ISB_OK;
+    });
+}
+
+static int complete_oldest(isb_hpe* h) {
+    isb_hpe::HostSlot& sl = h->slot[h->sub_tail];
+    ISB_HIP(hipEventSynchronize(sl.done));
+    const size_t jb = (size_t)sl.B * h->n_out * 12;
+    memcpy(sl.user_joints, sl.pin, jb);
+    memcpy(sl.user_valid, static_cast<const uint8_t*>(sl.pin) + jb, (size_t)sl.B);
+    sl.busy = false;
+    h->sub_tail ^= 1;
+    return ISB_OK;
+}
+
+extern "C" int isb_hpe_submit_host(isb_hpe* h, const uint8_t* frames, const int32_t* bbox, int32_t B, float* joints, uint8_t* valid) {
+    return isb::guard([&]() -> int {
+    ISB_REQUIRE(h && frames && bbox && joints && valid, ISB_ERR_INVALID, "null argument");
+    ISB_REQUIRE(B >= 1, ISB_ERR_INVALID, "batch %d < 1", B);
+    ISB_REQUIRE(h->n_aug == 0, ISB_ERR_STATE, "test-time augmentation is on: the reference defines it up to the augmented crops only (hpe.py:88-100)");
+    ISB_REQUIRE(h->weights && h->jointmap, ISB_ERR_STATE, "isb_hpe_submit_host needs weights and a joint map");
+    ISB_HIP(hipSetDevice(h->cfg.device));
+    isb_hpe::HostSlot& sl = h->slot[h->sub_head];
+    if (sl.busy) ISB_TRY(complete_oldest(h));    // two in flight already: the oldest (this slot) is finished first
+    const size_t fsz = (size_t)h->cfg.height * h->cfg.width * 3;
+    if (B > sl.cap) {
+        sl.cap = 0;
+        ISB_TRY(sl.frames.alloc(fsz * B));
+        ISB_TRY(sl.bbox.alloc((size_t)B * 16));
+        ISB_TRY(sl.joints.alloc((size_t)B * kMaxJoints * 12));
+        ISB_TRY(sl.valid.alloc((size_t)B));
+        if (sl.pin) (void)hipHostFree(sl.pin);
+        sl.pin = nullptr;
+        sl.pin_bytes = (size_t)B * (kMaxJoints * 12 + 1);
+        ISB_HIP(hipHostMalloc(&sl.pin, sl.pin_bytes, hipHostMallocDefault));
+        sl.cap = B;
+    }
+    hipStream_t st = h->own_stream, cs = h->copy_stream;
+    sl.boxes.assign(bbox, bbox + (size_t)B * 4);
+    // whole frames on the copy engine (no CU: a rectangle gather's waves would sit on their CUs for the length of the transfer and
+    // the previous batch's one-workgroup-per-CU kernels would find CUs taken -- measured, 21.3 against 19.2 ms per 256 frames)
+    ISB_HIP(hipMemcpyAsync(sl.bbox.p, sl.boxes.data(), (size_t)B * 16, hipMemcpyHostToDevice, cs));
+    ISB_HIP(hipMemcpyAsync(sl.frames.p, frames, fsz * B, hipMemcpyHostToDevice, cs));
+    ISB_HIP(hipEventRecord(sl.h2d, cs));
+    ISB_HIP(hipStreamWaitEvent(st, sl.h2d, 0));
+    ISB_TRY(isb_hpe_forward(h, sl.frames.as<uint8_t>(), sl.bbox.as<int32_t>(), B, sl.joints.as<float>(), sl.valid.as<uint8_t>(), st));
+    const size_t jb = (size_t)B * h->n_out * 12;
+    ISB_HIP(hipMemcpyAsync(sl.pin, sl.joints.p, jb, hipMemcpyDeviceToHost, st));
+    ISB_HIP(hipMemcpyAsync(static_cast<uint8_t*>(sl.pin) + jb, sl.valid.p, (size_t)B, hipMemcpyDeviceToHost, st));
+    ISB_HIP(hipEventRecord(sl.done, st));
+    sl.user_joints = joints; sl.user_valid = valid; sl.B = B; sl.busy = true;
+    h->sub_head ^= 1;
+    return ISB_OK;
+    });
+}
+
+extern "C" int isb_hpe_wait_host(isb_hpe* h) {
+    return isb::guard([&]() -> int {
+    ISB_REQUIRE(h, ISB_ERR_INVALID, "null argument");
+    ISB_REQUIRE(h->slot[h->sub_tail].busy, ISB_ERR_STATE, "isb_hpe_wait_host: no submission outstanding");
+    ISB_HIP(hipSetDevice(h->cfg.device));
+    return complete_oldest(h);
     });
 }
 
@@ -1234,9 +1331,10 @@ extern "C" int isb_debug_gemm_f32(int32_t device, const float* A, const float* W
     });
 }
 
-extern "C" int isb_debug_dwconv(int32_t device, const uint16_t* x, const float* w, const float* scale, const float* shift,
-                                int32_t B, int32_t H, int32_t C, int32_t stride, int32_t iters, uint16_t* out, float* pooled,
-                                float* ms_per_iter) {
+// se_w1 [cse, C] (optional): the squeeze-excite FC1 rides in the launch, se_part [dw_slabs][B][cse] receives the slabs' partial sums
+static int debug_dwconv_impl(int32_t device, const uint16_t* x, const float* w, const float* scale, const float* shift,
+                             int32_t B, int32_t H, int32_t C, int32_t stride, int32_t iters, uint16_t* out, float* pooled,
+                             float* ms_per_iter, const float* se_w1, int32_t cse, float* se_part, int32_t* n_parts) {
     return isb::guard([&]() -> int {
         ISB_REQUIRE(x && w && scale && shift && out && pooled && ms_per_iter, ISB_ERR_INVALID, "null argument");
         const int in_f16 = (stride & 0x100) ? 1 : 0, out_f16 = (stride & 0x200) ? 1 : 0;   // fp16 input + taps / fp16 output
@@ -1268,6 +1366,13 @@ extern "C" int isb_debug_dwconv(int32_t device, const uint16_t* x, const float* 
         d.pooled = dpool.as<float>(); d.B = B; d.H = H; d.W = H; d.C = C; d.OH = OH; d.OW = OH; d.stride = stride;
         d.pad = stride == 1 ? 1 : 0;
         d.in_f16 = in_f16; d.out_f16 = out_f16; d.general = general;
+        DevBuf dw1, dpart;
+        if (se_w1) {
+            ISB_REQUIRE(se_part && n_parts && cse >= 1 && cse <= 160, ISB_ERR_INVALID, "FC1 fold: se_part, n_parts and 1 <= cse <= 160");
+            ISB_TRY(upload(dw1, se_w1, (size_t)cse * C * 4));
+            ISB_TRY(dpart.alloc((size_t)dw_slabs(d) * B * cse * 4));
+            d.se_w1 = dw1.as<float>(); d.se_part = dpart.as<float>(); d.cse = cse;
+        }
         ISB_TRY(launch_dwconv3x3(d, nullptr));
         ISB_HIP(hipDeviceSynchronize());
         hipEvent_t e0, e1;
@@ -1284,8 +1389,25 @@ extern "C" int isb_debug_dwconv(int32_t device, const uint16_t* x, const float* 
         *ms_per_iter = ms / iters;
         ISB_HIP(hipMemcpy(out, dout.p, nout * 2, hipMemcpyDeviceToHost));
         ISB_HIP(hipMemcpy(pooled, dpool.p, (size_t)B * C * 4, hipMemcpyDeviceToHost));
+        if (se_w1) {
+            *n_parts = dw_slabs(d);
+            ISB_HIP(hipMemcpy(se_part, dpart.p, (size_t)dw_slabs(d) * B * cse * 4, hipMemcpyDeviceToHost));
+        }
         return ISB_OK;
     });
+}
+
+extern "C" int isb_debug_dwconv(int32_t device, const uint16_t* x, const float* w, const float* scale, const float* shift,
+                                int32_t B, int32_t H, int32_t C, int32_t stride, int32_t iters, uint16_t* out, float* pooled,
+                                float* ms_per_iter) {
+    return debug_dwconv_impl(device, x, w, scale, shift, B, H, C, stride, iters, out, pooled, ms_per_iter, nullptr, 0, nullptr, nullptr);
+}
+
+extern "C" int isb_debug_dwconv_fc1(int32_t device, const uint16_t* x, const float* w, const float* scale, const float* shift,
+                                    int32_t B, int32_t H, int32_t C, int32_t stride, int32_t iters, uint16_t* out, float* pooled,
+                                    float* ms_per_iter, const float* se_w1, int32_t cse, float* se_part, int32_t* n_parts) {
+    ISB_REQUIRE(se_w1, ISB_ERR_INVALID, "null argument");
+    return debug_dwconv_impl(device, x, w, scale, shift, B, H, C, stride, iters, out, pooled, ms_per_iter, se_w1, cse, se_part, n_parts);
 }
 
 // test / tuning hook: fused MBConv front half (1x1 expand + SiLU + depthwise 3x3 + SiLU + SE pool) on host tensors

@@ -92,6 +92,33 @@ class HpeEngine:
                                               valid.data_ptr(), C.c_void_p(stream)), "isb_hpe_forward")
         return joints, valid
 
+    def submit(self, frames: np.ndarray, bboxes: np.ndarray):
+        """forward() split in two (isb_hpe_submit_host / isb_hpe_wait_host): enqueue a host batch and return at once; `wait()`
+        hands back the OLDEST outstanding batch's (joints, valid). Up to two batches in flight: batch k + 1's frames cross PCIe
+        while batch k computes. `frames` should be pinned (torch.Tensor.pin_memory().numpy()) and stay untouched until its wait."""
+        if not (isinstance(frames, np.ndarray) and frames.dtype == np.uint8 and frames.flags["C_CONTIGUOUS"]):
+            raise TypeError("submit takes a contiguous uint8 numpy array")
+        bb = np.ascontiguousarray(bboxes, dtype=np.int32)
+        B = frames.shape[0]
+        if frames.shape != (B, self.height, self.width, 3) or bb.shape != (B, 4):
+            raise ValueError(f"bad shapes {frames.shape} {bb.shape}")
+        if not hasattr(self, "_inflight"):
+            self._inflight = []
+        if len(self._inflight) >= 2:
+            raise RuntimeError("two batches are in flight: wait() for the oldest first")
+        joints = np.empty((B, self.n_out, 3), np.float32)
+        valid = np.empty((B,), np.uint8)
+        _lib.check(_lib.lib().isb_hpe_submit_host(self._h, _ptr(frames), _ptr(bb), B, _ptr(joints), _ptr(valid)), "isb_hpe_submit_host")
+        self._inflight.append((frames, joints, valid))           # keeps the arrays alive until wait()
+
+    def wait(self):
+        """(joints f32 [B,n_out,3], valid u8 [B]) of the oldest submitted batch"""
+        if not getattr(self, "_inflight", None):
+            raise RuntimeError("wait() without a submitted batch")
+        _lib.check(_lib.lib().isb_hpe_wait_host(self._h), "isb_hpe_wait_host")
+        _, joints, valid = self._inflight.pop(0)
+        return joints, valid
+
     # -- stage-level hooks ----------------------------------------------------------------
     def set_augmentations(self, num_aug: int):
         """Test-time augmentation (MetrabsTRTConfig.num_aug, hpe.py:88-93): crop_params / warp then return num_aug
@@ -259,6 +286,26 @@ def dwconv_debug(x_bf16, w, scale, shift, stride=1, iters=1, device=0, in_f16=Fa
                                            stride | (0x100 if in_f16 else 0) | (0x200 if out_f16 else 0) | (0x400 if general else 0),
                                            iters, _ptr(out), _ptr(pooled), C.byref(ms)), "isb_debug_dwconv")
     return out, pooled, ms.value
+
+
+def dwconv_fc1_debug(x_bf16, w, scale, shift, se_w1, stride=1, device=0, in_f16=False, out_f16=False, general=False):
+    """dwconv_debug with the squeeze-excite FC1 folded into the launch (isb_debug_dwconv_fc1). se_w1 f32 [cse,C].
+    Returns (out, pooled, parts f32 [slabs,B,cse]): parts[s] = the slab's share of pooled @ se_w1.T."""
+    x = np.ascontiguousarray(x_bf16, dtype=np.uint16)
+    B, H, _, Cc = x.shape
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    se_w1 = f(se_w1)
+    cse = se_w1.shape[0]
+    out = np.empty((B, H // stride, H // stride, Cc), np.uint16)
+    pooled = np.empty((B, Cc), np.float32)
+    parts = np.zeros((32, B, cse), np.float32)
+    ms = C.c_float()
+    n = C.c_int32()
+    _lib.check(_lib.lib().isb_debug_dwconv_fc1(device, _ptr(x), _ptr(f(w)), _ptr(f(scale)), _ptr(f(shift)), B, H, Cc,
+                                               stride | (0x100 if in_f16 else 0) | (0x200 if out_f16 else 0) | (0x400 if general else 0),
+                                               1, _ptr(out), _ptr(pooled), C.byref(ms), _ptr(se_w1), cse, _ptr(parts), C.byref(n)),
+               "isb_debug_dwconv_fc1")
+    return out, pooled, parts[:n.value]
 
 
 def expand_dw_debug(x_bf16, w1, scale1, shift1, dww, dwscale, dwshift, iters=1, device=0):

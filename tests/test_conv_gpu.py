@@ -470,6 +470,30 @@ def test_dwconv_map8_is_bit_identical(HW, Cc, f16):
 
 
 @pytest.mark.parametrize("f16", [False, True])
+@pytest.mark.parametrize("HW,Cc,cse", [(8, 2304, 96), (8, 3840, 160), (16, 768, 48), (16, 1344, 56), (16, 200, 13)])
+def test_dwconv_map_fc1_fold(HW, Cc, cse, f16):
+    """Squeeze-excite FC1 folded into the depthwise launch (DwArgs.se_w1; the single-frame path runs this way): each channel
+    slab's workgroup leaves its share of pooled @ W1^T. The LDS-map kernel's partials are the general kernel's bits, and the
+    slabs add up to the f32 product of the pooled means."""
+    from isbfsar_amd.hpe_engine import dwconv_fc1_debug, f32_to_f16
+    rng = np.random.default_rng(Cc + cse + int(f16))
+    B = 3
+    x = rng.normal(0, 1, (B, HW, HW, Cc)).astype(np.float32)
+    w = (rng.normal(0, 1, (Cc, 3, 3)) / 3.0).astype(np.float32)
+    scale = rng.uniform(0.8, 1.2, Cc).astype(np.float32)
+    shift = rng.uniform(-0.1, 0.1, Cc).astype(np.float32)
+    w1 = (rng.normal(0, 1, (cse, Cc)) / np.sqrt(Cc)).astype(np.float32)
+    xin = f32_to_f16(x) if f16 else f32_to_bf16(x)
+    a, pa, parts_a = dwconv_fc1_debug(xin, w, scale, shift, w1, in_f16=f16, out_f16=f16)
+    g, pg, parts_g = dwconv_fc1_debug(xin, w, scale, shift, w1, in_f16=f16, out_f16=f16, general=True)
+    assert np.array_equal(a, g) and np.array_equal(pa, pg)
+    assert parts_a.shape == parts_g.shape == (-(-Cc // (128 if HW == 8 else 64)), B, cse)
+    assert np.array_equal(parts_a, parts_g)
+    want = pa.astype(np.float64) @ w1.astype(np.float64).T
+    np.testing.assert_allclose(parts_a.astype(np.float64).sum(axis=0), want, rtol=0, atol=2e-5 * max(1.0, float(np.abs(want).max())))
+
+
+@pytest.mark.parametrize("f16", [False, True])
 @pytest.mark.parametrize("shape", [(9, 2304, 384, 155), (5, 3840, 640, 156), (3, 1344, 384, 155), (2, 2304, 640, 156), (1, 768, 192, 155)])
 def test_gated_projection_with_loader_waves_is_bit_identical(shape, f16):
     """gemm1x1_lw_kernel (variants 155 / 156: 128-row tiles, 8 consumer + 4 loader waves, one barrier per k-step) against the

@@ -701,3 +701,51 @@ def test_roi_only_host_input_is_bit_identical(bbone_state, assets, monkeypatch):
     for k in ("0", "pageable", "dev"):
         assert np.array_equal(outs["1"][0], outs[k][0]) and np.array_equal(outs["1"][1], outs[k][1]), k
     assert outs["1"][1].sum() >= n - 4
+
+
+def test_submitted_host_batches_are_bit_identical(bbone_state, assets):
+    """isb_hpe_submit_host / isb_hpe_wait_host: two host batches in flight (batch k + 1's frames cross PCIe on the copy engine
+    while batch k computes, the lanes run on without a drain) give the bits of the synchronous isb_hpe_forward_host, in
+    submission order; a third submit finishes the oldest first; pageable frames work (the submit then blocks for the copy);
+    the synchronous entry may be mixed in; wait without a submission is an ISB_ERR_STATE. Micro-batches: max_batch 8 < 12."""
+    import torch
+    from isbfsar_amd import _lib
+    from isbfsar_amd.hpe_engine import HpeEngine
+    n = 12
+    frs = [synth.frames(n, seed=600 + i) for i in range(4)]
+    bbs = [synth.bboxes(n, seed=600 + i) for i in range(4)]
+    pinned = [torch.from_numpy(f).pin_memory().numpy() for f in frs]
+    e = HpeEngine(device=0, max_batch=8)
+    try:
+        e.set_joint_map(assets[0], assets[1]["smpl+head_30"]["indices"])
+        e.load_weights(bbone_state)
+        want = [e.forward(pinned[i], bbs[i]) for i in range(4)]
+        got = []
+        e.submit(pinned[0], bbs[0])
+        for i in range(1, 4):                                # submit batch i, then collect batch i - 1
+            e.submit(pinned[i], bbs[i])
+            got.append(e.wait())
+        mixed = e.forward(pinned[1], bbs[1])                 # the synchronous entry with batch 3 still outstanding
+        got.append(e.wait())
+        for (j, v), (jw, vw) in zip(got, want):
+            assert np.array_equal(j, jw) and np.array_equal(v, vw)
+        assert np.array_equal(mixed[0], want[1][0]) and np.array_equal(mixed[1], want[1][1])
+        with pytest.raises(RuntimeError):
+            e.wait()
+        with pytest.raises(_lib.IsbError, match="no submission"):
+            _lib.check(_lib.lib().isb_hpe_wait_host(e._h), "isb_hpe_wait_host")
+        # straight through the C entry: a third submit completes the oldest (its arrays are written at that moment)
+        outs = [(np.zeros((n, e.n_out, 3), np.float32), np.zeros((n,), np.uint8)) for _ in range(3)]
+        for i in range(3):
+            _lib.check(_lib.lib().isb_hpe_submit_host(e._h, pinned[i].ctypes.data, bbs[i].ctypes.data, n, outs[i][0].ctypes.data,
+                                                      outs[i][1].ctypes.data), "isb_hpe_submit_host")
+        assert np.array_equal(outs[0][0], want[0][0]) and np.array_equal(outs[0][1], want[0][1])
+        for i in (1, 2):
+            _lib.check(_lib.lib().isb_hpe_wait_host(e._h), "isb_hpe_wait_host")
+            assert np.array_equal(outs[i][0], want[i][0]) and np.array_equal(outs[i][1], want[i][1])
+        e.submit(frs[3], bbs[3])                             # pageable frames
+        j, v = e.wait()
+        assert np.array_equal(j, want[3][0]) and np.array_equal(v, want[3][1])
+        assert want[0][1].sum() > 0
+    finally:
+        e.close()

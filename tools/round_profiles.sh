@@ -13,10 +13,11 @@ echo "== extra lines: AR in bf16x3 (the reference arithmetic is fp32), pose stag
 timeout -k 10 300 python bench.py --workload ar --precision bf16x3 --no-cpu-baseline --min-gpu-seconds 0 2>/dev/null | tail -1 > gpurun_out/bench_ar_bf16x3.json
 timeout -k 10 300 python bench.py --workload hpe --host-input --no-cpu-baseline --min-gpu-seconds 0 2>/dev/null | tail -1 > gpurun_out/bench_hpe_host.json
 ISB_HPE_ROI=0 timeout -k 10 300 python bench.py --workload hpe --host-input --no-cpu-baseline --min-gpu-seconds 0 2>/dev/null | tail -1 > gpurun_out/bench_hpe_host_wholeframes.json
+timeout -k 10 300 python bench.py --workload hpe --host-input --pipelined --no-cpu-baseline --min-gpu-seconds 0 2>/dev/null | tail -1 > gpurun_out/bench_hpe_host_pipelined.json
 ISB_HPE_F16=0 timeout -k 10 300 python bench.py --workload hpe --min-gpu-seconds 0 2>/dev/null | tail -1 > gpurun_out/bench_hpe_bf16_everywhere.json
 timeout -k 10 400 python bench.py --workload pipeline --batch 2048 --steps 3 --warmup 1 --no-cpu-baseline --no-extras --min-gpu-seconds 0 2>/dev/null | tail -1 > gpurun_out/bench_pipe_b2048.json
 timeout -k 10 300 python tools/estimate_latency.py > gpurun_out/estimate_latency.json 2>gpurun_out/estimate_latency.err || true
-for f in ar_bf16x3 hpe_host hpe_host_wholeframes hpe_bf16_everywhere pipe_b2048; do python3 -c "import json;d=json.load(open('gpurun_out/bench_$f.json'));print('$f',d['value'],d['unit'],d['ms_per_step'],'ms')"; done
+for f in ar_bf16x3 hpe_host hpe_host_wholeframes hpe_host_pipelined hpe_bf16_everywhere pipe_b2048; do python3 -c "import json;d=json.load(open('gpurun_out/bench_$f.json'));print('$f',d['value'],d['unit'],d['ms_per_step'],'ms')"; done
 echo "== kernel stats (pipeline)"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_pipe -o run -- python3 bench.py --workload pipeline --steps 5 --warmup 2 --no-cpu-baseline --no-extras --min-gpu-seconds 0 > gpurun_out/prof_pipe.log 2>&1
 echo "== kernel stats (hpe, one lane: every convolution launch is a 256-frame launch, as in bench.py's roofline pass)"
