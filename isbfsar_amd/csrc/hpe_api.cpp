@@ -95,6 +95,11 @@ struct isb_hpe {
     Lane lanes[kMaxLanes];
     int n_lanes = 2;              // ISB_HPE_LANES=1 disables the split, up to kMaxLanes
     hipEvent_t fork_ev = nullptr, join_ev[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
+    // the lanes' workspaces belong to one pass at a time: a pass enqueued on ANOTHER stream than the previous one (device-pointer
+    // entry on the caller's stream after host batches on the handle's own stream, or the other way round) waits for it on the device
+    hipEvent_t last_ev = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool last_valid = false;
     // host-buffer entry point: persistent staging (grow-only) + a copy stream so that the H2D of chunk i + 1 travels
     // while chunk i computes
     hipStream_t copy_stream = nullptr;
@@ -453,6 +458,7 @@ extern "C" int isb_hpe_create(const isb_hpe_cfg* cfg, isb_hpe** out) {
     if (const char* e = getenv("ISB_HPE_ROI")) h->roi_mode = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("ISB_HPE_LANES")) h->n_lanes = std::max(1, std::min(kMaxLanes, atoi(e)));
     ISB_HIP(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
+    ISB_HIP(hipEventCreateWithFlags(&h->last_ev, hipEventDisableTiming));
     ISB_HIP(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
     for (auto& e : h->h2d_ev) ISB_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& sl : h->slot) {
@@ -482,6 +488,7 @@ extern "C" void isb_hpe_destroy(isb_hpe* h) {
         if (h->join_ev[l]) (void)hipEventDestroy(h->join_ev[l]);
     }
     if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
+    if (h->last_ev) (void)hipEventDestroy(h->last_ev);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     for (auto& sl : h->slot) {
         if (sl.h2d) (void)hipEventDestroy(sl.h2d);
@@ -671,6 +678,11 @@ extern "C" int isb_hpe_forward(isb_hpe* h, const uint8_t* d_frames, const int32_
         return run_post(h, L, s, L.logits.as<float>(), Bm, d_joints + (size_t)b0 * h->n_out * 3, d_valid + b0, nullptr,
                         d_bbox + (size_t)b0 * 4);
     };
+    // (not while the stream is being captured into a graph: a replayed step is ordered by its own launches)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    const bool track = cap == hipStreamCaptureStatusNone;
+    if (track && h->last_valid && h->last_stream != st) ISB_HIP(hipStreamWaitEvent(st, h->last_ev, 0));
     for (int b0 = 0; b0 < B; b0 += Bm_max) {
         const int Bm = std::min(Bm_max, B - b0);
         // every sample is independent, so the split changes no result. Small batches (latency regime) and the
@@ -696,6 +708,11 @@ extern "C" int isb_hpe_forward(isb_hpe* h, const uint8_t* d_frames, const int32_
         } else {
             for (int ph = 0; ph < n_phases; ++ph) ISB_TRY(run_phase(h->lanes[0], st, b0, Bm, ph, 0));
         }
+    }
+    if (track) {
+        ISB_HIP(hipEventRecord(h->last_ev, st));
+        h->last_stream = st;
+        h->last_valid = true;
     }
     return ISB_OK;
     });
