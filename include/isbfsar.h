@@ -185,7 +185,8 @@ int isb_hpe_forward_host(isb_hpe* h, const uint8_t* h_frames, const int32_t* h_b
  *   isb_hpe_wait_host    blocks until the OLDEST outstanding submission is finished and writes its h_joints / h_valid.
  * Up to two submissions may be in flight (a third submit first finishes the oldest, writing its results then). Submissions run
  * in order on the handle's stream: batch k + 1's transfer hides behind batch k's kernels, and the lanes go from batch to batch
- * without draining. Results are the bits isb_hpe_forward_host gives. ISB_ERR_STATE from wait when nothing is outstanding. */
+ * without draining. Results are the bits isb_hpe_forward_host gives. ISB_ERR_STATE from wait when nothing is outstanding, and
+ * from load_weights / set_joint_map / set_augmentations while a submission is. */
 int isb_hpe_submit_host(isb_hpe* h, const uint8_t* h_frames, const int32_t* h_bbox, int32_t B, float* h_joints, uint8_t* h_valid);
 int isb_hpe_wait_host(isb_hpe* h);
 

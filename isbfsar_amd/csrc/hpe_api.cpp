@@ -125,7 +125,7 @@ struct isb_hpe {
         hipEvent_t h2d = nullptr, done = nullptr;
         float* user_joints = nullptr;
         uint8_t* user_valid = nullptr;
-        int B = 0, cap = 0;
+        int B = 0, cap = 0, n_out = 0;  // n_out: joints per pose when the batch was submitted
         bool busy = false;
     };
     HostSlot slot[2];
@@ -503,6 +503,7 @@ extern "C" void isb_hpe_destroy(isb_hpe* h) {
 extern "C" int isb_hpe_load_weights(isb_hpe* h, const void* blob, size_t nbytes) {
     return isb::guard([&]() -> int {
     ISB_REQUIRE(h, ISB_ERR_INVALID, "null handle");
+    ISB_REQUIRE(!h->slot[0].busy && !h->slot[1].busy, ISB_ERR_STATE, "submitted host batches are outstanding: isb_hpe_wait_host first");
     ISB_HIP(hipSetDevice(h->cfg.device));
     hipStream_t st = h->own_stream;
     std::map<std::string, BlobTensor> m;
@@ -612,6 +613,7 @@ extern "C" int isb_hpe_set_joint_map(isb_hpe* h, const float* expand, const int3
     ISB_REQUIRE(h && expand, ISB_ERR_INVALID, "null argument");
     ISB_REQUIRE(n_out >= 1 && n_out <= 122, ISB_ERR_INVALID, "n_out %d outside [1,122]", n_out);
     ISB_REQUIRE(indices || n_out == 122, ISB_ERR_INVALID, "without indices n_out must be 122");
+    ISB_REQUIRE(!h->slot[0].busy && !h->slot[1].busy, ISB_ERR_STATE, "submitted host batches are outstanding: isb_hpe_wait_host first");
     if (indices)
         for (int i = 0; i < n_out; ++i)
             ISB_REQUIRE(indices[i] >= 0 && indices[i] < 122, ISB_ERR_INVALID, "joint index %d outside [0,122)", indices[i]);
@@ -629,6 +631,7 @@ extern "C" int isb_hpe_set_augmentations(isb_hpe* h, int32_t n_aug, const double
     return isb::guard([&]() -> int {
     ISB_REQUIRE(h, ISB_ERR_INVALID, "null handle");
     ISB_REQUIRE(n_aug >= 0 && n_aug <= 64, ISB_ERR_INVALID, "n_aug %d outside [0,64]", n_aug);
+    ISB_REQUIRE(!h->slot[0].busy && !h->slot[1].busy, ISB_ERR_STATE, "submitted host batches are outstanding: isb_hpe_wait_host first");
     ISB_REQUIRE(n_aug == 0 || (rotflip && scales), ISB_ERR_INVALID, "augmentation tables missing");
     ISB_HIP(hipSetDevice(h->cfg.device));
     if (n_aug > 0) {
@@ -851,7 +854,7 @@ extern "C" int isb_hpe_forward_host(isb_hpe* h, const uint8_t* frames, const int
 static int complete_oldest(isb_hpe* h) {
     isb_hpe::HostSlot& sl = h->slot[h->sub_tail];
     ISB_HIP(hipEventSynchronize(sl.done));
-    const size_t jb = (size_t)sl.B * h->n_out * 12;
+    const size_t jb = (size_t)sl.B * sl.n_out * 12;
     memcpy(sl.user_joints, sl.pin, jb);
     memcpy(sl.user_valid, static_cast<const uint8_t*>(sl.pin) + jb, (size_t)sl.B);
     sl.busy = false;
@@ -894,7 +897,7 @@ extern "C" int isb_hpe_submit_host(isb_hpe* h, const uint8_t* frames, const int3
     ISB_HIP(hipMemcpyAsync(sl.pin, sl.joints.p, jb, hipMemcpyDeviceToHost, st));
     ISB_HIP(hipMemcpyAsync(static_cast<uint8_t*>(sl.pin) + jb, sl.valid.p, (size_t)B, hipMemcpyDeviceToHost, st));
     ISB_HIP(hipEventRecord(sl.done, st));
-    sl.user_joints = joints; sl.user_valid = valid; sl.B = B; sl.busy = true;
+    sl.user_joints = joints; sl.user_valid = valid; sl.B = B; sl.n_out = h->n_out; sl.busy = true;
     h->sub_head ^= 1;
     return ISB_OK;
     });

@@ -743,6 +743,10 @@ def test_submitted_host_batches_are_bit_identical(bbone_state, assets):
         for i in (1, 2):
             _lib.check(_lib.lib().isb_hpe_wait_host(e._h), "isb_hpe_wait_host")
             assert np.array_equal(outs[i][0], want[i][0]) and np.array_equal(outs[i][1], want[i][1])
+        e.submit(pinned[0], bbs[0])                          # the handle's configuration is frozen while a batch is outstanding
+        with pytest.raises(_lib.IsbError, match="outstanding"):
+            e.set_joint_map(assets[0], None)
+        e.wait()
         e.submit(frs[3], bbs[3])                             # pageable frames
         j, v = e.wait()
         assert np.array_equal(j, want[3][0]) and np.array_equal(v, want[3][1])
