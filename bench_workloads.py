@@ -478,9 +478,11 @@ class DetWorkload:
         from isbfsar_amd import yolov4
         from isbfsar_amd.det_engine import DetEngine
         self.torch = torch
-        self.B = args.batch or 64
+        self.B = args.batch or 256                           # the frames of BASELINE configs[1] / [3]'s per-GPU shard
         self.state = yolov4.make_state(0)
-        self.det = DetEngine(device=dev, max_batch=min(self.B, 64))
+        # one micro-batch (isb_det caps it at 256 frames): 110 launches whatever the batch, and at 64 frames most of them are too
+        # small to fill the chip (14.0 k frames/s in 64-frame micro-batches, 18.4 k in 128, 20.1 k in 256)
+        self.det = DetEngine(device=dev, max_batch=min(self.B, int(os.environ.get("ISB_DET_MICROBATCH", "256"))))
         self.det.load_weights(self.state)
         self.frames_host = synth.frames(self.B, seed=20_000 * (rank + 1))
         self.frames = torch.from_numpy(self.frames_host).cuda(dev)

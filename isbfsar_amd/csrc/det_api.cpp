@@ -17,7 +17,7 @@ namespace {
 constexpr int kActLinear = 0, kActMish = 2, kActLeaky = 3;
 constexpr int kNBoxes = 4032, kNCls = 80, kNo = 255, kNoPad = 256;
 constexpr int kAnchors[18] = {12, 16, 19, 36, 40, 28, 36, 75, 76, 55, 72, 146, 142, 110, 192, 243, 459, 401};
-constexpr int kMaxBatch = 128;     // activations of one frame reach 4 MiB (256 x 256 x 32 bf16): 128 frames keep every tensor < 2 GiB
+constexpr int kMaxBatch = 256;     // activations of one frame reach 4 MiB (256 x 256 x 32 bf16): 256 frames = 1 GiB, every tensor < 2 GiB
 
 struct DetConv {
     std::string name;

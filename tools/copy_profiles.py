@@ -18,11 +18,11 @@ import os
 for src, dst in (("bench_ar_bf16x3.json", "bench_ar_bf16x3.json"), ("bench_hpe_host.json", "bench_hpe_host_input.json"),
                  ("bench_pipe_b2048.json", "bench_pipe_b2048.json"), ("mfma_hpe.json", "mfma_counters_hpe_b256_onelane.json"),
                  ("mfma_ar.json", "mfma_counters_ar_b1024.json"), ("layer_breakdown.txt", "hpe_b256_layer_breakdown.txt"),
-                 ("dw_breakdown.txt", "hpe_b256_depthwise_breakdown.txt"), ("det_breakdown.txt", "det_b64_layer_breakdown.txt"),
+                 ("dw_breakdown.txt", "hpe_b256_depthwise_breakdown.txt"), ("det_breakdown.txt", "det_b256_layer_breakdown.txt"),
                  ("bench_hpe_host_wholeframes.json", "bench_hpe_host_input_wholeframes.json"),
                  ("bench_hpe_host_pipelined.json", "bench_hpe_host_input_pipelined.json"),
                  ("bench_hpe_bf16_everywhere.json", "bench_hpe_bf16_everywhere.json"), ("estimate_latency.json", "estimate_latency.json"),
-                 ("prof_det/run_kernel_stats.csv", "det_b64_kernel_stats.csv")):
+                 ("prof_det/run_kernel_stats.csv", "det_b256_kernel_stats.csv")):
     if os.path.exists(f"{G}/{src}"):
         shutil.copy(f"{G}/{src}", f"{P}/{tag}_{dst}")
 for src, dst in (("pmc_fetch", "hpe_b256_fetch_size"), ("pmc_write", "hpe_b256_write_size")):

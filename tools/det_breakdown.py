@@ -31,7 +31,7 @@ def in_hw(name):          # input resolution of a layer at 256 x 256 (module ord
 
 
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if any(k in r["Kernel_Name"] for k in ("conv_igemm", "gemm1x1", "conv3x3_dma", "det_stem"))]
-B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 last = rows[-len(L):]
 agg = collections.OrderedDict()
 tot = 0.0
