@@ -1972,7 +1972,15 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
             else if (a.Cout % 192 == 0 && a.stride == 1 && a.Cin == 96 && a.W == 32 && a.H % 4 == 0 && conv3_halo())
                 v = 167;                              // 128 x 192, halo-tile A operand
             else if (a.Cout % 192 == 0) v = 161;      // 128 x 192
-            else v = 162;                             // 128 x 128
+            else {
+                // the detector's / the ResNet trunk's plain 3x3 layers (same k order in every tile shape: bit-identical). At 256 frames:
+                // 64 outputs on 256 x 64 tiles instead of half-empty 128 x 128 ones (32 -> 64 @128: 417 vs 584 us, 64 -> 64 @64: 157 vs
+                // 227); widening layers from 512 outputs on 256 x 128 (256 -> 512 @16: 193 vs 227, 512 -> 1024 @8: 174 vs 218)
+                static const bool sel = [] { const char* e = getenv("ISB_C3_SEL"); return !e || atoi(e) != 0; }();   // A/B switch
+                if (sel && a.Cout == 64 && a.M >= 32768) v = 165;                            // 256 x  64
+                else if (sel && a.Cout >= 512 && a.Cout % 128 == 0 && a.Cout > a.Cin && a.M >= 16384) v = 164;   // 256 x 128
+                else v = 162;                         // 128 x 128
+            }
         } else if (!a.gate && a.zeros) {
             if (a.Cout == 32) v = 59;                 // 256 x  32, 8 waves
             else if (a.Cout % 192 == 0) v = 54;       // 128 x 192, 8 waves of 32 x 96
