@@ -267,6 +267,8 @@ int isb_hpe_profile_read(isb_hpe* h, double* ms_total, int64_t* launches);
  *   the split-K GEMM + reduction pair; variant = 900000 + v (v = 131-148, 181) runs the kernel with in-kernel s_memtime
  *   stamps and prints the phase clocks of its first workgroups to stderr (tuning probe);
  *   out bf16 [B,OH,OW,Cout]; ms_per_iter = HIP-event time of one launch. 
+ *   stride | 0x100 (with stride 2, k 3): PyTorch's symmetric padding 1 instead of TF-SAME (bottom / right) -- the detector's and
+ *   the ResNet trunk's down-sampling layers;
  *   act | 0x100: fp16 operands (ConvArgs.f16): h_x / h_res / h_out hold fp16 bits and the weights are rounded to fp16;
  *   implemented by the variants the 8x8 stages select (131, 132, 138, 141, 144, 146, 147, 185, 186; 0 = automatic). */
 int isb_debug_conv(int32_t device, const uint16_t* h_x, const float* h_w, const float* h_scale, const float* h_shift,

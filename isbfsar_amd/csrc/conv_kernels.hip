@@ -1925,7 +1925,10 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
         //   * a single frame (M <= 2048) needs many small workgroups: 64-row tiles.
         const bool g1 = a.KH == 1 && a.stride == 1 && a.pad == 0 && a.zeros;
         const int ohw = a.OH * a.OW;
-        const bool c3 = !a.gate && a.KH == 3 && a.KW == 3 && ((a.stride == 1 && a.pad == 1) || (a.stride == 2 && a.pad == 0)) &&
+        // (stride 2: TF-SAME on an even input = pad 0, bottom / right overhang; or PyTorch's symmetric pad 1 -- the lean 3x3 kernel
+        // addresses its taps from a shifted buffer base and a per-lane validity mask, whatever the padding)
+        static const bool c3_s2p1 = [] { const char* e = getenv("ISB_C3_S2P1"); return !e || atoi(e) != 0; }();   // A/B switch
+        const bool c3 = !a.gate && a.KH == 3 && a.KW == 3 && ((a.stride == 1 && a.pad == 1) || (a.stride == 2 && (a.pad == 0 || (a.pad == 1 && c3_s2p1)))) &&
                         (size_t)a.B * a.H * a.W * a.Cin * 2 + (size_t)(a.W + 1) * a.Cin * 2 < 0x7ffffff0ull;
         if (a.M <= 2048 && a.Cout >= 64) {
             if (g1 && !a.gate) v = 138;
@@ -1964,8 +1967,7 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
             else if (a.Cout == 224) v = 143;           // 128 x 224
             else if (a.Cout % 192 == 0) v = 141;       // 128 x 192
             else v = 142;                              // 128 x 128
-        } else if (!a.gate && a.KH == 3 && a.KW == 3 && ((a.stride == 1 && a.pad == 1) || (a.stride == 2 && a.pad == 0)) &&
-                   (size_t)a.B * a.H * a.W * a.Cin * 2 + (size_t)(a.W + 1) * a.Cin * 2 < 0x7ffffff0ull) {
+        } else if (c3) {
             if (a.Cout == 32 && a.Cin == 32 && a.stride == 1 && a.W == 128 && a.H % 2 == 0 && !a.out_f32 && a.act <= 1)
                 v = 171;                              // rows ring in LDS, +50 % over the implicit GEMM (bit-identical)
             else if (a.Cout == 32) v = 163;           // 256 x  32   (lean 3x3, buffer-addressed A operand)
@@ -2205,7 +2207,7 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
 #undef ISB_CONV_LAUNCH_G1
 #define ISB_CONV_LAUNCH_C3(TM, TN, WGM, WGN)                                                                     \
     do {                                                                                                         \
-        const bool same1 = a.stride == 1 && a.pad == 1, same2 = a.stride == 2 && a.pad == 0;                     \
+        const bool same1 = a.stride == 1 && a.pad == 1, same2 = a.stride == 2 && (a.pad == 0 || a.pad == 1);    \
         if (a.gate || a.KH != 3 || a.KW != 3 || !(same1 || same2) ||                                             \
             (size_t)a.B * a.H * a.W * a.Cin * 2 + (size_t)(a.W + 1) * a.Cin * 2 >= 0x7ffffff0ull) {             \
             set_error("conv_igemm: variants 161-169 are un-gated 3x3 convolutions on tensors below 2 GiB");      \

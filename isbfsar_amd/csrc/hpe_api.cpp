@@ -1055,6 +1055,8 @@ extern "C" int isb_debug_conv(int32_t device, const uint16_t* x, const float* w,
                               uint16_t* out, float* ms_per_iter) {
     return isb::guard([&]() -> int {
     ISB_REQUIRE(x && w && scale && shift && out && ms_per_iter, ISB_ERR_INVALID, "null argument");
+    const int sym2 = (stride & 0x100) ? 1 : 0;  // stride 2 with PyTorch's symmetric pad 1 (the detector / ResNet trunk) instead of TF-SAME
+    stride &= 0xff;
     ISB_REQUIRE((k == 1 || k == 3) && (stride == 1 || stride == 2) && iters >= 1, ISB_ERR_INVALID, "bad conv parameters");
     ISB_HIP(hipSetDevice(device));
     const int f16 = (act & 0x100) ? 1 : 0;      // x / res / out hold fp16 bits and the weights are rounded to fp16
@@ -1078,7 +1080,7 @@ extern "C" int isb_debug_conv(int32_t device, const uint16_t* x, const float* w,
     a.in = dx.as<uint16_t>(); a.w = dw16.as<uint16_t>(); a.bias = dsh.as<float>();
     a.res = res ? dres.as<uint16_t>() : nullptr; a.gate = gate ? dgate.as<float>() : nullptr; a.out = dout.p;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = k; a.KW = k; a.stride = stride; a.OH = OH; a.OW = OW;
-    a.pad = (k == 3 && stride == 1) ? 1 : 0; a.M = B * OH * OW; a.K = k * k * Cin; a.act = act; a.out_f32 = 0; a.zeros = dzero.as<uint16_t>();
+    a.pad = (k == 3 && (stride == 1 || sym2)) ? 1 : 0; a.M = B * OH * OW; a.K = k * k * Cin; a.act = act; a.out_f32 = 0; a.zeros = dzero.as<uint16_t>();
     a.variant = variant % 1000;
     DevBuf dpart;
     if (variant >= 900000) {                    // kernels with in-kernel time stamps (tuning probes): 900181, 900131, 900143, ...

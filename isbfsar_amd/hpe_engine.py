@@ -216,10 +216,12 @@ def bf16_to_f32(a: np.ndarray) -> np.ndarray:
     return (np.ascontiguousarray(a, dtype=np.uint16).astype(np.uint32) << 16).view(np.float32)
 
 
-def conv_debug(x_bf16, w, scale, shift, k, stride, act, res_bf16=None, gate=None, variant=0, iters=1, device=0, f16=False):
+def conv_debug(x_bf16, w, scale, shift, k, stride, act, res_bf16=None, gate=None, variant=0, iters=1, device=0, f16=False,
+               torch_pad=False):
     """One backbone convolution through isb_debug_conv. x_bf16 uint16 [B,H,W,Cin] (bf16 bits),
     w f32 [Cout,k,k,Cin]. Returns (out uint16 [B,OH,OW,Cout], ms_per_launch). f16: x / res / out hold fp16 bits and the
-    weights are rounded to fp16 (ConvArgs.f16, the 8x8 stages)."""
+    weights are rounded to fp16 (ConvArgs.f16, the 8x8 stages). torch_pad: a stride-2 3x3 pads symmetrically (PyTorch, the
+    detector / ResNet trunk) instead of TF-SAME."""
     x = np.ascontiguousarray(x_bf16, dtype=np.uint16)
     B, H, W, Cin = x.shape
     w = np.ascontiguousarray(w, dtype=np.float32)
@@ -232,7 +234,8 @@ def conv_debug(x_bf16, w, scale, shift, k, stride, act, res_bf16=None, gate=None
     g = None if gate is None else np.ascontiguousarray(gate, dtype=np.float32)
     _lib.check(_lib.lib().isb_debug_conv(device, _ptr(x), _ptr(w), _ptr(np.ascontiguousarray(scale, dtype=np.float32)),
                                          _ptr(np.ascontiguousarray(shift, dtype=np.float32)), _ptr(r), _ptr(g),
-                                         B, H, W, Cin, Cout, k, stride, int(act), variant, iters, _ptr(out), C.byref(ms)),
+                                         B, H, W, Cin, Cout, k, stride | (0x100 if torch_pad else 0), int(act), variant, iters,
+                                         _ptr(out), C.byref(ms)),
                "isb_debug_conv")
     return out, ms.value
 

@@ -120,6 +120,31 @@ def test_conv_halo_c32(B, H, act, use_res):
     assert np.all(np.abs(got - ref) <= tol), float(np.abs(got - ref).max())
 
 
+@pytest.mark.parametrize("B,H,Cin,Cout", [(2, 32, 32, 64), (3, 16, 64, 128), (2, 16, 128, 256), (5, 14, 128, 128), (1, 8, 512, 1024)])
+def test_conv3x3_stride2_symmetric_padding(B, H, Cin, Cout):
+    """The detector's / ResNet trunk's down-sampling layers (PyTorch: stride 2, pad 1 on every side) on the lean 3x3 kernel -- its
+    taps come from a shifted buffer base and a per-lane validity mask, so the padding rule is only the window origin: against
+    torch-CPU on the same rounded operands, and the same bits as the general implicit-GEMM kernel (variant 55)."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(B + H + Cin + Cout)
+    x = rng.normal(0, 1, (B, H, H, Cin)).astype(np.float32)
+    w = (rng.normal(0, 1, (Cout, 3, 3, Cin)) / np.sqrt(9 * Cin)).astype(np.float32)
+    scale = rng.uniform(0.8, 1.2, Cout).astype(np.float32)
+    shift = rng.uniform(-0.1, 0.1, Cout).astype(np.float32)
+    out, _ = conv_debug(f32_to_bf16(x), w, scale, shift, 3, 2, 1, torch_pad=True)
+    gen, _ = conv_debug(f32_to_bf16(x), w, scale, shift, 3, 2, 1, variant=55, torch_pad=True)
+    xb = torch.from_numpy(bf16_to_f32(f32_to_bf16(x))).permute(0, 3, 1, 2)
+    wf = (torch.from_numpy(w) * torch.from_numpy(scale).view(-1, 1, 1, 1)).bfloat16().float().permute(0, 3, 1, 2)
+    y = F.conv2d(xb, wf, stride=2, padding=1) + torch.from_numpy(shift).view(1, -1, 1, 1)
+    ref = (y * torch.sigmoid(y)).permute(0, 2, 3, 1).bfloat16().float().numpy()
+    got = bf16_to_f32(out)
+    assert got.shape == ref.shape
+    tol = 2.0 ** -7 * np.maximum(1.0, np.abs(ref))
+    assert np.all(np.abs(got - ref) <= tol), float(np.abs(got - ref).max())
+    assert np.array_equal(out, gen)
+
+
 @pytest.mark.parametrize("B,Cout,act", [(2, 384, 1), (3, 192, 0)])
 def test_conv3x3_halo_c96(B, Cout, act):
     """3x3 96 -> Cout on 32 x 32 maps with the A operand read from an LDS halo tile (variant 167): bit for bit the
