@@ -110,18 +110,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
                 pk.x = (uint32_t)T16<F16>::from_f32(v0) | ((uint32_t)T16<F16>::from_f32(v1) << 16);
                 pk.y = (uint32_t)T16<F16>::from_f32(v2) | ((uint32_t)T16<F16>::from_f32(v3) << 16);
                 if constexpr (STAGE) *reinterpret_cast<uint2*>(Cs + ml * CROW + nl * 2) = pk;
-                else if (mok && n < p.Cout) *reinterpret_cast<uint2*>(out16 + (size_t)m * p.Cout + n) = pk;
+                else if (mok && n < p.Cout) *reinterpret_cast<uint2*>(out16 + (size_t)m * (p.out_ld ? p.out_ld : p.Cout) + n) = pk;
             }
     }
     if constexpr (!STAGE) return;
     __syncthreads();
     constexpr int CPR = BN / 8;                            // 16-byte pieces per tile row
+    const int ldo = p.out_ld ? p.out_ld : p.Cout;          // (a channel slice of a wider tensor: ConvArgs.out_ld)
 #pragma unroll 4
     for (int id = tid; id < BM * CPR; id += NT) {
         const int row = id / CPR, cc = id - row * CPR;
         const int m = m0 + row, n = n0 + cc * 8;
         if (m < p.M && n < p.Cout)
-            *reinterpret_cast<uint4*>(out16 + (size_t)m * p.Cout + n) = *reinterpret_cast<const uint4*>(Cs + row * CROW + cc * 16);
+            *reinterpret_cast<uint4*>(out16 + (size_t)m * ldo + n) = *reinterpret_cast<const uint4*>(Cs + row * CROW + cc * 16);
     }
 }
 
@@ -194,7 +195,7 @@ __device__ __forceinline__ void conv_epilogue_wl(const ConvArgs& p, f32x16 (&acc
         for (int k2 = 0; k2 < 2; ++k2) {
             const uint4 v = *reinterpret_cast<const uint4*>(st + (16 * k2 + row16) * WL_SROW + cc * 16);
             const int m = m0 + (wm * TM + i) * 32 + 16 * k2 + row16;
-            if (m < p.M) *reinterpret_cast<uint4*>(out16 + (size_t)m * p.Cout + nb + cc * 8) = v;
+            if (m < p.M) *reinterpret_cast<uint4*>(out16 + (size_t)m * (p.out_ld ? p.out_ld : p.Cout) + nb + cc * 8) = v;
         }
     }
 }
@@ -2003,6 +2004,10 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
     const bool is_g1 = (v >= 131 && v <= 153) || (v >= 191 && v <= 197);
     if (a.act_after_res && (a.act < 2 || a.out_f32 || aa.splits > 1 || v == 171 || (v >= 181 && v <= 188) || !ISB_EPI_SHARED)) {
         set_error("conv_igemm: act_after_res takes act 2-4 on the kernels with the shared bf16 epilogue (variant %d)", v);
+        return ISB_ERR_INVALID;
+    }
+    if (a.out_ld && (a.out_ld < a.Cout || a.out_ld % 8 != 0 || a.out_f32 || aa.splits > 1 || v == 171 || v == 149 || (v >= 181 && v <= 188))) {
+        set_error("conv_igemm: out_ld (a channel slice of a wider 16-bit tensor) needs out_ld >= Cout, a multiple of 8, and a kernel with the shared epilogue (variant %d)", v);
         return ISB_ERR_INVALID;
     }
     if (a.f16 && !(v == 131 || v == 132 || v == 138 || v == 141 || v == 144 || v == 146 || v == 147 || v == 149 || v == 155 || v == 156 || v == 185 || v == 186)) {

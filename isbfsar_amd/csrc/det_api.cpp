@@ -36,6 +36,9 @@ struct Op {
 struct Tensor {
     int hw = 0, c = 0;
     bool f32 = false;
+    // alias >= 0: this tensor is only ever read by ONE concatenation, so its producer writes it straight into channels
+    // [c_off, c_off + c) of that concatenation's output (ConvArgs.out_ld) and it owns no buffer
+    int alias = -1, c_off = 0;
     DevBuf buf;
 };
 
@@ -169,10 +172,36 @@ struct Builder {
     }
 };
 
+// concatenations in place: an input that a convolution produces and nothing but the concatenation reads (both halves of the five
+// CSP joins, the lateral / down-sampling halves of the four PANet joins) is written by that convolution into its slice of the
+// joined tensor; what is left for concat_kernel is the halves that have other readers or are up-sampled on the way.
+void alias_concat_inputs(isb_det* d) {
+    const char* e = getenv("ISB_DET_ALIAS");               // A/B switch, read when the handle is created
+    if (e && atoi(e) == 0) return;
+    std::vector<int> readers(d->tens.size(), 0), producer(d->tens.size(), -1);
+    for (size_t i = 0; i < d->ops.size(); ++i) {
+        const Op& o = d->ops[i];
+        for (int t : {o.in0, o.in1, o.res})
+            if (t >= 0) readers[t] += 1;
+        if (o.kind == OP_CONV && o.out >= 0) producer[o.out] = (int)i;
+    }
+    for (const Op& o : d->ops) {
+        if (o.kind != OP_CONCAT) continue;
+        const int side[2] = {o.in0, o.in1};
+        for (int s = 0; s < 2; ++s) {
+            const int t = side[s];
+            if ((s == 1 && o.up) || producer[t] < 0 || readers[t] != 1 || d->tens[t].f32 || d->tens[t].c % 8 != 0) continue;
+            d->tens[t].alias = o.out;
+            d->tens[t].c_off = s == 0 ? 0 : d->tens[o.in0].c;
+        }
+    }
+}
+
 int ensure_ws(isb_det* d, int B) {
     if (B <= d->ws_B) return ISB_OK;
     d->ws_B = 0;
-    for (Tensor& t : d->tens) ISB_TRY(t.buf.alloc((size_t)B * t.hw * t.hw * t.c * (t.f32 ? 4 : 2)));
+    for (Tensor& t : d->tens)
+        if (t.alias < 0) ISB_TRY(t.buf.alloc((size_t)B * t.hw * t.hw * t.c * (t.f32 ? 4 : 2)));
     d->ws_B = B;
     return ISB_OK;
 }
@@ -196,6 +225,11 @@ int run(isb_det* d, hipStream_t st, const uint8_t* d_frames, int B, float* d_box
                 a.in = ti.buf.as<uint16_t>(); a.w = c.w.as<uint16_t>(); a.bias = c.bias.as<float>();
                 a.res = o.res >= 0 ? d->tens[o.res].buf.as<uint16_t>() : nullptr;
                 a.out = to.buf.p;
+                if (to.alias >= 0) {                                           // written into its slice of the concatenation
+                    const Tensor& tc = d->tens[to.alias];
+                    a.out = tc.buf.as<uint16_t>() + to.c_off;
+                    a.out_ld = tc.c;
+                }
                 a.B = B; a.H = ti.hw; a.W = ti.hw; a.Cin = c.cin; a.Cout = c.cout_pad; a.KH = c.k; a.KW = c.k; a.stride = c.stride;
                 a.OH = to.hw; a.OW = to.hw; a.pad = (c.k - 1) / 2;             // PyTorch padding: symmetric, also at stride 2
                 a.M = B * to.hw * to.hw; a.K = c.k * c.k * c.cin;
@@ -206,7 +240,8 @@ int run(isb_det* d, hipStream_t st, const uint8_t* d_frames, int B, float* d_box
             }
             case OP_CONCAT: {
                 const Tensor &ta = d->tens[o.in0], &tb = d->tens[o.in1], &to = d->tens[o.out];
-                ISB_TRY(launch_concat(ta.buf.as<uint16_t>(), tb.buf.as<uint16_t>(), to.buf.as<uint16_t>(), B, to.hw, to.hw, ta.c, tb.c, o.up, st));
+                ISB_TRY(launch_concat(ta.alias >= 0 ? nullptr : ta.buf.as<uint16_t>(), tb.alias >= 0 ? nullptr : tb.buf.as<uint16_t>(),
+                                      to.buf.as<uint16_t>(), B, to.hw, to.hw, ta.c, tb.c, o.up, st));
                 break;
             }
             case OP_SPP: {
@@ -269,6 +304,7 @@ extern "C" int isb_det_create(const isb_det_cfg* cfg, isb_det** out) {
     ISB_HIP(hipMemset(d->zeros.p, 0, 256));
     Builder b{d.get()};
     b.build();
+    alias_concat_inputs(d.get());
     *out = d.release();
     return ISB_OK;
     });

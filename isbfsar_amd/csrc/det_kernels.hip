@@ -107,13 +107,15 @@ int launch_det_stem(const StemArgs& a, hipStream_t st) {
 
 // ------------------------------------------------------------------------------------------
 // out[b, y, x, 0:Ca] = a[b, y, x, :];  out[b, y, x, Ca:Ca+Cb] = b[b, y >> up, x >> up, :]   (bf16, 16-byte pieces)
+// a / bsrc may be null: that side of `out` was written in place by its producer (ConvArgs.out_ld), only the other one is copied
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void concat_kernel(const uint16_t* a, const uint16_t* bsrc, uint16_t* out, int B, int H, int W, int Ca,
                                                      int Cb, int up) {
-    const int pc = (Ca + Cb) >> 3;                            // pieces per pixel
+    const int p0 = a ? 0 : (Ca >> 3), p1 = bsrc ? ((Ca + Cb) >> 3) : (Ca >> 3);   // pieces of a pixel this launch copies
+    const int pc = p1 - p0;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (size_t)B * H * W * pc) return;
-    const int piece = (int)(idx % pc);
+    const int piece = p0 + (int)(idx % pc);
     const size_t pix = idx / pc;
     const int c = piece * 8;
     uint4 v;
@@ -132,7 +134,8 @@ int launch_concat(const uint16_t* a, const uint16_t* b, uint16_t* out, int B, in
         set_error("concat: channel counts must be multiples of 8 (Ca=%d Cb=%d) and an upsampled map even-sized", Ca, Cb);
         return ISB_ERR_INVALID;
     }
-    const size_t total = (size_t)B * H * W * ((Ca + Cb) >> 3);
+    if (!a && !b) return ISB_OK;                               // both sides written in place
+    const size_t total = (size_t)B * H * W * (((a ? Ca : 0) + (b ? Cb : 0)) >> 3);
     hipLaunchKernelGGL(concat_kernel, dim3((unsigned)cdivz(total, 256)), dim3(256), 0, st, a, b, out, B, H, W, Ca, Cb, up);
     ISB_LAUNCHED("concat", st);
     return ISB_OK;

@@ -129,6 +129,9 @@ struct ConvArgs {
     int act;                // 0 none, 1 SiLU, 2 Mish, 3 LeakyReLU(0.1), 4 ReLU
     int act_after_res;      // 1: out = act(conv + bias + res) (a ResNet bottleneck's tail) instead of act(conv + bias) + res; shared epilogue only
     int out_f32;
+    // row stride of `out` in elements, 0 = Cout: the 16-bit output lands in a channel slice of a wider tensor (the detector's
+    // concatenations are written in place). Shared / wave-local epilogues only (launch_conv_igemm refuses it elsewhere).
+    int out_ld;
     // in / w / res / out (unless out_f32) hold IEEE fp16 instead of bf16: the two 8x8 stages and the 640 -> 1280 convolution of
     // the pose backbone under isb_hpe_cfg.precision 0. Implemented by the gemm1x1 variants the 8x8 stages
     // select (131, 132, 138; gated 141, 144, 146, 147, 149; weights-stationary 185 / 186) and the split-K reduction.

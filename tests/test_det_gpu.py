@@ -127,6 +127,23 @@ def test_large_micro_batches_are_bit_identical(det, state):
     assert np.isfinite(b1).all() and float(c1.max()) > 0
 
 
+def test_concatenations_in_place_are_bit_identical(det, state, monkeypatch):
+    """Convolutions whose output only a concatenation reads write straight into their channel slice of the joined tensor
+    (ConvArgs.out_ld; both halves of the five CSP joins, one half of the four PANet joins): the same bits as with every
+    concatenation copied (ISB_DET_ALIAS=0, read when the handle is created)."""
+    from isbfsar_amd.det_engine import DetEngine
+    fr = _structured_frames(5, 77)
+    b1, c1 = det.forward(fr)
+    monkeypatch.setenv("ISB_DET_ALIAS", "0")
+    plain = DetEngine(device=0, max_batch=4)
+    try:
+        plain.load_weights(state)
+        b0, c0 = plain.forward(fr)
+    finally:
+        plain.close()
+    assert np.array_equal(b0, b1) and np.array_equal(c0, c1)
+
+
 def test_estimator_uses_the_builtin_detector():
     """HumanPoseEstimator with detector weights configured: estimate() runs detector -> post-processing -> crop -> pose with
     no caller-supplied box (the reference's flow, hpe.py:51-173); just_box mode returns the detector's box."""
