@@ -8,23 +8,25 @@
 
 namespace isb {
 
-// grid (tiles of 8 x 8 output pixels, N); block 256: thread = (pixel 0..63, group of 16 output channels).
-// LDS: the 21 x 21 x 3 input patch of the tile (zeros outside the image) + the 147 x 64 weights, tap-major.
+// grid (tiles of 16 x 16 output pixels, N); block 256: thread = (2 x 2 block of output pixels, group of 16 output channels).
+// LDS: the 37 x 37 x 3 input patch of the tile (zeros outside the image) + the 147 x 64 weights, tap-major. A tap's four
+// weight vectors feed four pixels (8 LDS reads per 64 FMAs; one pixel per thread read 5 per 16 and the launch was bound by
+// them: 2.06 ms per 256 images). Every output still sums its taps in (ky, kx, c) order: the same bits.
 __global__ __launch_bounds__(256) void rgb_stem_kernel(RgbStemArgs p) {
-    __shared__ float patch[3][21][22];
+    __shared__ float patch[3][37][38];
     __shared__ __attribute__((aligned(16))) float wt[147][64];
     const int tid = threadIdx.x;
     const int OH = p.H / 2, OW = p.W / 2;
-    const int tiles_x = (OW + 7) / 8;
+    const int tiles_x = (OW + 15) / 16;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int n = blockIdx.y;
     for (int i = tid; i < 147 * 64; i += 256) {                 // p.w [64][7][7][3] -> wt[(ky * 7 + kx) * 3 + c][o]
         const int o = i / 147, t = i - o * 147;
         wt[t][o] = p.w[i];
     }
-    const int y0 = ty * 16 - 3, x0 = tx * 16 - 3;               // input origin of the patch (stride 2, pad 3)
-    for (int i = tid; i < 3 * 21 * 21; i += 256) {
-        const int c = i / 441, r = (i - c * 441) / 21, q = i - c * 441 - r * 21;
+    const int y0 = ty * 32 - 3, x0 = tx * 32 - 3;               // input origin of the patch (stride 2, pad 3)
+    for (int i = tid; i < 3 * 37 * 37; i += 256) {
+        const int c = i / 1369, r = (i - c * 1369) / 37, q = i - c * 1369 - r * 37;
         const int y = y0 + r, x = x0 + q;
         float v = 0.f;
         if (y >= 0 && y < p.H && x >= 0 && x < p.W)
@@ -32,30 +34,35 @@ __global__ __launch_bounds__(256) void rgb_stem_kernel(RgbStemArgs p) {
         patch[c][r][q] = v;
     }
     __syncthreads();
-    const int px = tid >> 2, g = tid & 3;
-    const int oy = ty * 8 + (px >> 3), ox = tx * 8 + (px & 7);
-    float acc[16];
+    const int quad = tid >> 2, g = tid & 3;
+    const int qy = quad >> 3, qx = quad & 7;                    // outputs (2 qy + dy, 2 qx + dx) of the tile
+    float acc[4][16];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    const int py = (px >> 3) * 2, pxx = (px & 7) * 2;
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[o][e] = 0.f;
     for (int ky = 0; ky < 7; ++ky)
         for (int kx = 0; kx < 7; ++kx)
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float v = patch[c][py + ky][pxx + kx];
                 const float4* wr = reinterpret_cast<const float4*>(&wt[(ky * 7 + kx) * 3 + c][g * 16]);
+                const float4 w0 = wr[0], w1 = wr[1], w2 = wr[2], w3 = wr[3];
+                const float wv[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 w4 = wr[q];
-                    acc[4 * q] = fmaf(v, w4.x, acc[4 * q]); acc[4 * q + 1] = fmaf(v, w4.y, acc[4 * q + 1]);
-                    acc[4 * q + 2] = fmaf(v, w4.z, acc[4 * q + 2]); acc[4 * q + 3] = fmaf(v, w4.w, acc[4 * q + 3]);
+                for (int o = 0; o < 4; ++o) {
+                    const float v = patch[c][(2 * qy + (o >> 1)) * 2 + ky][(2 * qx + (o & 1)) * 2 + kx];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[o][e] = fmaf(v, wv[e], acc[o][e]);
                 }
             }
-    if (oy < OH && ox < OW) {
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        const int oy = ty * 16 + 2 * qy + (o >> 1), ox = tx * 16 + 2 * qx + (o & 1);
+        if (oy >= OH || ox >= OW) continue;
         uint32_t pk[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float a = fmaxf(acc[2 * e] + p.bias[g * 16 + 2 * e], 0.f), b = fmaxf(acc[2 * e + 1] + p.bias[g * 16 + 2 * e + 1], 0.f);
+            const float a = fmaxf(acc[o][2 * e] + p.bias[g * 16 + 2 * e], 0.f), b = fmaxf(acc[o][2 * e + 1] + p.bias[g * 16 + 2 * e + 1], 0.f);
             pk[e] = (uint32_t)f2bf_(a) | ((uint32_t)f2bf_(b) << 16);
         }
         uint4* d = reinterpret_cast<uint4*>(p.out + (((size_t)n * OH + oy) * OW + ox) * 64 + g * 16);
@@ -70,7 +77,7 @@ int launch_rgb_stem(const RgbStemArgs& a, hipStream_t st) {
         return ISB_ERR_INVALID;
     }
     const int OH = a.H / 2, OW = a.W / 2;
-    hipLaunchKernelGGL(rgb_stem_kernel, dim3(cdiv(OH, 8) * cdiv(OW, 8), a.N), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(rgb_stem_kernel, dim3(cdiv(OH, 16) * cdiv(OW, 16), a.N), dim3(256), 0, st, a);
     ISB_LAUNCHED("rgb_stem", st);
     return ISB_OK;
 }
