@@ -264,7 +264,15 @@ class PipelineWorkload(_HpeBase):
 
     def step(self):
         torch = self.torch
-        joints, valid = self.hpe.forward(self.frames, self.bbox)                 # [B,122,3]
+        bbox = self.bbox
+        if getattr(self, "det", None) is not None:
+            # the reference's whole per-frame path (hpe.py:51-79): detector -> most confident person box -> pose. The synthetic
+            # detector weights find no person in synthetic frames, so a frame without a box keeps its synthetic one: every stage
+            # does its full work on every frame
+            boxes, confs = self.det.forward(self.frames)
+            det_bbox, found = self.hpe.select_person(boxes, confs, 0.3)
+            bbox = torch.where(found.bool()[:, None], det_bbox, self.bbox)
+        joints, valid = self.hpe.forward(self.frames, bbox)                      # [B,122,3]
         if not self.checked:
             assert bool(valid.all().item()), "synthetic frames are expected to give in-FOV poses"
             self.checked = True
@@ -303,10 +311,22 @@ class PipelineWorkload(_HpeBase):
 
     def extras(self, args):
         """Measured in the same run as the headline, reported inside `config` (N = 1 only):
+          * value_with_detector -- the reference's whole per-frame path: the YOLOv4 person detector and the box selection in
+            front of the pose stage (BASELINE's configs hand the boxes in);
           * value_bf16x3 -- the pipeline with the AR attention at its fp32-grade precision (hi + lo split, 3 MFMAs per
             product; the reference's TRXOS is fp32);
           * whole_batch_2048 -- BASELINE configs[3]'s WHOLE batch (2048 frames -> 2048 windows) on this one GPU."""
         out = {}
+        if self.B <= 256:
+            from isbfsar_amd import yolov4
+            from isbfsar_amd.det_engine import DetEngine
+            self.det = DetEngine(device=self.dev, max_batch=self.B)
+            self.det.load_weights(yolov4.make_state(0))
+            dt = self._timed(max(3, min(args.steps, 10)))
+            out["value_with_detector"] = round(self.B / dt, 3)
+            out["ms_per_step_with_detector"] = round(dt * 1e3, 4)
+            self.det.close()
+            self.det = None
         if self.ar_precision != "bf16x3":
             ar0 = self.ar
             self.ar = ArEngine(self.L, self.J, self.way, device=self.dev, precision="bf16x3", max_batch=self.B)

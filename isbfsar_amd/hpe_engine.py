@@ -177,7 +177,18 @@ class HpeEngine:
         return joints, valid, pred
 
     def select_person(self, boxes, confs, conf_thresh: float = 0.3):
-        """YOLOv4 export tensors (numpy) -> (bbox int32 [B,4] as x1,x2,y1,y2 or -1s, found u8 [B])."""
+        """YOLOv4 export tensors -> (bbox int32 [B,4] as x1,x2,y1,y2 or -1s, found u8 [B]). numpy -> numpy; torch CUDA
+        tensors (DetEngine.forward's) -> torch CUDA tensors, asynchronous on the current stream."""
+        if not isinstance(boxes, np.ndarray):
+            import torch
+            bx, cf = boxes.contiguous().float(), confs.contiguous().float()
+            B = bx.shape[0]
+            bbox = torch.empty((B, 4), dtype=torch.int32, device=bx.device)
+            found = torch.empty((B,), dtype=torch.uint8, device=bx.device)
+            stream = torch.cuda.current_stream(bx.device).cuda_stream
+            _lib.check(_lib.lib().isb_hpe_select_person(self._h, bx.data_ptr(), cf.data_ptr(), B, conf_thresh, bbox.data_ptr(),
+                                                        found.data_ptr(), C.c_void_p(stream)), "isb_hpe_select_person")
+            return bbox, found
         bx = np.ascontiguousarray(boxes, dtype=np.float32).reshape(-1, 4032, 4)
         cf = np.ascontiguousarray(confs, dtype=np.float32).reshape(-1, 4032, 80)
         B = bx.shape[0]
