@@ -103,6 +103,9 @@ def test_device_path_batching_and_person_selection(det, state):
     eng = HpeEngine(device=0, max_batch=8)
     try:
         bbox, found = eng.select_person(boxes, confs, 0.3)
+        bbox_d, found_d = eng.select_person(b2, c2, 0.3)                        # device tensors in, device tensors out
+        torch.cuda.synchronize()
+        assert np.array_equal(bbox_d.cpu().numpy(), bbox) and np.array_equal(found_d.cpu().numpy(), found)
         for i in range(6):
             sel = ho.select_person(boxes[i:i + 1], confs[i:i + 1], 640, 480)
             assert (sel is None and not found[i]) or tuple(bbox[i]) == sel
