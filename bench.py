@@ -26,7 +26,7 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "bf16x3": 2500.0 / 3.0, "f32": 157.3}   # MI355X_MICROARCH.md
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "bf16x3": 2500.0 / 3.0, "f32": 157.3}   # MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
 
@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--workload", default="auto", choices=["auto", "pipeline", "hpe", "ar", "stream", "det"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (0 = the BASELINE config's)")
     ap.add_argument("--way", type=int, default=60)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "bf16x3"])
     ap.add_argument("--host-input", action="store_true",
                     help="hpe workload: frames start in (pinned) HOST memory each step, isb_hpe_forward_host copies them (PCIe-inclusive "
                          "rate: the reference's Runner pattern; never the headline value)")

@@ -313,6 +313,8 @@ class PipelineWorkload(_HpeBase):
         """Measured in the same run as the headline, reported inside `config` (N = 1 only):
           * value_with_detector -- the reference's whole per-frame path: the YOLOv4 person detector and the box selection in
             front of the pose stage (BASELINE's configs hand the boxes in);
+          * value_f16 -- the pipeline with the AR attention on fp16 operands (11 significant bits at bf16's matrix rate: logits
+            2-13x closer to the fp32 reference, tests/test_ar_gpu.py);
           * value_bf16x3 -- the pipeline with the AR attention at its fp32-grade precision (hi + lo split, 3 MFMAs per
             product; the reference's TRXOS is fp32);
           * whole_batch_2048 -- BASELINE configs[3]'s WHOLE batch (2048 frames -> 2048 windows) on this one GPU."""
@@ -327,6 +329,16 @@ class PipelineWorkload(_HpeBase):
             out["ms_per_step_with_detector"] = round(dt * 1e3, 4)
             self.det.close()
             self.det = None
+        if self.ar_precision == "bf16":
+            ar0 = self.ar
+            self.ar = ArEngine(self.L, self.J, self.way, device=self.dev, precision="f16", max_batch=self.B)
+            self.ar.load_weights(self.ar_state)
+            self.ar.set_support(poses=self.ss)
+            dt = self._timed(max(3, min(args.steps, 10)))
+            out["value_f16"] = round(self.B / dt, 3)
+            out["ms_per_step_f16"] = round(dt * 1e3, 4)
+            self.ar.close() if hasattr(self.ar, "close") else None
+            self.ar = ar0
         if self.ar_precision != "bf16x3":
             ar0 = self.ar
             self.ar = ArEngine(self.L, self.J, self.way, device=self.dev, precision="bf16x3", max_batch=self.B)

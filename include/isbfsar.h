@@ -45,6 +45,8 @@ extern "C" {
  * GEMMs always run on the exact f32 MFMA path. */
 #define ISB_AR_PREC_BF16 0     /* bf16 operands, f32 accumulate                      */
 #define ISB_AR_PREC_BF16X3 1   /* split-bf16 (hi+lo, 3 MFMA / product), ~2^-16 rel.  */
+#define ISB_AR_PREC_F16 2      /* IEEE fp16 operands (11 significant bits, 8x bf16's resolution) at bf16's rate: K, V^T and the
+                                  attention weights of the all-classes pass; the arg-max class's pass stays split-bf16 */
 
 const char* isb_last_error(void);
 int isb_version(void);

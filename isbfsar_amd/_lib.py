@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("ISB_LIB_PATH") or os.path.join(_HERE, "csrc", "libisb
 
 ISB_AR_PREC_BF16 = 0
 ISB_AR_PREC_BF16X3 = 1
+ISB_AR_PREC_F16 = 2
 
 
 class IsbError(RuntimeError):

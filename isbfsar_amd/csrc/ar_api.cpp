@@ -23,13 +23,14 @@ struct isb_ar {
     int n = 0;                    // live classes
     bool weights = false, support = false;
     bool x3 = false, online = false;
+    bool f16 = false;       // ISB_AR_PREC_F16: the all-classes attention pass on fp16 fragment images (KqF16 / KcF16 / VtF16)
     float kscale = 0.f, qnorm_bound = 0.f;
     hipStream_t own_stream = nullptr;
 
     // weights (device)
     DevBuf w1, b1, w2, b2, wcat, bk, bv, gamma, beta, wd, bd, wf1, bf1, wf2, bf2, wf3, bf3, pe, tup;
     // support cache
-    DevBuf s_feat, s_proj, KcF, KcF_lo, VtF, VtF_lo, ub;
+    DevBuf s_feat, s_proj, KcF, KcF_lo, VtF, VtF_lo, ub, KcF16, VtF16, KqF16;
     // per-chunk workspace
     int ws_B = 0;
     DevBuf VqF;
@@ -59,6 +60,7 @@ int ensure_ws(isb_ar* h, int Bc) {
     ISB_TRY(h->KqF.alloc(B * h->NT * 4096 * 2));
     ISB_TRY(h->VqF.alloc(B * h->NT * 16 * 64 * 16));       // f32 V of the query tuples, 16 KiB per 32-tuple tile
     ISB_TRY(h->KqF_lo.alloc(B * h->NT * 4096 * 2));        // always: the arg-max class's diff is formed in bf16x3 (below)
+    if (h->f16) ISB_TRY(h->KqF16.alloc(B * h->NT * 4096 * 2));
     ISB_TRY(h->lse2.alloc(B * nmax * h->Tp * 4));
     ISB_TRY(h->lse2c.alloc(B * h->Tp * 4));
     ISB_TRY(h->part.alloc(B * nmax * h->NT * 4));
@@ -113,8 +115,8 @@ extern "C" int isb_ar_create(const isb_ar_cfg* cfg, isb_ar** out) {
     ISB_REQUIRE(cfg->seq_len >= 2 && cfg->seq_len <= 64, ISB_ERR_INVALID, "seq_len %d outside [2,64]", cfg->seq_len);
     ISB_REQUIRE(cfg->n_joints >= 1 && cfg->n_joints <= 1024, ISB_ERR_INVALID, "n_joints %d outside [1,1024]", cfg->n_joints);
     ISB_REQUIRE(cfg->way_max >= 1 && cfg->way_max <= 4096, ISB_ERR_INVALID, "way_max %d outside [1,4096]", cfg->way_max);
-    ISB_REQUIRE(cfg->precision == ISB_AR_PREC_BF16 || cfg->precision == ISB_AR_PREC_BF16X3, ISB_ERR_INVALID,
-                "unknown precision %d", cfg->precision);
+    ISB_REQUIRE(cfg->precision == ISB_AR_PREC_BF16 || cfg->precision == ISB_AR_PREC_BF16X3 || cfg->precision == ISB_AR_PREC_F16,
+                ISB_ERR_INVALID, "unknown precision %d", cfg->precision);
     int ndev = 0;
     ISB_HIP(hipGetDeviceCount(&ndev));
     ISB_REQUIRE(cfg->device >= 0 && cfg->device < ndev, ISB_ERR_INVALID, "device %d not in [0,%d)", cfg->device, ndev);
@@ -131,6 +133,7 @@ extern "C" int isb_ar_create(const isb_ar_cfg* cfg, isb_ar** out) {
     h->NT = cdiv(h->T, 32);
     h->Tp = h->NT * 32;
     h->x3 = cfg->precision == ISB_AR_PREC_BF16X3;
+    h->f16 = cfg->precision == ISB_AR_PREC_F16;
     ISB_HIP(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     *out = h.release();
     return ISB_OK;
@@ -312,6 +315,10 @@ static int set_support_impl(isb_ar* h, const float* poses, const float* trunk, c
     ISB_TRY(h->VtF.alloc(img));
     ISB_TRY(h->KcF_lo.alloc(img));            // lo parts always: the arg-max class's diff (the Discriminator's input) is
     ISB_TRY(h->VtF_lo.alloc(img));            // formed in bf16x3 whatever the precision of the all-classes pass
+    if (h->f16) {
+        ISB_TRY(h->KcF16.alloc(img));
+        ISB_TRY(h->VtF16.alloc(img));
+    }
     ISB_TRY(h->ub.alloc((size_t)n * h->Tp * 4));
     ISB_HIP(hipMemsetAsync(h->ub.p, 0, (size_t)n * h->Tp * 4, st));
     ArTupleArgs a{};
@@ -321,6 +328,7 @@ static int set_support_impl(isb_ar* h, const float* poses, const float* trunk, c
     a.tup = h->tup.as<int16_t>();
     a.KF = h->KcF.as<uint16_t>(); a.KF_lo = h->KcF_lo.as<uint16_t>();
     a.VtF = h->VtF.as<uint16_t>(); a.VtF_lo = h->VtF_lo.as<uint16_t>();
+    if (h->f16) { a.KF16 = h->KcF16.as<uint16_t>(); a.VtF16 = h->VtF16.as<uint16_t>(); }
     a.ub = h->ub.as<float>();
     a.kscale = 1.0f;
     a.qnorm_bound = h->qnorm_bound;
@@ -393,17 +401,18 @@ static int infer_impl(isb_ar* h, const float* d_windows, const float* d_trunk, i
         ta.gamma = h->gamma.as<float>(); ta.beta = h->beta.as<float>();
         ta.tup = h->tup.as<int16_t>();
         ta.KF = h->KqF.as<uint16_t>(); ta.KF_lo = h->KqF_lo.as<uint16_t>();
+        if (h->f16) ta.KF16 = h->KqF16.as<uint16_t>();
         ta.VqF = h->VqF.as<float>();
         ta.kscale = h->kscale;
         ta.n_items = Bc; ta.L = L; ta.T = T; ta.NT = NT;
         ISB_TRY(launch_ar_tuples(ta, st));
 
         ArStatsArgs sa{};
-        sa.KqF = h->KqF.as<uint16_t>(); sa.KqF_lo = h->x3 ? h->KqF_lo.as<uint16_t>() : nullptr;
-        sa.KcF = h->KcF.as<uint16_t>(); sa.KcF_lo = h->x3 ? h->KcF_lo.as<uint16_t>() : nullptr;
+        sa.KqF = (h->f16 ? h->KqF16 : h->KqF).as<uint16_t>(); sa.KqF_lo = h->x3 ? h->KqF_lo.as<uint16_t>() : nullptr;
+        sa.KcF = (h->f16 ? h->KcF16 : h->KcF).as<uint16_t>(); sa.KcF_lo = h->x3 ? h->KcF_lo.as<uint16_t>() : nullptr;
         sa.ub = h->ub.as<float>();
         sa.lse2 = h->lse2.as<float>();
-        sa.B = Bc; sa.n = n; sa.T = T; sa.NT = NT; sa.x3 = h->x3; sa.online = h->online;
+        sa.B = Bc; sa.n = n; sa.T = T; sa.NT = NT; sa.x3 = h->x3; sa.f16 = h->f16; sa.online = h->online;
         ISB_TRY(launch_ar_stats(sa, st));
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (h->prof) {
@@ -414,12 +423,12 @@ static int infer_impl(isb_ar* h, const float* d_windows, const float* d_trunk, i
 
         ArProtoArgs pa{};
         pa.KqF = sa.KqF; pa.KqF_lo = sa.KqF_lo; pa.KcF = sa.KcF; pa.KcF_lo = sa.KcF_lo;
-        pa.VtF = h->VtF.as<uint16_t>(); pa.VtF_lo = h->x3 ? h->VtF_lo.as<uint16_t>() : nullptr;
+        pa.VtF = (h->f16 ? h->VtF16 : h->VtF).as<uint16_t>(); pa.VtF_lo = h->x3 ? h->VtF_lo.as<uint16_t>() : nullptr;
         pa.lse2 = h->lse2.as<float>();
         pa.proj = h->proj.as<float>(); pa.bv = h->bv.as<float>(); pa.tup = h->tup.as<int16_t>();
         pa.VqF = h->VqF.as<float>();
         pa.chosen = nullptr; pa.part = h->part.as<float>(); pa.diff = nullptr;
-        pa.B = Bc; pa.n = n; pa.L = L; pa.T = T; pa.NT = NT; pa.x3 = h->x3;
+        pa.B = Bc; pa.n = n; pa.L = L; pa.T = T; pa.NT = NT; pa.x3 = h->x3; pa.f16 = h->f16;
         ISB_TRY(launch_ar_proto(pa, st));
         if (h->prof) {
             ISB_HIP(hipEventRecord(e1, st));
@@ -437,11 +446,13 @@ static int infer_impl(isb_ar* h, const float* d_windows, const float* d_trunk, i
         // with resolving power amplifies bf16 noise in `diff` to 6e-2 on the open-set score: tests/golden/ar_sharp_*):
         // it ALWAYS runs in bf16x3 -- column sums of the chosen class (ar_stats, chosen mode) and prototype alike --
         // so the open-set score holds the 1e-3 of the north star in either precision setting.
-        sa.chosen = chosen; sa.lse2 = h->lse2c.as<float>(); sa.x3 = 1;
+        sa.chosen = chosen; sa.lse2 = h->lse2c.as<float>(); sa.x3 = 1; sa.f16 = 0;
+        sa.KqF = h->KqF.as<uint16_t>(); sa.KcF = h->KcF.as<uint16_t>();
         sa.KqF_lo = h->KqF_lo.as<uint16_t>(); sa.KcF_lo = h->KcF_lo.as<uint16_t>();
         ISB_TRY(launch_ar_stats(sa, st));
         pa.chosen = chosen; pa.part = nullptr; pa.diff = h->diff.as<float>();
-        pa.x3 = 1; pa.lse2 = h->lse2c.as<float>(); pa.lse_per_window = 1;
+        pa.x3 = 1; pa.f16 = 0; pa.lse2 = h->lse2c.as<float>(); pa.lse_per_window = 1;
+        pa.KqF = h->KqF.as<uint16_t>(); pa.KcF = h->KcF.as<uint16_t>(); pa.VtF = h->VtF.as<uint16_t>();
         pa.KqF_lo = h->KqF_lo.as<uint16_t>(); pa.KcF_lo = h->KcF_lo.as<uint16_t>(); pa.VtF_lo = h->VtF_lo.as<uint16_t>();
         ISB_TRY(launch_ar_proto(pa, st));
         ISB_TRY(gemm(st, h->diff.as<float>(), 128, h->wd.as<float>(), 128, h->bd.as<float>(), h->y1.as<float>(), L,

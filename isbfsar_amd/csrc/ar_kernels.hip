@@ -48,6 +48,16 @@ __device__ __forceinline__ bf16x8 ld_frag(const uint16_t* p) {
 }
 
 #define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// the same 16-byte fragments read as IEEE fp16 (ISB_AR_PREC_F16): 11 significant bits instead of 8 at the matrix pipe's bf16 rate
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ uint16_t f2h_sat(float x) {      // round to nearest even, saturating at the largest finite fp16
+    return __builtin_bit_cast(uint16_t, (_Float16)fminf(fmaxf(x, -65504.0f), 65504.0f));
+}
 
 // One LDS-DMA instruction (lane l's 16 bytes land at LDS byte address lds_addr + 16 l), issued through inline asm:
 // through the builtin the compiler models an LDS store and orders every later LDS read behind it (vmcnt(0)),
@@ -131,12 +141,13 @@ __global__ __launch_bounds__(512) void ar_tuples_k_kernel(ArTupleArgs p) {
     for (int q = 0; q < 16; ++q) var += red[q][r];
     var *= (1.f / 128.f);
     const float rstd = 1.0f / sqrtf(var + 1e-5f);
-    uint16_t hi[8], lo[8];
+    uint16_t hi[8], lo[8], hf[8];
     float nrm = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         float y = 0.f;
         if (valid) y = ((k[e] - mean) * rstd * p.gamma[d0 + e] + p.beta[d0 + e]) * p.kscale;
+        hf[e] = f2h_sat(y);
         hi[e] = f2bf(y);
         const float yh = bf2f(hi[e]);
         lo[e] = f2bf(y - yh);
@@ -173,6 +184,11 @@ __global__ __launch_bounds__(512) void ar_tuples_k_kernel(ArTupleArgs p) {
         o.z = lo[4] | ((uint32_t)lo[5] << 16); o.w = lo[6] | ((uint32_t)lo[7] << 16);
         *reinterpret_cast<uint4*>(p.KF_lo + off) = o;
     }
+    if (p.KF16) {
+        o.x = hf[0] | ((uint32_t)hf[1] << 16); o.y = hf[2] | ((uint32_t)hf[3] << 16);
+        o.z = hf[4] | ((uint32_t)hf[5] << 16); o.w = hf[6] | ((uint32_t)hf[7] << 16);
+        *reinterpret_cast<uint4*>(p.KF16 + off) = o;
+    }
     if (p.ub) {   // support side: ub[item][t] = |kc_t| * bound(|kq'|)
         __syncthreads();
         red[slot][r] = nrm;
@@ -194,7 +210,7 @@ __global__ __launch_bounds__(512) void ar_tuples_vt_kernel(ArTupleArgs p) {
     const int jt = blockIdx.x, item = blockIdx.y;
     const int d = 32 * dt + r;
     const float bias = p.bv[d];
-    uint16_t hi[8], lo[8];
+    uint16_t hi[8], lo[8], hf[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int j = jt * 32 + 16 * s + 8 * (e >> 2) + 4 * h + (e & 3);
@@ -204,6 +220,7 @@ __global__ __launch_bounds__(512) void ar_tuples_vt_kernel(ArTupleArgs p) {
             y = p.proj[(size_t)(item * p.L + f0) * 512 + 256 + d] +
                 p.proj[(size_t)(item * p.L + f1) * 512 + 384 + d] + bias;
         }
+        hf[e] = f2h_sat(y);
         hi[e] = f2bf(y);
         lo[e] = f2bf(y - bf2f(hi[e]));
     }
@@ -216,6 +233,11 @@ __global__ __launch_bounds__(512) void ar_tuples_vt_kernel(ArTupleArgs p) {
         o.x = lo[0] | ((uint32_t)lo[1] << 16); o.y = lo[2] | ((uint32_t)lo[3] << 16);
         o.z = lo[4] | ((uint32_t)lo[5] << 16); o.w = lo[6] | ((uint32_t)lo[7] << 16);
         *reinterpret_cast<uint4*>(p.VtF_lo + off) = o;
+    }
+    if (p.VtF16) {
+        o.x = hf[0] | ((uint32_t)hf[1] << 16); o.y = hf[2] | ((uint32_t)hf[3] << 16);
+        o.z = hf[4] | ((uint32_t)hf[5] << 16); o.w = hf[6] | ((uint32_t)hf[7] << 16);
+        *reinterpret_cast<uint4*>(p.VtF16 + off) = o;
     }
 }
 
@@ -234,8 +256,9 @@ int launch_ar_tuples(const ArTupleArgs& a, hipStream_t st) {
 // =====================================================================================
 constexpr int STATS_WT = 8, STATS_ST = 16;
 
-template <bool X3, bool ONLINE>
+template <bool X3, bool ONLINE, bool F16 = false>
 __global__ __launch_bounds__(512, 2) void ar_stats_kernel(ArStatsArgs p) {
+    static_assert(!(X3 && F16), "fp16 fragments have no lo part");
     constexpr int TILE_U16 = 8 * 64 * 8;                  // one K tile: 8 chunks of 1 KiB
     constexpr int NBUF_U16 = TILE_U16 * (X3 ? 2 : 1);
     constexpr int NB = 4;                                 // ring: tile it is consumed while it+1 .. it+3 are in flight
@@ -321,7 +344,7 @@ __global__ __launch_bounds__(512, 2) void ar_stats_kernel(ArStatsArgs p) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
-                acc = MFMA_BF16(a_hi[ks], bh[ks], acc);
+                acc = mfma16<F16>(a_hi[ks], bh[ks], acc);
                 if (X3) {
                     acc = MFMA_BF16(a_hi[ks], bl[ks], acc);
                     acc = MFMA_BF16(a_lo[ks], bh[ks], acc);
@@ -389,9 +412,16 @@ int launch_ar_stats(const ArStatsArgs& a0, hipStream_t st) {
     a.wt = std::min(STATS_WT, cdiv(a.B, 8));      // a few windows (the live loop): no grid padding to a full L2 block
     const int ncls = a.chosen ? 1 : a.n;
     dim3 grid(8 * cdiv(cdiv(a.B, 8), a.wt) * cdiv(cdiv(ncls * a.NT, 8), STATS_ST) * (a.wt * STATS_ST));
+    if (a.f16 && a.x3) {
+        set_error("ar_stats: fp16 fragments and the bf16 hi + lo split exclude each other");
+        return ISB_ERR_INVALID;
+    }
     if (a.x3) {
         if (online) hipLaunchKernelGGL((ar_stats_kernel<true, true>), grid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((ar_stats_kernel<true, false>), grid, dim3(512), 0, st, a);
+    } else if (a.f16) {
+        if (online) hipLaunchKernelGGL((ar_stats_kernel<false, true, true>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((ar_stats_kernel<false, false, true>), grid, dim3(512), 0, st, a);
     } else {
         if (online) hipLaunchKernelGGL((ar_stats_kernel<false, true>), grid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((ar_stats_kernel<false, false>), grid, dim3(512), 0, st, a);
@@ -410,8 +440,9 @@ int launch_ar_stats(const ArStatsArgs& a0, hipStream_t st) {
 // =====================================================================================
 constexpr int PROTO_WT = 16, PROTO_CT = 8;
 
-template <bool X3, bool CHOSEN>
+template <bool X3, bool CHOSEN, bool F16 = false>
 __global__ __launch_bounds__(512, 2) void ar_proto_kernel(ArProtoArgs p) {
+    static_assert(!(X3 && F16), "fp16 fragments have no lo part");
     constexpr int KT_U16 = 8 * 64 * 8;                    // Kc tile (8 KiB)
     constexpr int VT_U16 = 4 * 2 * 64 * 8;                // V^T tile (8 KiB)
     constexpr int PART_U16 = KT_U16 + VT_U16;
@@ -551,7 +582,7 @@ __global__ __launch_bounds__(512, 2) void ar_proto_kernel(ArProtoArgs p) {
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
-                    acc = MFMA_BF16(ah[ks], q_hi[ks], acc);
+                    acc = mfma16<F16>(ah[ks], q_hi[ks], acc);
                     if (X3) {
                         acc = MFMA_BF16(ah[ks], q_lo[ks], acc);
                         acc = MFMA_BF16(al[ks], q_hi[ks], acc);
@@ -573,16 +604,20 @@ __global__ __launch_bounds__(512, 2) void ar_proto_kernel(ArProtoArgs p) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float pe = __builtin_amdgcn_exp2f(acc[8 * s + e] - lse[8 * s + e]);
-                    const __bf16 ph = (__bf16)pe;
-                    a_hi[s][e] = ph;
-                    if (X3) a_lo[s][e] = (__bf16)(pe - (float)ph);
+                    if constexpr (F16) {
+                        a_hi[s][e] = __builtin_bit_cast(__bf16, (_Float16)pe);      // A^T <= 1: no saturation needed
+                    } else {
+                        const __bf16 ph = (__bf16)pe;
+                        a_hi[s][e] = ph;
+                        if (X3) a_lo[s][e] = (__bf16)(pe - (float)ph);
+                    }
                 }
             // P^T += V^T[jt] * A^T
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    pacc[dt] = MFMA_BF16(vh[dt * 2 + s], a_hi[s], pacc[dt]);
+                    pacc[dt] = mfma16<F16>(vh[dt * 2 + s], a_hi[s], pacc[dt]);
                     if (X3) {
                         pacc[dt] = MFMA_BF16(vh[dt * 2 + s], a_lo[s], pacc[dt]);
                         pacc[dt] = MFMA_BF16(vl[dt * 2 + s], a_hi[s], pacc[dt]);
@@ -634,7 +669,13 @@ int launch_ar_proto(const ArProtoArgs& a0, hipStream_t st) {
         a.wt = std::min(PROTO_WT, nxl);                             // a few windows: no grid padding to a full L2 block
         grid = dim3(8 * cdiv(nxl, a.wt) * cdiv(a.n, PROTO_CT) * (a.wt * PROTO_CT));
     }
-    if (a.x3) {
+    if (a.f16 && (a.x3 || chosen)) {
+        set_error("ar_proto: fp16 fragments are the all-classes pass's; the arg-max class's pass runs on the bf16 hi + lo images");
+        return ISB_ERR_INVALID;
+    }
+    if (a.f16) {
+        hipLaunchKernelGGL((ar_proto_kernel<false, false, true>), grid, dim3(512), 0, st, a);
+    } else if (a.x3) {
         if (chosen) hipLaunchKernelGGL((ar_proto_kernel<true, true>), grid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((ar_proto_kernel<true, false>), grid, dim3(512), 0, st, a);
     } else {

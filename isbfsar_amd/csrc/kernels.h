@@ -48,6 +48,8 @@ struct ArTupleArgs {
     uint16_t* KF_lo;        // out, lo part (bf16x3) or null
     uint16_t* VtF;          // out (support only) or null
     uint16_t* VtF_lo;       // out or null
+    uint16_t* KF16;         // out or null: the same K image in IEEE fp16 (ISB_AR_PREC_F16: operands of the all-classes pass)
+    uint16_t* VtF16;        // out or null: the V^T image in fp16
     float* ub;              // out (support only): [n_items][Tp] = |kc_j| * qnorm_bound, or null
     float* VqF;             // out (query only) or null: f32 V of every tuple in ar_proto's epilogue order,
                             // [item][it][piece = 4 dt + q][lane = 32 h + r][4] = V[32 it + r][32 dt + 8 q + 4 h ..+4]
@@ -66,6 +68,7 @@ struct ArStatsArgs {
     float* lse2;            // out [B][n][Tp]: log2 sum_i exp2(s'[i,j])
     int B, n, T, NT;
     int x3;
+    int f16;                // KqF / KcF hold fp16 fragments (ArTupleArgs.KF16): v_mfma_f32_32x32x16_f16; not with x3 / chosen
     int online;             // 1: running-max variant (bound too loose to exclude underflow)
     int wt;                 // grid decode: windows per L2 block (set by the launcher, <= STATS_WT)
     const int32_t* chosen;  // null: every class -> lse2 [B][n][Tp]; else ONLY class chosen[b] of window b -> lse2 [B][Tp]
@@ -89,6 +92,7 @@ struct ArProtoArgs {
     float* diff;            // out [B][T][128] (chosen mode)
     int B, n, L, T, NT;
     int x3;
+    int f16;                // KqF / KcF / VtF hold fp16 fragments and A^T is formed in fp16; not with x3 / chosen
     int wt;                 // grid decode: window groups per L2 block (set by the launcher, <= PROTO_WT)
     int lse_per_window;     // chosen mode: lse2 is [B][Tp] (ArStatsArgs.chosen), not [B][n][Tp]
 };

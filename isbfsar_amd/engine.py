@@ -35,12 +35,12 @@ class ArEngine:
         """input_type (TRXConfig.input_type): "skeleton" (features = MLP(pose), 256 wide) or "hybrid" (features =
         [PostResNet(ResNet-50 trunk) | MLP(pose)], 512 wide; set_support / infer then also take trunk features
         [.., L, 2048], e.g. from RgbEngine)."""
-        prec = {"bf16": _lib.ISB_AR_PREC_BF16, "bf16x3": _lib.ISB_AR_PREC_BF16X3}.get(precision, precision)
+        prec = {"bf16": _lib.ISB_AR_PREC_BF16, "bf16x3": _lib.ISB_AR_PREC_BF16X3, "f16": _lib.ISB_AR_PREC_F16}.get(precision, precision)
         if input_type not in ("skeleton", "hybrid"):
             raise ValueError(f"input_type {input_type!r}: 'skeleton' or 'hybrid' (the reference's 'rgb' type is inconsistent with "
                              "its own model: utils/params.py:81 sizes the transformer for 1000-wide features, model.py:274-277 makes 256)")
         self.L, self.J, self.way_max, self.device = seq_len, n_joints, way_max, device
-        self.precision = "bf16x3" if prec == _lib.ISB_AR_PREC_BF16X3 else "bf16"
+        self.precision = {_lib.ISB_AR_PREC_BF16X3: "bf16x3", _lib.ISB_AR_PREC_F16: "f16"}.get(prec, "bf16")
         self.input_type = input_type
         self.d_in = 512 if input_type == "hybrid" else 256
         self.n = 0
