@@ -599,19 +599,32 @@ __global__ __launch_bounds__(512, 2) void ar_proto_kernel(ArProtoArgs p) {
             __builtin_amdgcn_sched_barrier(0);
             // A^T = exp2(S^T - lse2): accumulator rows 8s..8s+7 become k-step s of the B operand
             bf16x8 a_hi[2], a_lo[2];
+            if constexpr (F16) {
+                // pairs through v_cvt_pk_f16_f32 (A^T <= 1: no saturation needed)
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
+                for (int s = 0; s < 2; ++s) {
+                    uint32_t w[4];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float pe = __builtin_amdgcn_exp2f(acc[8 * s + e] - lse[8 * s + e]);
-                    if constexpr (F16) {
-                        a_hi[s][e] = __builtin_bit_cast(__bf16, (_Float16)pe);      // A^T <= 1: no saturation needed
-                    } else {
+                    for (int e = 0; e < 4; ++e) {
+                        const f32x2 pe = {__builtin_amdgcn_exp2f(acc[8 * s + 2 * e] - lse[8 * s + 2 * e]),
+                                          __builtin_amdgcn_exp2f(acc[8 * s + 2 * e + 1] - lse[8 * s + 2 * e + 1])};
+                        w[e] = __builtin_bit_cast(uint32_t, __builtin_convertvector(pe, f16x2));
+                    }
+                    a_hi[s] = __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float pe = __builtin_amdgcn_exp2f(acc[8 * s + e] - lse[8 * s + e]);
                         const __bf16 ph = (__bf16)pe;
                         a_hi[s][e] = ph;
                         if (X3) a_lo[s][e] = (__bf16)(pe - (float)ph);
                     }
-                }
+            }
             // P^T += V^T[jt] * A^T
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
