@@ -38,7 +38,8 @@ def parse():
     ap.add_argument("--workload", default="auto", choices=["auto", "pipeline", "hpe", "ar", "stream", "det"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (0 = the BASELINE config's)")
     ap.add_argument("--way", type=int, default=60)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "bf16x3"])
+    ap.add_argument("--precision", default="f16", choices=["bf16", "f16", "bf16x3"],
+                    help="operand type of the two tuple-attention contractions (f16: the default -- bf16's matrix rate, logits 2-13x closer to the fp32 reference)")
     ap.add_argument("--host-input", action="store_true",
                     help="hpe workload: frames start in (pinned) HOST memory each step, isb_hpe_forward_host copies them (PCIe-inclusive "
                          "rate: the reference's Runner pattern; never the headline value)")
@@ -133,7 +134,7 @@ class ArWorkload:
         traffic = None
         from bench_workloads import latest_traffic_json
         tj = latest_traffic_json()
-        if tj and chunk == 1024 and self.way == 60 and self.precision == "bf16":
+        if tj and chunk == 1024 and self.way == 60 and self.precision in ("bf16", "f16"):
             with open(tj) as f:       # HBM bytes of one ar_proto launch (PMC passes, profiles/README.md)
                 traffic = json.load(f).get("ar_b1024", {}).get("ar_proto", {}).get("hbm_bytes_per_launch")
         return {"bound": "mfma", "kernel": "ar_proto_kernel", "achieved": round(achieved, 2), "peak": peak,

@@ -103,7 +103,7 @@ def igemm_macs_per_crop() -> int:
 
 class _HpeBase:
     L, J = 30, 122
-    precision = "bf16"
+    precision = "f16"          # 16-bit storage type of the pose backbone (isb_hpe_cfg.precision 0 / 2) and of the AR attention operands
 
     def _setup_hpe(self, args, rank, dev):
         import torch
@@ -313,8 +313,8 @@ class PipelineWorkload(_HpeBase):
         """Measured in the same run as the headline, reported inside `config` (N = 1 only):
           * value_with_detector -- the reference's whole per-frame path: the YOLOv4 person detector and the box selection in
             front of the pose stage (BASELINE's configs hand the boxes in);
-          * value_f16 -- the pipeline with the AR attention on fp16 operands (11 significant bits at bf16's matrix rate: logits
-            2-13x closer to the fp32 reference, tests/test_ar_gpu.py);
+          * value_ar_bf16 -- the pipeline with the AR attention on bf16 operands (round 3's default; fp16 operands -- 11 significant
+            bits at the same matrix rate, logits 2-13x closer to the fp32 reference, tests/test_ar_gpu.py -- are the default now);
           * value_bf16x3 -- the pipeline with the AR attention at its fp32-grade precision (hi + lo split, 3 MFMAs per
             product; the reference's TRXOS is fp32);
           * whole_batch_2048 -- BASELINE configs[3]'s WHOLE batch (2048 frames -> 2048 windows) on this one GPU."""
@@ -329,14 +329,14 @@ class PipelineWorkload(_HpeBase):
             out["ms_per_step_with_detector"] = round(dt * 1e3, 4)
             self.det.close()
             self.det = None
-        if self.ar_precision == "bf16":
+        if self.ar_precision == "f16":
             ar0 = self.ar
-            self.ar = ArEngine(self.L, self.J, self.way, device=self.dev, precision="f16", max_batch=self.B)
+            self.ar = ArEngine(self.L, self.J, self.way, device=self.dev, precision="bf16", max_batch=self.B)
             self.ar.load_weights(self.ar_state)
             self.ar.set_support(poses=self.ss)
             dt = self._timed(max(3, min(args.steps, 10)))
-            out["value_f16"] = round(self.B / dt, 3)
-            out["ms_per_step_f16"] = round(dt * 1e3, 4)
+            out["value_ar_bf16"] = round(self.B / dt, 3)
+            out["ms_per_step_ar_bf16"] = round(dt * 1e3, 4)
             self.ar.close() if hasattr(self.ar, "close") else None
             self.ar = ar0
         if self.ar_precision != "bf16x3":
@@ -382,11 +382,13 @@ class PipelineWorkload(_HpeBase):
 
     def config(self, world):
         return {"workload": f"BASELINE configs[3] per-GPU shard: {self.B} synthetic 640x480 frames/GPU "
-                            f"({self.N_CAM} cameras x {self.steps_per_cam} steps) -> HPE (EfficientNetV2-L bf16, 122 joints) -> "
+                            f"({self.N_CAM} cameras x {self.steps_per_cam} steps) -> HPE (EfficientNetV2-L, 122 joints) -> "
                             f"30-frame windows -> AR (way={self.way}) -> open-set score",
                 "per_gpu_batch": self.B, "seq_len": self.L, "n_joints": self.J, "way": self.way,
-                "ar_precision": self.ar_precision, "hpe_precision": self.hpe.precision + " (bf16 storage; fp16 in the two 8x8 stages "
-                "and the 640->1280 conv; f32 accumulate, f32 head / decode, f64 reconstruction)" if self.hpe.precision == "bf16_f16tail" else self.hpe.precision,
+                "ar_precision": self.ar_precision,
+                "hpe_precision": self.hpe.precision + {"f16": " (IEEE fp16 weights and activations in every stage -- the reference's TensorRT precision, "
+                                                              "7_create_engines.py:10; f32 accumulate, f32 head / decode, f64 reconstruction)",
+                                                       "bf16_f16tail": " (bf16 storage; fp16 in the two 8x8 stages and the 640->1280 conv)"}.get(self.hpe.precision, ""),
                 "parallelism": f"dp{world} (frames sharded; one all-gather of per-window records"
                                + (": RCCL behind the C ABI (isb_dist_all_gather)" if self.gather is not None else "")
                                + (", on a second stream beside the next step's pose stage)" if self.side is not None else ")")}

@@ -150,13 +150,15 @@ typedef struct isb_hpe_cfg {
                                * convolution kernels address a tensor with 32-bit byte offsets and the largest activation
                                * is 2 MiB per frame. Any B is accepted by isb_hpe_forward (it micro-batches). */
     int32_t n_out_joints;     /* informational: joints per pose after selection (30 / 122) */
-    int32_t precision;        /* 16-bit storage type of the backbone (was `reserved`; 0 keeps old callers valid):
-                               * 0 = bf16, with the two 8x8 stages (32 of the 79 blocks) and the 640 -> 1280 convolution in IEEE
-                               *     fp16 (weights and activations; same MFMA rate, 3 more mantissa bits): the returned absolute
-                               *     pose (hpe.py:171) then sits within 1e-3 of the fp32 definition, where bf16 everywhere is at
-                               *     1e-3 ... 3e-3 (per-stage budget: DESIGN.md section 4). The reference's own engines are fp16
-                               *     throughout (7_create_engines.py:10).
-                               * 1 = bf16 everywhere (the round-2 layout). */
+    int32_t precision;        /* 16-bit storage type of the backbone (weights AND activations; f32 accumulate everywhere):
+                               * 0 = default = 2.
+                               * 2 = IEEE fp16 in every stage -- the precision the reference runs its backbone at (TensorRT
+                               *     engines built with fp16=True, 7_create_engines.py:10). Same MFMA rate and bytes as bf16,
+                               *     3 more mantissa bits; conversions saturate at +-65504. Closest 16-bit layout to the fp32
+                               *     definition on both weight profiles.
+                               * 1 = bf16 everywhere (the round-2 layout).
+                               * 3 = bf16, with the two 8x8 stages (32 of the 79 blocks) and the 640 -> 1280 convolution in fp16
+                               *     (round 3's default). */
 } isb_hpe_cfg;
 
 int isb_hpe_create(const isb_hpe_cfg* cfg, isb_hpe** out);
@@ -277,13 +279,6 @@ int isb_debug_conv(int32_t device, const uint16_t* h_x, const float* h_w, const 
                    const uint16_t* h_res, const float* h_gate, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
                    int32_t k, int32_t stride, int32_t act, int32_t variant, int32_t iters, uint16_t* h_out,
                    float* ms_per_iter);
-
-/* test / tuning hook: the fused MBConv front half (1x1 expand + BN + SiLU -> depthwise 3x3 + BN + SiLU,
- * plus the squeeze-excite mean) on host tensors; HW = 8 or 16 (one sample per workgroup tile).
- *   h_x bf16 [B,HW,HW,Cin], h_w1 f32 [Cexp,Cin], h_dww f32 [Cexp,3,3]; out bf16 [B,HW,HW,Cexp], pooled f32 [B,Cexp] */
-int isb_debug_expand_dw(int32_t device, const uint16_t* h_x, const float* h_w1, const float* h_scale1, const float* h_shift1,
-                        const float* h_dww, const float* h_dwscale, const float* h_dwshift, int32_t B, int32_t HW, int32_t Cin,
-                        int32_t Cexp, int32_t iters, uint16_t* h_out, float* h_pooled, float* ms_per_iter);
 
 /* test / tuning hook: a whole Fused-MBConv block (3x3 expand + BN + SiLU -> 1x1 project + BN [+ residual]) in ONE
  * launch on host tensors. h_x bf16 [B,H,H,Cin], h_w1 f32 [Cexp,3,3,Cin] (Cexp = 128, 256 or 384), h_w2 f32 [Cout2,Cexp]

@@ -26,14 +26,34 @@ SOURCES = [
     "gemm_f32.hip",
     "ar_kernels.hip",
     "ar_api.cpp",
+    "hpe_kernels.hip",
+    # the convolution family: one translation unit per kernel family (none above ~90 s), the dispatcher that picks a tile per layer
+    "conv_dispatch.hip",
+    "conv_igemm.hip",
+    "conv_gemm1x1.hip",
+    "conv_gemm1x1_gate.hip",
+    "conv_3x3.hip",
+    "conv_fused_mb.hip",
+    "conv_ws.hip",
+    "conv_dw_se.hip",
+    "hpe_api.cpp",
+    "det_kernels.hip",
+    "det_api.cpp",
+    "dist_api.cpp",
+    "rgb_kernels.hip",
+    "rgb_api.cpp",
 ]
 # optional units appear as they are written
-for _extra in ("hpe_kernels.hip", "conv_kernels.hip", "conv_ws.hip", "hpe_api.cpp", "det_kernels.hip", "det_api.cpp", "dist_api.cpp", "rgb_kernels.hip", "rgb_api.cpp"):
+for _extra in ("conv_mb8.hip",):
     if os.path.exists(os.path.join(CSRC, _extra)):
         SOURCES.append(_extra)
 
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result", "-ffp-contract=on"]
+# ISB_BUILD_PROBES=1 python -m isbfsar_amd.build --force: also the tile variants / kernel forms that were measured and NOT selected
+# (EXPERIMENTS.md, tools/): ~130 more instantiations, a 6-minute build. The product build holds what the three networks launch.
+if os.environ.get("ISB_BUILD_PROBES", "0") not in ("", "0"):
+    FLAGS.append("-DISB_BUILD_PROBES")
 
 
 def _hipcc() -> str:
@@ -87,7 +107,7 @@ def wspipe_registers_private(lib_path: str):
                 kernels[cur] = []
         elif cur and line.strip():
             kernels[cur].append(line.split("//")[0])
-    if len(kernels) < 12:       # NK 3/6/7/12 x act / no act / stamps x 1 or 2 waves per SIMD x MFMA shape x operand type
+    if len(kernels) < 10:       # variants 184 (NK 3 / 6 / 7), 185, 186 (NK 12) x bf16 / fp16 operands; probe builds have more
         return f"only {len(kernels)} gemm1x1_wspipe_kernel instantiations found in the code object"
 
     def regs(line, letter):
@@ -146,7 +166,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             print(r.stderr.strip())
 
     if jobs:
-        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+        with ThreadPoolExecutor(max_workers=min(int(os.environ.get("ISB_BUILD_JOBS", "8")), len(jobs))) as ex:
             list(ex.map(run, jobs))
     guard_o = os.path.join(OBJ, "wsreg_guard.o")
     if jobs or force or not os.path.exists(LIB) or not os.path.exists(guard_o):

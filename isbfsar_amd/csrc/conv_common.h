@@ -1,4 +1,4 @@
-// Device helpers shared by the convolution translation units (conv_kernels.hip, conv_ws.hip): operand typedefs, the LDS row
+// Device helpers shared by the convolution translation units (conv_*.hip): operand typedefs, the LDS row
 // layout and its swizzle, activations, the LDS-DMA issue helper, the dynamic LDS symbol.
 #pragma once
 #include <algorithm>
@@ -65,6 +65,9 @@ struct T16 {
     static __device__ __forceinline__ f32x16 mfma32(uint4 a, uint4 b, f32x16 c) {
         if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
         else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {     // fragments held as 8 x 16-bit vectors
+        return mfma32(__builtin_bit_cast(uint4, a), __builtin_bit_cast(uint4, b), c);
     }
     // acc + x.lo * w.lo + x.hi * w.hi in f32 (v_dot2_f32_*: with one half of w zero, an f32 FMA straight from the pair)
     static __device__ __forceinline__ float dot2(uint32_t x, uint32_t w, float acc) {

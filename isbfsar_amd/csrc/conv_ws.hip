@@ -1,6 +1,5 @@
-// The weights-stationary GEMMs of the MBConv expand convolutions (split from conv_kernels.hip: every instantiation is a fully
-// unrolled tile pass, and the two translation units compile side by side). launch_conv_ws is called by launch_conv_igemm
-// for tile variants 181 - 188.
+// The weights-stationary GEMMs of the MBConv expand convolutions (every instantiation is a fully unrolled tile pass).
+// launch_conv_ws is called by launch_conv_igemm for tile variants 184 - 186 (181 - 183, 187, 188: -DISB_BUILD_PROBES builds).
 #include "conv_common.h"
 
 namespace isb {
@@ -40,6 +39,7 @@ constexpr int ws_lds_bytes(int nk, int nw, int tmb) { return 2 * nk * (32 * tmb 
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+#ifdef ISB_BUILD_PROBES
 // Two shapes are instantiated:
 //   NW = 6, TMB = 3 (variant 181): 96 x 192 tiles, six waves on four SIMDs, the SIMD partners (waves w and w + 4) run
 //                   multiply / finish in opposite order;
@@ -220,6 +220,8 @@ __global__ __launch_bounds__(64 * NW, NW == 6 ? 2 : 1) void gemm1x1_wsreg_kernel
         }
     }
 }
+
+#endif  // ISB_BUILD_PROBES
 
 // -------------------------------------------------------------------------------------------
 // Weights-stationary GEMM, one wave per SIMD, epilogue software-pipelined into the next tile's MFMA stream (variant 183).
@@ -556,15 +558,16 @@ __global__ __launch_bounds__(256 * NWM, WPC) void gemm1x1_wspipe_kernel(ConvArgs
 
 int launch_conv_ws(const ConvArgs& a, ConvArgs& aa, int v, hipStream_t st) {
     switch (v) {
+#ifdef ISB_BUILD_PROBES
         case 181:                                            // weights-stationary persistent GEMM: 96 x 192 tiles, 6 waves
         case 182: {                                          //                                  or 128 x 128 tiles, 4 waves (one per SIMD)
             const int nw = v == 181 ? 6 : 4, tmb = v == 181 ? 3 : 4;
             const int bm = 32 * tmb, bn = 32 * nw;
             const int n_mt = cdiv(a.M, bm), nsl = cdiv(a.Cout, bn);
-            if (a.gate || a.res || a.out_f32 || a.act > 1 || a.KH != 1 || a.stride != 1 || a.pad != 0 || a.splits > 1 || a.Cout % 32 != 0 ||
+            if (a.f16 || a.gate || a.res || a.out_f32 || a.act > 1 || a.KH != 1 || a.stride != 1 || a.pad != 0 || a.splits > 1 || a.Cout % 32 != 0 ||
                 (v == 181 && a.Cout % bn != 0) || nsl > 128 ||
                 (a.Cin != 96 && a.Cin != 192 && a.Cin != 224 && a.Cin != 384) || (size_t)a.M * a.Cin * 2 >= 0xffffffffull) {
-                set_error("conv_igemm: variants 181 / 182 are un-gated 1x1 GEMMs without residual, Cin 96/192/224/384 (181: Cout %% 192 == 0)");
+                set_error("conv_igemm: variants 181 / 182 are un-gated bf16 1x1 GEMMs without residual, Cin 96/192/224/384 (181: Cout %% 192 == 0)");
                 return ISB_ERR_INVALID;
             }
             // one workgroup per CU (256, a multiple of 8 for the XCD decode); Q tile sequences of nsl slices each
@@ -572,8 +575,6 @@ int launch_conv_ws(const ConvArgs& a, ConvArgs& aa, int v, hipStream_t st) {
             const int Q = std::max(1, std::min(n_wg / nsl, n_mt));
             aa.grid_n = nsl;
             aa.grid_m = Q;
-            static const int probe = [] { const char* e = getenv("ISB_WS_PROBE"); return e ? atoi(e) : 0; }();
-            aa.probe = a.probe | (probe & ~3);
             const dim3 g(n_wg);
             // at least 84 KiB so that two of these never share a CU (the phase pairing assumes one workgroup per CU)
 #define ISB_WS(NK, NW, TMB)                                                                                     \
@@ -602,82 +603,79 @@ int launch_conv_ws(const ConvArgs& a, ConvArgs& aa, int v, hipStream_t st) {
 #undef ISB_WS
             break;
         }
-        case 183: case 184: case 185: case 186: case 187: case 188: {            // weights-stationary, epilogue pipelined into the MFMA stream:
-            // 183: 128-row tiles, one wave per SIMD; 184: 64-row tiles, two workgroups per CU (K <= 224); 185: 64-row tiles, one
-            // workgroup of 4 waves per CU, K = 384 (96 weight registers per lane); 186: the same tiles, 8 waves (2 x 32 rows)
+        case 183: case 187: case 188:
+#endif
+        case 184: case 185: case 186: {            // weights-stationary, epilogue pipelined into the MFMA stream:
+            // 184: 64-row tiles, two workgroups per CU (K <= 224); 185: 64-row tiles, one workgroup of 4 waves per CU, K = 384 (96
+            // weight registers per lane); 186: the same tiles, 8 waves (2 x 32 rows). Probe builds: 183 = 128-row tiles, one wave
+            // per SIMD; 187 / 188 = 184 / 186 on the 16x16x32 MFMA
             const int bm = v == 183 ? 128 : 64;
             const int nsl = cdiv(a.Cout, 128), n_mt = cdiv(a.M, bm);
-            // 187 / 188: 184 / 186 on the 16x16x32 MFMA
             const bool k_ok = (v == 185 || v == 186 || v == 188) ? a.Cin == 384 : (a.Cin == 96 || a.Cin == 192 || a.Cin == 224);
             if (a.gate || a.res || a.out_f32 || a.act > 1 || a.KH != 1 || a.stride != 1 || a.pad != 0 || a.splits > 1 || a.Cout % 32 != 0 ||
                 nsl > 128 || !k_ok || (size_t)a.M * a.Cin * 2 >= 0xffffffffull) {
-                set_error("conv_igemm: variants 183 / 184 (Cin 96/192/224) and 185 / 186 (Cin 384) are un-gated 1x1 GEMMs without residual");
+                set_error("conv_igemm: variants 184 (Cin 96/192/224) and 185 / 186 (Cin 384) are un-gated 1x1 GEMMs without residual");
                 return ISB_ERR_INVALID;
             }
             const int n_wg = (v == 184 || v == 187) ? 512 : 256;
             aa.grid_n = nsl;
             aa.grid_m = std::max(1, std::min(n_wg / nsl, n_mt));
             const dim3 g(n_wg);
-#define ISB_WSP_GO(NK, ACT, STAMPS, TMB, WPC, NWM) ISB_WSP_GO2(NK, ACT, STAMPS, TMB, WPC, NWM, false)
-#define ISB_WSP_GO2(NK, ACT, STAMPS, TMB, WPC, NWM, M16_)                                                              \
+#define ISB_WSP_GO(NK, ACT, STAMPS, TMB, WPC, NWM, M16_, F16_)                                                  \
     do {                                                                                                        \
         const int bytes = std::max(2 * NK * (32 * TMB * NWM) * 64 + 4 * NWM * 2 * WS_STAGE, WPC == 1 ? 84 * 1024 : 0); \
         static bool attr_set = false;                                                                           \
         if (!attr_set) {                                                                                        \
-            ISB_HIP(hipFuncSetAttribute((const void*)gemm1x1_wspipe_kernel<NK, ACT, STAMPS, TMB, WPC, NWM, M16_>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); \
+            ISB_HIP(hipFuncSetAttribute((const void*)gemm1x1_wspipe_kernel<NK, ACT, STAMPS, TMB, WPC, NWM, M16_, F16_>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); \
             attr_set = true;                                                                                    \
         }                                                                                                       \
-        hipLaunchKernelGGL((gemm1x1_wspipe_kernel<NK, ACT, STAMPS, TMB, WPC, NWM, M16_>), g, dim3(256 * NWM), bytes, st, aa); \
+        hipLaunchKernelGGL((gemm1x1_wspipe_kernel<NK, ACT, STAMPS, TMB, WPC, NWM, M16_, F16_>), g, dim3(256 * NWM), bytes, st, aa); \
     } while (0)
+            // every instantiation is a fully unrolled tile pass: the product build holds the forms the network selects (SiLU
+            // epilogue, both 16-bit operand types); no-activation / stamped / 16x16x32 / 128-row forms are probe builds
+#ifdef ISB_BUILD_PROBES
 #define ISB_WSP(NK, TMB, WPC, NWM)                                                                              \
     do {                                                                                                        \
-        if (a.probe & 2) ISB_WSP_GO(NK, true, true, TMB, WPC, NWM);                                             \
-        else if (a.act) ISB_WSP_GO(NK, true, false, TMB, WPC, NWM);                                             \
-        else ISB_WSP_GO(NK, false, false, TMB, WPC, NWM);                                                       \
+        if (a.f16 && a.act && !(a.probe & 2)) ISB_WSP_GO(NK, true, false, TMB, WPC, NWM, false, true);          \
+        else if (a.f16) { set_error("conv_igemm: fp16 weights-stationary forms have the SiLU epilogue, no stamps"); return ISB_ERR_INVALID; } \
+        else if (a.probe & 2) ISB_WSP_GO(NK, true, true, TMB, WPC, NWM, false, false);                          \
+        else if (a.act) ISB_WSP_GO(NK, true, false, TMB, WPC, NWM, false, false);                               \
+        else ISB_WSP_GO(NK, false, false, TMB, WPC, NWM, false, false);                                         \
     } while (0)
-            // the forms the network does not select (183, 185 without activation, 187 / 188) exist with the SiLU epilogue only:
-            // every instantiation is a fully unrolled tile pass
-#define ISB_WSP_ACT(NK, TMB, WPC, NWM, M16_)                                                                    \
+#else
+#define ISB_WSP(NK, TMB, WPC, NWM)                                                                              \
     do {                                                                                                        \
         if (!a.act || (a.probe & 2)) {                                                                          \
-            set_error("conv_igemm: variant %d is built with the SiLU epilogue and without stamps only", v);     \
+            set_error("conv_igemm: variant %d without SiLU / with stamps needs a -DISB_BUILD_PROBES build", v); \
             return ISB_ERR_INVALID;                                                                             \
         }                                                                                                       \
-        ISB_WSP_GO2(NK, true, false, TMB, WPC, NWM, M16_);                                                      \
+        if (a.f16) ISB_WSP_GO(NK, true, false, TMB, WPC, NWM, false, true);                                     \
+        else ISB_WSP_GO(NK, true, false, TMB, WPC, NWM, false, false);                                          \
     } while (0)
-            if (a.f16) {                                     // fp16 operands: the K = 384 forms with the SiLU epilogue (the 8x8 stages' expands)
-                if ((v != 185 && v != 186) || !a.act || (a.probe & 2)) {
-                    set_error("conv_igemm: fp16 operands on the weights-stationary kernels: variants 185 / 186 with SiLU only");
-                    return ISB_ERR_INVALID;
-                }
-#define ISB_WSP_F16(NK, TMB, WPC, NWM)                                                                          \
+#endif
+            if (v == 186) ISB_WSP(12, 1, 1, 2);
+            else if (v == 185) ISB_WSP(12, 2, 1, 1);
+            else if (v == 184) { if (a.Cin == 96) ISB_WSP(3, 2, 2, 1); else if (a.Cin == 192) ISB_WSP(6, 2, 2, 1); else ISB_WSP(7, 2, 2, 1); }
+#ifdef ISB_BUILD_PROBES
+#define ISB_WSP_ACT(NK, TMB, WPC, NWM, M16_)                                                                    \
     do {                                                                                                        \
-        const int bytes = std::max(2 * NK * (32 * TMB * NWM) * 64 + 4 * NWM * 2 * WS_STAGE, WPC == 1 ? 84 * 1024 : 0); \
-        static bool attr_set = false;                                                                           \
-        if (!attr_set) {                                                                                        \
-            ISB_HIP(hipFuncSetAttribute((const void*)gemm1x1_wspipe_kernel<NK, true, false, TMB, WPC, NWM, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); \
-            attr_set = true;                                                                                    \
+        if (!a.act || (a.probe & 2) || a.f16) {                                                                 \
+            set_error("conv_igemm: variant %d is built in bf16 with the SiLU epilogue and without stamps only", v); \
+            return ISB_ERR_INVALID;                                                                             \
         }                                                                                                       \
-        hipLaunchKernelGGL((gemm1x1_wspipe_kernel<NK, true, false, TMB, WPC, NWM, false, true>), g, dim3(256 * NWM), bytes, st, aa); \
+        ISB_WSP_GO(NK, true, false, TMB, WPC, NWM, M16_, false);                                                \
     } while (0)
-                if (v == 186) ISB_WSP_F16(12, 1, 1, 2); else ISB_WSP_F16(12, 2, 1, 1);
-#undef ISB_WSP_F16
-            }
             else if (v == 188) ISB_WSP_ACT(12, 1, 1, 2, true);
             else if (v == 187) { if (a.Cin == 96) ISB_WSP_ACT(3, 2, 2, 1, true); else if (a.Cin == 192) ISB_WSP_ACT(6, 2, 2, 1, true); else ISB_WSP_ACT(7, 2, 2, 1, true); }
-            else if (v == 186) ISB_WSP(12, 1, 1, 2);
-            else if (v == 185) ISB_WSP_ACT(12, 2, 1, 1, false);
             else if (v == 183) { if (a.Cin == 96) ISB_WSP_ACT(3, 4, 1, 1, false); else if (a.Cin == 192) ISB_WSP_ACT(6, 4, 1, 1, false); else ISB_WSP_ACT(7, 4, 1, 1, false); }
-            else { if (a.Cin == 96) ISB_WSP(3, 2, 2, 1); else if (a.Cin == 192) ISB_WSP(6, 2, 2, 1); else ISB_WSP(7, 2, 2, 1); }
 #undef ISB_WSP_ACT
-#undef ISB_WSP16
+#endif
 #undef ISB_WSP
-#undef ISB_WSP_GO2
 #undef ISB_WSP_GO
             break;
         }
         default:
-            set_error("conv_ws: unknown variant %d", v);
+            set_error("conv_ws: tile variant %d is not in this build (weights-stationary: 184, 185, 186)", v);
             return ISB_ERR_INVALID;
     }
     return ISB_OK;

@@ -66,18 +66,13 @@ struct isb_hpe {
     isb_hpe_cfg cfg{};
     hipStream_t own_stream = nullptr;
     bool weights = false, jointmap = false;
-    bool dw_fc1_batched = false;  // ISB_DW_FC1=1: batches too compute FC1 inside the depthwise launch (one SE launch per block)
-    bool fuse_se = true;          // single-frame split-K projections compute their SE gate in the GEMM; ISB_FUSE_SE=0 disables
-    bool split_k = true;          // split-K for the projections of single-frame calls; ISB_SPLIT_K=0 disables
-    bool fuse_block = true;       // Fused-MBConv blocks (3x3 expand + 1x1 project) in one launch; ISB_FUSE_BLOCK=0 disables
-    int fuse_block_max_cexp = 256;   // 384 expanded channels (E tile 96 KiB) measured 10 % slower than two launches
-    // Storage type of the last stages: stages >= f16_from (index into kStages; default 5 = the two 8x8 stages, 32 of the 79
-    // blocks, 31 % of the FLOPs) and the 640 -> 1280 convolution keep activations AND weights in IEEE fp16 instead of bf16 -- same
-    // MFMA rate, 3 more mantissa bits where the per-stage error budget (oracle/error_budget.py) puts the
-    // distance to the fp32 definition. isb_hpe_cfg.precision = 1 or ISB_HPE_F16=0 -> bf16 everywhere (f16_from = 7).
-    int f16_from = 5;
-    bool fuse_front = false;      // MBConv expand + depthwise + pool in one kernel (ISB_FUSE_FRONT=1): measured equal to
-                                  // the two-launch form on MI355X (E stays in the 256 MiB Infinity Cache), so off by default
+    bool fuse_se = true;          // single-frame split-K projections compute their SE gate in the GEMM; ISB_FUSE_SE=0 disables (tests)
+    // 16-bit storage type per stage: stages >= f16_from (index into kStages) and the 640 -> 1280 convolution keep activations AND
+    // weights in IEEE fp16 instead of bf16 -- same MFMA rate, 3 more mantissa bits (per-stage error budget: DESIGN.md section 4,
+    // oracle/error_budget.py). isb_hpe_cfg.precision: 0 (default) / 2 = fp16 everywhere, what the reference's TensorRT engines
+    // run (7_create_engines.py:10; f16_from = 0, the stem stores fp16 too); 3 = bf16 with fp16 in the two 8x8 stages (round 3's
+    // layout; f16_from = 5); 1 = bf16 everywhere (f16_from = 7)
+    int f16_from = 0;
     int n_out = 0;
     double K[9] = {0};
     // weights
@@ -227,7 +222,7 @@ int conv(isb_hpe* h, hipStream_t st, const ConvW& cw, const void* in, int B, int
     // each walking up to 120 k-tiles in series. Split K across workgroups so that the launch covers more of the chip.
     // Only for single-frame calls, and with a split count that depends on the layer alone: batches of two or more
     // frames keep one summation order whatever their size, so any sharding of a batch stays bit-identical.
-    if (lane && h->split_k && B == 1 && cw.k == 1 && stride == 1 && !out_f32 && a.Cout >= 64 &&
+    if (lane && B == 1 && cw.k == 1 && stride == 1 && !out_f32 && a.Cout >= 64 &&
         (!gate || (a.OH * a.OW) % 64 == 0)) {
         const int s = std::min(a.Cin / 32 / 6, 16);
         if (s > 1 && (size_t)s * a.M * a.Cout * 4 <= kSplitKBytes) { a.splits = s; a.part = lane->part.as<float>(); }
@@ -275,7 +270,7 @@ int gemm(hipStream_t st, const float* A, int lda, const float* W, int ldw, const
 int backbone_begin(isb_hpe* h, Lane& L, hipStream_t st, const float* crops, int B) {
     StemArgs sa{};
     sa.in = crops; sa.w = h->stem_w.as<float>(); sa.bias = h->stem_b.as<float>(); sa.out = L.bufX.as<uint16_t>();
-    sa.B = B; sa.H = 256; sa.W = 256;
+    sa.B = B; sa.H = 256; sa.W = 256; sa.out_f16 = h->f16_from <= 0 ? 1 : 0;
     ISB_TRY(launch_stem(sa, st));
     L.X = L.bufX.p;
     L.Y = L.bufY.p;
@@ -291,7 +286,7 @@ int backbone_blocks(isb_hpe* h, Lane& L, hipStream_t st, int B, size_t i0, size_
         if (b.fused) {
             if (b.cexp == b.cin) {
                 ISB_TRY(conv(h, st, b.expand, X, B, b.in_hw, b.in_hw, b.stride, true, res, nullptr, Y, false));
-            } else if (h->fuse_block && b.cexp <= h->fuse_block_max_cexp && b.cout <= 128) {
+            } else if (b.cexp <= 256 && b.cout <= 128) {      // (384 expanded channels measured slower than two launches)
                 // whole Fused-MBConv block in one launch: the expanded tensor never leaves the chip (bit-identical to
                 // the two-launch path below; -26...32 % on the 64-channel stage, see launch_fused_mb)
                 ConvArgs a{};
@@ -299,7 +294,7 @@ int backbone_blocks(isb_hpe* h, Lane& L, hipStream_t st, int B, size_t i0, size_
                 a.res = (const uint16_t*)res; a.out = Y;
                 a.B = B; a.H = b.in_hw; a.W = b.in_hw; a.Cin = b.cin; a.Cout = b.cexp; a.KH = 3; a.KW = 3; a.stride = b.stride;
                 a.OH = b.out_hw; a.OW = b.out_hw; a.pad = b.stride == 1 ? 1 : 0; a.M = B * b.out_hw * b.out_hw; a.K = 9 * b.cin;
-                a.act = 1;
+                a.act = 1; a.f16 = b.f16 ? 1 : 0;
                 a.w2 = b.project.w16.as<uint16_t>(); a.bias2 = b.project.bias.as<float>(); a.Cout2 = b.cout;
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (h->prof) {
@@ -319,28 +314,7 @@ int backbone_blocks(isb_hpe* h, Lane& L, hipStream_t st, int B, size_t i0, size_
             }
         } else {
             int se_parts = 0;
-            if (b.stride == 1 && h->fuse_front && !b.f16) {
-                // expand 1x1 + dw 3x3 + SE pool in one launch: the expanded tensor never leaves the chip
-                ConvArgs a{};
-                a.in = (const uint16_t*)X; a.w = b.expand.w16.as<uint16_t>(); a.bias = b.expand.bias.as<float>();
-                a.B = B; a.H = b.in_hw; a.W = b.in_hw; a.Cin = b.cin; a.Cout = b.cexp; a.KH = 1; a.KW = 1; a.stride = 1;
-                a.OH = b.in_hw; a.OW = b.in_hw; a.pad = 0; a.M = B * b.in_hw * b.in_hw; a.K = b.cin; a.act = 1;
-                a.zeros = h->zeros.as<uint16_t>();
-                a.dw_w = b.dw_w.as<float>(); a.dw_bias = b.dw_b.as<float>(); a.dw_out = L.bufD.as<uint16_t>();
-                a.pooled = L.pooled.as<float>();
-                hipEvent_t e0 = nullptr, e1 = nullptr;
-                if (h->prof) {
-                    ISB_HIP(hipEventCreate(&e0));
-                    ISB_HIP(hipEventCreate(&e1));
-                    ISB_HIP(hipEventRecord(e0, st));
-                }
-                ISB_TRY(launch_conv_expand_dw(a, st));
-                if (h->prof) {
-                    ISB_HIP(hipEventRecord(e1, st));
-                    h->prof_ev.emplace_back(e0, e1);
-                    h->prof_launches += 1;
-                }
-            } else {
+            {
                 ISB_TRY(conv(h, st, b.expand, X, B, b.in_hw, b.in_hw, 1, true, nullptr, nullptr, L.bufE.p, false));
                 DwArgs d{};
                 d.in = L.bufE.as<uint16_t>(); d.w = b.dw_w16.as<uint16_t>(); d.bias = b.dw_b.as<float>(); d.out = L.bufD.as<uint16_t>();
@@ -348,7 +322,7 @@ int backbone_blocks(isb_hpe* h, Lane& L, hipStream_t st, int B, size_t i0, size_
                 d.pad = b.stride == 1 ? 1 : 0;
                 d.in_f16 = b.f16_in ? 1 : 0; d.out_f16 = b.f16 ? 1 : 0;
                 d.pooled = L.pooled.as<float>();
-                if ((B == 1 && h->split_k) || h->dw_fc1_batched) {   // FC1 of the squeeze-excite rides in the depthwise launch
+                if (B == 1) {   // one frame: FC1 of the squeeze-excite rides in the depthwise launch (batches: measured slower)
                     d.se_w1 = b.se_w1.as<float>(); d.se_part = L.semid.as<float>(); d.cse = b.cse;
                     se_parts = dw_slabs(d);
                 }
@@ -369,7 +343,7 @@ int backbone_blocks(isb_hpe* h, Lane& L, hipStream_t st, int B, size_t i0, size_
 int backbone_end(isb_hpe* h, Lane& L, hipStream_t st, int B) {
     void* X = L.X;
     ISB_TRY(conv(h, st, h->headconv, X, B, 8, 8, 1, true, nullptr, nullptr, L.feat.p, true));
-    if (B == 1 && h->split_k) {
+    if (B == 1) {
         // one frame: 64 rows x 288 outputs are 5 tiles walking 40 k-tiles each -> 8 K-splits + an in-order reduction
         constexpr int kHeadSplits = 8;
         GemmF32Args g{};
@@ -429,8 +403,8 @@ extern "C" int isb_hpe_create(const isb_hpe_cfg* cfg, isb_hpe** out) {
     ISB_REQUIRE(cfg->width >= 16 && cfg->height >= 16 && cfg->width <= 8192 && cfg->height <= 8192, ISB_ERR_INVALID,
                 "frame size %dx%d unsupported", cfg->width, cfg->height);
     ISB_REQUIRE(cfg->fx > 0 && cfg->fy > 0, ISB_ERR_INVALID, "focal lengths must be positive");
-    ISB_REQUIRE(cfg->precision == 0 || cfg->precision == 1, ISB_ERR_INVALID,
-                "isb_hpe_cfg.precision %d: 0 (bf16, fp16 in the two 8x8 stages) or 1 (bf16 everywhere)", cfg->precision);
+    ISB_REQUIRE(cfg->precision >= 0 && cfg->precision <= 3, ISB_ERR_INVALID,
+                "isb_hpe_cfg.precision %d: 0 / 2 (fp16 everywhere), 1 (bf16 everywhere) or 3 (bf16, fp16 in the two 8x8 stages)", cfg->precision);
     int ndev = 0;
     ISB_HIP(hipGetDeviceCount(&ndev));
     ISB_REQUIRE(cfg->device >= 0 && cfg->device < ndev, ISB_ERR_INVALID, "device %d not in [0,%d)", cfg->device, ndev);
@@ -447,14 +421,8 @@ extern "C" int isb_hpe_create(const isb_hpe_cfg* cfg, isb_hpe** out) {
     ISB_HIP(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     ISB_TRY(h->zeros.alloc(256));
     ISB_HIP(hipMemset(h->zeros.p, 0, 256));
-    h->fuse_front = getenv("ISB_FUSE_FRONT") != nullptr;
-    if (const char* e = getenv("ISB_FUSE_BLOCK")) h->fuse_block = atoi(e) != 0;
-    if (const char* e = getenv("ISB_SPLIT_K")) h->split_k = atoi(e) != 0;
     if (const char* e = getenv("ISB_FUSE_SE")) h->fuse_se = atoi(e) != 0;
-    if (const char* e = getenv("ISB_DW_FC1")) h->dw_fc1_batched = atoi(e) != 0;
-    if (const char* e = getenv("ISB_FUSE_BLOCK_CEXP")) h->fuse_block_max_cexp = atoi(e);
-    if (cfg->precision == 1) h->f16_from = 7;
-    if (const char* e = getenv("ISB_HPE_F16")) h->f16_from = atoi(e) == 0 ? 7 : 5;
+    h->f16_from = cfg->precision == 1 ? 7 : (cfg->precision == 3 ? 5 : 0);
     if (const char* e = getenv("ISB_HPE_ROI")) h->roi_mode = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("ISB_HPE_LANES")) h->n_lanes = std::max(1, std::min(kMaxLanes, atoi(e)));
     ISB_HIP(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
@@ -530,7 +498,7 @@ extern "C" int isb_hpe_load_weights(isb_hpe* h, const void* blob, size_t nbytes)
         for (int r = 0; r < s.repeats; ++r, ++idx) {
             std::unique_ptr<BlockW> b(new BlockW());
             b->f16_in = stream_f16;
-            b->f16 = !s.fused && si >= h->f16_from;
+            b->f16 = si >= h->f16_from;
             stream_f16 = b->f16;
             b->fused = s.fused;
             b->cin = r == 0 ? s.cin : s.cout;
@@ -545,10 +513,10 @@ extern "C" int isb_hpe_load_weights(isb_hpe* h, const void* blob, size_t nbytes)
             const std::string p = "bbone.b" + std::to_string(idx);
             if (b->fused) {
                 if (b->cexp == b->cin) {
-                    ISB_TRY(upload_conv(m, p + ".expand", b->cout, 3, b->cin, b->expand, st));
+                    ISB_TRY(upload_conv(m, p + ".expand", b->cout, 3, b->cin, b->expand, st, b->f16));
                 } else {
-                    ISB_TRY(upload_conv(m, p + ".expand", b->cexp, 3, b->cin, b->expand, st));
-                    ISB_TRY(upload_conv(m, p + ".project", b->cout, 1, b->cexp, b->project, st));
+                    ISB_TRY(upload_conv(m, p + ".expand", b->cexp, 3, b->cin, b->expand, st, b->f16));
+                    ISB_TRY(upload_conv(m, p + ".project", b->cout, 1, b->cexp, b->project, st, b->f16));
                 }
             } else {
                 ISB_TRY(upload_conv(m, p + ".expand", b->cexp, 1, b->cin, b->expand, st, b->f16_in));
@@ -1253,6 +1221,8 @@ extern "C" int isb_debug_fused_mb(int32_t device, const uint16_t* x, const float
                                   uint16_t* out, float* ms_per_iter) {
     return isb::guard([&]() -> int {
         ISB_REQUIRE(x && w1 && scale1 && shift1 && w2 && scale2 && shift2 && out && ms_per_iter, ISB_ERR_INVALID, "null argument");
+        const int f16 = (stride & 0x100) ? 1 : 0;      // x / res / out hold fp16 bits and the weights are rounded to fp16
+        stride &= 0xff;
         ISB_REQUIRE((stride == 1 || stride == 2) && iters >= 1 && B >= 1, ISB_ERR_INVALID, "bad parameters");
         ISB_HIP(hipSetDevice(device));
         const int OH = H / stride;
@@ -1270,9 +1240,10 @@ extern "C" int isb_debug_fused_mb(int32_t device, const uint16_t* x, const float
         ISB_TRY(dw2.alloc(nw2 * 2));
         ISB_TRY(dout.alloc(nout * 2));
         if (res) ISB_TRY(upload(dres, res, nout * 2));
-        ISB_TRY(launch_f32_to_bf16_rows(dw1f.as<float>(), ds1.as<float>(), dw1.as<uint16_t>(), Cexp, (size_t)9 * Cin, nullptr));
-        ISB_TRY(launch_f32_to_bf16_rows(dw2f.as<float>(), ds2.as<float>(), dw2.as<uint16_t>(), Cout2, (size_t)Cexp, nullptr));
+        ISB_TRY(launch_f32_to_bf16_rows(dw1f.as<float>(), ds1.as<float>(), dw1.as<uint16_t>(), Cexp, (size_t)9 * Cin, nullptr, f16));
+        ISB_TRY(launch_f32_to_bf16_rows(dw2f.as<float>(), ds2.as<float>(), dw2.as<uint16_t>(), Cout2, (size_t)Cexp, nullptr, f16));
         ConvArgs a{};
+        a.f16 = f16;
         a.in = dx.as<uint16_t>(); a.w = dw1.as<uint16_t>(); a.bias = db1.as<float>();
         a.res = res ? dres.as<uint16_t>() : nullptr; a.out = dout.p;
         a.B = B; a.H = H; a.W = H; a.Cin = Cin; a.Cout = Cexp; a.KH = 3; a.KW = 3; a.stride = stride; a.OH = OH; a.OW = OH;
@@ -1432,53 +1403,3 @@ extern "C" int isb_debug_dwconv_fc1(int32_t device, const uint16_t* x, const flo
     return debug_dwconv_impl(device, x, w, scale, shift, B, H, C, stride, iters, out, pooled, ms_per_iter, se_w1, cse, se_part, n_parts);
 }
 
-// test / tuning hook: fused MBConv front half (1x1 expand + SiLU + depthwise 3x3 + SiLU + SE pool) on host tensors
-extern "C" int isb_debug_expand_dw(int32_t device, const uint16_t* x, const float* w1, const float* scale1, const float* shift1,
-                                   const float* dww, const float* dwscale, const float* dwshift, int32_t B, int32_t HW,
-                                   int32_t Cin, int32_t Cexp, int32_t iters, uint16_t* out, float* pooled, float* ms_per_iter) {
-    return isb::guard([&]() -> int {
-        ISB_REQUIRE(x && w1 && scale1 && shift1 && dww && dwscale && dwshift && out && pooled && ms_per_iter, ISB_ERR_INVALID,
-                    "null argument");
-        ISB_REQUIRE((HW == 8 || HW == 16) && iters >= 1, ISB_ERR_INVALID, "HW must be 8 or 16");
-        ISB_HIP(hipSetDevice(device));
-        const size_t nin = (size_t)B * HW * HW * Cin, nout = (size_t)B * HW * HW * Cexp, nw = (size_t)Cexp * Cin;
-        DevBuf dx, dwf, dsc, dsh, dw16, ddw, ddb, dout, dpool, dzero;
-        ISB_TRY(dzero.alloc(256));
-        ISB_HIP(hipMemset(dzero.p, 0, 256));
-        ISB_TRY(upload(dx, x, nin * 2));
-        ISB_TRY(upload(dwf, w1, nw * 4));
-        ISB_TRY(upload(dsc, scale1, (size_t)Cexp * 4));
-        ISB_TRY(upload(dsh, shift1, (size_t)Cexp * 4));
-        ISB_TRY(dw16.alloc(nw * 2));
-        ISB_TRY(launch_f32_to_bf16_rows(dwf.as<float>(), dsc.as<float>(), dw16.as<uint16_t>(), Cexp, (size_t)Cin, nullptr));
-        std::vector<float> wt((size_t)9 * Cexp);
-        for (int c = 0; c < Cexp; ++c)
-            for (int t = 0; t < 9; ++t) wt[(size_t)t * Cexp + c] = bf16_to_float(bf16_rne(dww[(size_t)c * 9 + t] * dwscale[c]));
-        ISB_TRY(upload(ddw, wt.data(), wt.size() * 4));
-        ISB_TRY(upload(ddb, dwshift, (size_t)Cexp * 4));
-        ISB_TRY(dout.alloc(nout * 2));
-        ISB_TRY(dpool.alloc((size_t)B * Cexp * 4));
-        ConvArgs a{};
-        a.in = dx.as<uint16_t>(); a.w = dw16.as<uint16_t>(); a.bias = dsh.as<float>();
-        a.B = B; a.H = HW; a.W = HW; a.Cin = Cin; a.Cout = Cexp; a.KH = 1; a.KW = 1; a.stride = 1; a.OH = HW; a.OW = HW;
-        a.pad = 0; a.M = B * HW * HW; a.K = Cin; a.act = 1; a.zeros = dzero.as<uint16_t>();
-        a.dw_w = ddw.as<float>(); a.dw_bias = ddb.as<float>(); a.dw_out = dout.as<uint16_t>(); a.pooled = dpool.as<float>();
-        ISB_TRY(launch_conv_expand_dw(a, nullptr));
-        ISB_HIP(hipDeviceSynchronize());
-        hipEvent_t e0, e1;
-        ISB_HIP(hipEventCreate(&e0));
-        ISB_HIP(hipEventCreate(&e1));
-        ISB_HIP(hipEventRecord(e0, nullptr));
-        for (int i = 0; i < iters; ++i) ISB_TRY(launch_conv_expand_dw(a, nullptr));
-        ISB_HIP(hipEventRecord(e1, nullptr));
-        ISB_HIP(hipEventSynchronize(e1));
-        float ms = 0.f;
-        ISB_HIP(hipEventElapsedTime(&ms, e0, e1));
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-        *ms_per_iter = ms / iters;
-        ISB_HIP(hipMemcpy(out, dout.p, nout * 2, hipMemcpyDeviceToHost));
-        ISB_HIP(hipMemcpy(pooled, dpool.p, (size_t)B * Cexp * 4, hipMemcpyDeviceToHost));
-        return ISB_OK;
-    });
-}

@@ -216,8 +216,9 @@ struct StemArgs {
     const float* in;        // f32 [B,H,W,3]
     const float* w;         // f32 [32][27], BN scale folded
     const float* bias;      // [32]
-    uint16_t* out;          // bf16 [B,H/2,W/2,32]
+    uint16_t* out;          // bf16 (fp16 when out_f16) [B,H/2,W/2,32]
     int B, H, W;
+    int out_f16;
 };
 int launch_stem(const StemArgs& a, hipStream_t st);
 // out[r][c] = T(in[r][c] * row_scale[r]), T = bf16 or (f16 != 0) fp16, round to nearest even

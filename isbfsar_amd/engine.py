@@ -31,7 +31,7 @@ class ArEngine:
     (reference modules/ar/utils/model.py:291-328) for B windows sharing one support set."""
 
     def __init__(self, seq_len: int, n_joints: int, way_max: int, device: int = 0,
-                 precision: Union[int, str] = "bf16", max_batch: int = 1024, input_type: str = "skeleton"):
+                 precision: Union[int, str] = "f16", max_batch: int = 1024, input_type: str = "skeleton"):
         """input_type (TRXConfig.input_type): "skeleton" (features = MLP(pose), 256 wide) or "hybrid" (features =
         [PostResNet(ResNet-50 trunk) | MLP(pose)], 512 wide; set_support / infer then also take trunk features
         [.., L, 2048], e.g. from RgbEngine)."""

@@ -12,7 +12,7 @@ from .weights import pack_blob
 
 
 
-PRECISIONS = {"bf16_f16tail": 0, "bf16": 1}      # isb_hpe_cfg.precision
+PRECISIONS = {"f16": 2, "bf16": 1, "bf16_f16tail": 3}      # isb_hpe_cfg.precision (0 = the library's default = "f16")
 
 
 def _ptr(a: Optional[np.ndarray]):
@@ -25,9 +25,11 @@ class HpeEngine:
 
     def __init__(self, fx=384.025146484375, fy=384.025146484375, ppx=319.09661865234375,
                  ppy=237.75723266601562, width=640, height=480, device: int = 0, max_batch: int = 64,
-                 precision: str = "bf16_f16tail"):
-        """precision: "bf16_f16tail" (default: bf16, with the two 8x8 stages and the 640 -> 1280 convolution in fp16 --
-        absolute pose within 1e-3 of the fp32 definition) or "bf16" (bf16 everywhere)."""
+                 precision: str = "f16"):
+        """precision (16-bit storage of the backbone's weights and activations, f32 accumulate): "f16" (default: IEEE fp16 in
+        every stage -- what the reference's TensorRT engines run, 7_create_engines.py:10, and the closest 16-bit layout to the
+        fp32 definition), "bf16" (bf16 everywhere) or "bf16_f16tail" (round 3's layout: bf16 with the two
+        8x8 stages and the 640 -> 1280 convolution in fp16)."""
         if precision not in PRECISIONS:
             raise ValueError(f"precision {precision!r} not in {sorted(PRECISIONS)}")
         self.width, self.height, self.device, self.max_batch = width, height, device, max_batch
@@ -251,9 +253,9 @@ def conv_debug(x_bf16, w, scale, shift, k, stride, act, res_bf16=None, gate=None
     return out, ms.value
 
 
-def fused_mb_debug(x_bf16, w1, scale1, shift1, w2, scale2, shift2, res_bf16=None, stride=1, iters=1, device=0):
+def fused_mb_debug(x_bf16, w1, scale1, shift1, w2, scale2, shift2, res_bf16=None, stride=1, iters=1, device=0, f16=False):
     """A whole Fused-MBConv block through isb_debug_fused_mb. x_bf16 uint16 [B,H,H,Cin], w1 f32 [Cexp,3,3,Cin],
-    w2 f32 [Cout2,Cexp]. Returns (out uint16 [B,H/stride,H/stride,Cout2], ms_per_launch)."""
+    w2 f32 [Cout2,Cexp]. Returns (out uint16 [B,H/stride,H/stride,Cout2], ms_per_launch). f16: x / res / out hold fp16 bits."""
     x = np.ascontiguousarray(x_bf16, dtype=np.uint16)
     B, H, _, Cin = x.shape
     f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
@@ -263,7 +265,7 @@ def fused_mb_debug(x_bf16, w1, scale1, shift1, w2, scale2, shift2, res_bf16=None
     r = None if res_bf16 is None else np.ascontiguousarray(res_bf16, dtype=np.uint16)
     ms = C.c_float()
     _lib.check(_lib.lib().isb_debug_fused_mb(device, _ptr(x), _ptr(w1), _ptr(f(scale1)), _ptr(f(shift1)), _ptr(w2),
-                                             _ptr(f(scale2)), _ptr(f(shift2)), _ptr(r), B, H, Cin, Cexp, Cout2, stride, iters,
+                                             _ptr(f(scale2)), _ptr(f(shift2)), _ptr(r), B, H, Cin, Cexp, Cout2, stride | (0x100 if f16 else 0), iters,
                                              _ptr(out), C.byref(ms)), "isb_debug_fused_mb")
     return out, ms.value
 
@@ -320,23 +322,6 @@ def dwconv_fc1_debug(x_bf16, w, scale, shift, se_w1, stride=1, device=0, in_f16=
                                                1, _ptr(out), _ptr(pooled), C.byref(ms), _ptr(se_w1), cse, _ptr(parts), C.byref(n)),
                "isb_debug_dwconv_fc1")
     return out, pooled, parts[:n.value]
-
-
-def expand_dw_debug(x_bf16, w1, scale1, shift1, dww, dwscale, dwshift, iters=1, device=0):
-    """Fused MBConv front half through isb_debug_expand_dw. x_bf16 uint16 [B,HW,HW,Cin].
-    Returns (D uint16 [B,HW,HW,Cexp], pooled f32 [B,Cexp], ms_per_launch)."""
-    x = np.ascontiguousarray(x_bf16, dtype=np.uint16)
-    B, HW, _, Cin = x.shape
-    w1 = np.ascontiguousarray(w1, dtype=np.float32)
-    Cexp = w1.shape[0]
-    f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
-    out = np.empty((B, HW, HW, Cexp), np.uint16)
-    pooled = np.empty((B, Cexp), np.float32)
-    ms = C.c_float()
-    _lib.check(_lib.lib().isb_debug_expand_dw(device, _ptr(x), _ptr(w1), _ptr(f(scale1)), _ptr(f(shift1)), _ptr(f(dww)),
-                                              _ptr(f(dwscale)), _ptr(f(dwshift)), B, HW, Cin, Cexp, iters, _ptr(out), _ptr(pooled),
-                                              C.byref(ms)), "isb_debug_expand_dw")
-    return out, pooled, ms.value
 
 
 def get_augmentations(num_aug: int, rot_aug_linspace_noend: bool = True):

@@ -15,7 +15,11 @@ classifier top (117,234,272 trainable: the figures Keras prints for EfficientNet
 
 Numeric modes:
   * ``mode="f32"``   plain fp32 everywhere;
-  * ``mode="bf16"``  the storage/rounding points of the HIP path's default precision (isb_hpe_cfg.precision = 0): conv
+  * ``mode="f16"``   the storage/rounding points of the HIP path's DEFAULT precision (isb_hpe_cfg.precision = 0 / 2; the
+    precision the reference's TensorRT engines are built with, 7_create_engines.py:10): conv weights incl. the depthwise
+    taps (BN scale folded in) and every stored activation -- stem output included -- rounded to IEEE fp16 (saturating);
+    accumulation / bias / SiLU / SE in fp32, the last 1x1 conv stores f32 and the pose head runs in f32;
+  * ``mode="bf16"``  isb_hpe_cfg.precision = 3 (round 3's layout): conv
     weights incl. the depthwise taps (BN scale folded in) and every stored activation are rounded to bf16 in the stem and
     in block strings 0-4; in the two 8x8 stages (block strings 5 and 6) and in the 640->1280 conv they are rounded to IEEE
     fp16 instead (the block that ENTERS the fp16 stages still runs its expand conv and its depthwise taps on bf16: its
@@ -170,7 +174,7 @@ class EffNetV2LOracle:
     F16_FROM = 5        # first block string the product runs in fp16 (hpe_api.cpp f16_from)
 
     def __init__(self, state: Mapping[str, np.ndarray], mode: str = "bf16", rounding=None):
-        assert mode in ("f32", "bf16", "bf16_plain")
+        assert mode in ("f32", "f16", "bf16", "bf16_plain")
         self.mode = mode
         mixed = rounding is None and mode == "bf16"
         if rounding is None:
@@ -178,6 +182,8 @@ class EffNetV2LOracle:
                 rounding = lambda stage, point: "f16" if stage >= self.F16_FROM else "bf16"
             elif mode == "bf16_plain":
                 rounding = lambda stage, point: "bf16"
+            elif mode == "f16":
+                rounding = lambda stage, point: "f16"
             else:
                 rounding = lambda stage, point: "f32"
         self.rounding = rounding

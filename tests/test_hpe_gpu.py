@@ -251,15 +251,16 @@ def eng_w(eng, bbone_state):
 
 
 def test_backbone_vs_oracle(eng_w, bbone_state, assets):
-    """K2: HIP EfficientNetV2-L (bf16 storage / f32 accumulate) against our own CPU definition
-    (parity unpinned w.r.t. MetrABS: the reference has neither source nor weights)."""
+    """K2: HIP EfficientNetV2-L (default precision: fp16 storage / f32 accumulate -- the reference's engines are fp16,
+    7_create_engines.py:10) against our own CPU definition in its storage-faithful mode (parity unpinned w.r.t. MetrABS:
+    the reference has neither source nor weights)."""
     from oracle import hpe_oracle as ho
     from oracle.effnetv2_oracle import EffNetV2LOracle
     fr = synth.frames(2, seed=0)
     bb = synth.bboxes(2, seed=0)
     crops = np.stack([ho.warp(fr[i], ho.crop_params(bb[i], _K())[2][0]) for i in range(2)])
     feat, logits = eng_w.backbone(crops)
-    o16 = EffNetV2LOracle(bbone_state, "bf16")
+    o16 = EffNetV2LOracle(bbone_state, "f16")
     f16 = o16.backbone(crops)
     l16 = o16.head(f16)
     scale = float(np.abs(f16).max())
@@ -298,7 +299,7 @@ def test_backbone_signal_profile_vs_oracle(eng, assets):
         bb = synth.bboxes(B, seed=5)
         crops = np.stack([ho.warp(fr[i], ho.crop_params(bb[i], _K())[2][0]) for i in range(B)])
         feat, logits = eng.backbone(crops)
-        o16 = EffNetV2LOracle(state, "bf16")
+        o16 = EffNetV2LOracle(state, "f16")
         f16 = o16.backbone(crops)
         l16 = o16.head(f16)
         scale = float(np.abs(f16).max())
@@ -337,7 +338,7 @@ def test_forward_end_to_end_vs_oracle(eng_w, bbone_state, assets):
     fr = synth.frames(B, seed=20)
     bb = synth.bboxes(B, seed=20)
     joints, valid = eng_w.forward(fr, bb)
-    o16 = EffNetV2LOracle(bbone_state, "bf16")
+    o16 = EffNetV2LOracle(bbone_state, "f16")
     o32 = EffNetV2LOracle(bbone_state, "f32")
     crops = np.stack([ho.warp(fr[b], ho.crop_params(bb[b], _K())[2][0]) for b in range(B)])
     _, lg_gpu = eng_w.backbone(crops)
@@ -357,11 +358,11 @@ def test_forward_end_to_end_vs_oracle(eng_w, bbone_state, assets):
 
 
 def test_absolute_pose_within_1e3_of_fp32_definition(bbone_state, assets):
-    """estimate() RETURNS the absolute pose (hpe.py:171; main.py:102 takes its distance), so it has to
-    sit within the north star's 1e-3 of the fp32 path too, not only of the bf16-faithful oracle. 16 frames (the first 8
-    are the frames bench.py's parity object uses), default weights: default precision (bf16, fp16 in the two 8x8 stages
-    and the 640 -> 1280 convolution) against the fp32 oracle at a flat 1e-3; the plain-bf16 precision is run beside it and must be the worse one
-    (its own distance to fp32 is a property of bf16 storage: oracle/error_budget.py)."""
+    """estimate() RETURNS the absolute pose (hpe.py:171; main.py:102 takes its distance), so it has to sit within the north
+    star's 1e-3 of the fp32 path too, not only of the storage-faithful oracle. 16 frames (the first 8 are the frames
+    bench.py's parity object uses), default weights, all three storage layouts against the fp32 oracle: the default (fp16
+    everywhere = the reference's TensorRT precision) and round 3's mixed layout at a flat 1e-3; plain bf16 is run beside
+    them and must be the worst (its distance to fp32 is a property of bf16 storage: oracle/error_budget.py)."""
     from isbfsar_amd.hpe_engine import HpeEngine
     from oracle import hpe_oracle as ho
     from oracle.effnetv2_oracle import EffNetV2LOracle
@@ -373,7 +374,7 @@ def test_absolute_pose_within_1e3_of_fp32_definition(bbone_state, assets):
     o32 = EffNetV2LOracle(bbone_state, "f32")
     l32 = o32.head(o32.backbone(crops))
     errs = {}
-    for prec in ("bf16_f16tail", "bf16"):
+    for prec in ("f16", "bf16_f16tail", "bf16"):
         e = HpeEngine(device=0, max_batch=16, precision=prec)
         try:
             e.set_joint_map(W, idx)
@@ -389,8 +390,82 @@ def test_absolute_pose_within_1e3_of_fp32_definition(bbone_state, assets):
             d.append(float(np.abs(joints[b] - ref).max()))
         errs[prec] = np.array(d)
         print(f"absolute pose vs fp32 definition, precision {prec}: median {np.median(d):.2e} max {max(d):.2e}")
+    assert errs["f16"].max() < 1e-3
     assert errs["bf16_f16tail"].max() < 1e-3
-    assert np.median(errs["bf16_f16tail"]) < np.median(errs["bf16"])
+    assert np.median(errs["f16"]) < np.median(errs["bf16"]) and np.median(errs["bf16_f16tail"]) < np.median(errs["bf16"])
+
+
+def test_signal_profile_fp16_vs_fp32_definition(assets):
+    """VERDICT r3 item 1(b). On the "signal" weight profile (activations that carry the input, peaked heat-maps: the regime
+    of a trained MetrABS) no 16-bit layout reaches 1e-3 of fp32 -- a random 79-block SiLU network amplifies every rounding
+    -- but the layouts differ by an order of magnitude: the CPU budget (oracle/error_budget.py, profiles/
+    r03_pose_error_budget.txt) puts fp16 everywhere at 3.4e-3 decoded-3D / 2.0e-3 absolute against 2.7e-2 / 5.4e-2 for the
+    bf16 layouts. The HIP fp16 path (the default) has to land within 1.5x of that budget AGAINST THE FP32 ORACLE, and the
+    bf16 layouts -- reported beside it -- must be the worse ones."""
+    from isbfsar_amd import effnetv2
+    from isbfsar_amd.hpe_engine import HpeEngine
+    from oracle import hpe_oracle as ho
+    from oracle.effnetv2_oracle import EffNetV2LOracle
+    W, st = assets
+    idx = st["smpl+head_30"]["indices"]
+    state = effnetv2.make_state(0, "signal", head_gain=0.5)
+    B = 8
+    fr, bb = synth.frames(B, seed=0), synth.bboxes(B, seed=0)
+    crops = np.stack([ho.warp(fr[b], ho.crop_params(bb[b], _K())[2][0]) for b in range(B)])
+    o32 = EffNetV2LOracle(state, "f32")
+    l32 = o32.head(o32.backbone(crops))
+    p2_32, p3_32 = ho.decode(l32)
+    res = {}
+    for prec in ("f16", "bf16_f16tail", "bf16"):
+        e = HpeEngine(device=0, max_batch=8, precision=prec)
+        try:
+            e.set_joint_map(W, idx)
+            e.load_weights(state)
+            joints, valid = e.forward(fr, bb)
+            _, lg = e.backbone(crops)
+        finally:
+            e.close()
+        p2, p3 = ho.decode(lg)
+        e3 = float(np.abs(p3 - p3_32).max())
+        e2 = float(np.abs(p2 - p2_32).max())
+        ea = 0.0
+        for b in range(B):
+            nk, r, _ = ho.crop_params(bb[b], _K())
+            ref = ho.postprocess(l32[b:b + 1], nk, r, W, idx)
+            if ref is not None and valid[b]:
+                ea = max(ea, float(np.abs(joints[b] - ref).max()))
+        res[prec] = (e3, e2, ea)
+        print(f"signal profile vs fp32 definition, precision {prec}: decoded 3D {e3:.2e}, 2D {e2:.3f} px, absolute pose {ea:.2e}")
+    assert res["f16"][0] < 1.5 * 3.4e-3, res["f16"]           # decoded 3D (heat-map units): 1.5 x the CPU budget's fp16-everywhere figure
+    assert res["f16"][2] < 1.5 * 3.4e-3, res["f16"]           # absolute pose under the same ceiling
+    assert res["f16"][0] < 0.5 * res["bf16"][0] and res["f16"][0] < 0.5 * res["bf16_f16tail"][0]
+
+
+def test_mixed_precision_vs_its_oracle(bbone_state, assets):
+    """isb_hpe_cfg.precision = 3 (round 3's layout: bf16, fp16 in the two 8x8 stages and the 640 -> 1280 convolution)
+    against the oracle's matching mode ("bf16")."""
+    from isbfsar_amd.hpe_engine import HpeEngine
+    from oracle import hpe_oracle as ho
+    from oracle.effnetv2_oracle import EffNetV2LOracle
+    W, st = assets
+    idx = st["smpl+head_30"]["indices"]
+    B = 3
+    fr, bb = synth.frames(B, seed=22), synth.bboxes(B, seed=22)
+    crops = np.stack([ho.warp(fr[b], ho.crop_params(bb[b], _K())[2][0]) for b in range(B)])
+    o16 = EffNetV2LOracle(bbone_state, "bf16")
+    e = HpeEngine(device=0, max_batch=8, precision="bf16_f16tail")
+    try:
+        e.set_joint_map(W, idx)
+        e.load_weights(bbone_state)
+        joints, valid = e.forward(fr, bb)
+        _, lg_gpu = e.backbone(crops)
+    finally:
+        e.close()
+    for b in range(B):
+        nk, r, _ = ho.crop_params(bb[b], _K())
+        lg = o16.head(o16.backbone(crops[b:b + 1]))
+        assert valid[b] == 1
+        _check_pose(joints[b], lg_gpu[b:b + 1], lg, nk, r, W, idx, tag=f" mixed layout frame {b}")
 
 
 def test_plain_bf16_precision_vs_its_oracle(bbone_state, assets):
@@ -457,7 +532,7 @@ def test_single_frame_call_vs_oracle(eng_w, bbone_state, assets):
     j2, v2 = eng_w.forward(fr, bb)
     assert np.array_equal(j1, j1b) and v1[0] == v2[0] == 1
     nk, r, H = ho.crop_params(bb[0], _K())
-    o16 = EffNetV2LOracle(bbone_state, "bf16")
+    o16 = EffNetV2LOracle(bbone_state, "f16")
     crop = ho.warp(fr[0], H[0])[None]
     _, lg_gpu = eng_w.backbone(crop)                     # B = 1: the same split-K path as the forward call above
     _check_pose(j1[0], lg_gpu, o16.head(o16.backbone(crop)), nk, r, W, idx, tag=" single frame")

@@ -43,7 +43,7 @@ def bb_state():
 def _oracle_poses(bb_state, expand, frames, boxes):
     from oracle import hpe_oracle as ho
     from oracle.effnetv2_oracle import EffNetV2LOracle
-    net = EffNetV2LOracle(bb_state, "bf16")
+    net = EffNetV2LOracle(bb_state, "f16")
     out = []
     for f, b in zip(frames, boxes):
         nk, r, H = ho.crop_params(b, _K())

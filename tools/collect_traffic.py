@@ -12,7 +12,7 @@ import sys
 def family(name: str) -> str:
     if "dwconv3x3" in name:
         return "dwconv3x3_pool"
-    if "conv_igemm" in name or "gemm1x1" in name or "conv3x3_dma" in name or "conv3x3_c32_rows" in name or "fused_mb" in name:
+    if "conv_igemm" in name or "gemm1x1" in name or "conv3x3_dma" in name or "conv3x3_c32_rows" in name or "fused_mb" in name or "mbconv8" in name:
         return "conv_igemm"
     if "se_fc" in name:
         return "se_fc"
@@ -46,17 +46,25 @@ for f in sorted(set(fetch) | set(write)):
                           "hbm_bytes_per_forward": (2.0 * fk + wk) * 1024.0}
 # optional: the same two passes of `bench.py --workload ar --steps 1 --warmup 1 --no-cpu-baseline` (argv[4], argv[5])
 if len(sys.argv) > 5:
-    def per_launch(path, counter, key):
+    import re
+
+    # the all-classes instantiation, whatever its operand type: ar_proto_kernel<X3, CHOSEN = false, F16> -- the second template
+    # argument (round 3's fp16 operands added a third one, which a literal "<false, false>" no longer matched)
+    ALL_CLASSES = {"ar_proto": re.compile(r"ar_proto_kernel<\s*(?:true|false)\s*,\s*false\b"), "ar_stats": re.compile(r"ar_stats_kernel<")}
+
+    def per_launch(path, counter, rx):
         tot = n = 0
         for r in csv.DictReader(open(path)):
-            if r["Counter_Name"] == counter and key in r["Kernel_Name"]:
+            if r["Counter_Name"] == counter and rx.search(r["Kernel_Name"]):
                 tot += float(r["Counter_Value"])
                 n += 1
         return tot / max(n, 1), n
     out["ar_b1024"] = {}
-    for key, name in (("ar_proto_kernel<false, false>", "ar_proto"), ("ar_stats_kernel", "ar_stats")):
-        fk, n = per_launch(sys.argv[4], "FETCH_SIZE", key)
-        wk, _ = per_launch(sys.argv[5], "WRITE_SIZE", key)
+    for name, rx in ALL_CLASSES.items():
+        fk, n = per_launch(sys.argv[4], "FETCH_SIZE", rx)
+        wk, _ = per_launch(sys.argv[5], "WRITE_SIZE", rx)
+        if n == 0:
+            raise SystemExit(f"collect_traffic: no {name} launch matched in {sys.argv[4]} -- refusing to write a zero")
         out["ar_b1024"][name] = {"FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "launches_in_trace": n,
                                  "hbm_bytes_per_launch": (2.0 * fk + wk) * 1024.0}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
