@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--way", type=int, default=60)
     ap.add_argument("--precision", default="f16", choices=["bf16", "f16", "bf16x3"],
                     help="operand type of the two tuple-attention contractions (f16: the default -- bf16's matrix rate, logits 2-13x closer to the fp32 reference)")
+    ap.add_argument("--hpe-precision", default="f16", choices=["f16", "bf16", "bf16_f16tail"],
+                    help="16-bit storage type of the pose backbone (isb_hpe_cfg.precision): f16 = IEEE fp16 in every stage, the default and "
+                         "what the reference's TensorRT engines run; bf16; bf16_f16tail = round 3's mixed layout")
     ap.add_argument("--host-input", action="store_true",
                     help="hpe workload: frames start in (pinned) HOST memory each step, isb_hpe_forward_host copies them (PCIe-inclusive "
                          "rate: the reference's Runner pattern; never the headline value)")

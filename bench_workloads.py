@@ -111,7 +111,9 @@ class _HpeBase:
         self.B = args.batch or 256
         self.dev = dev
         self.bb_state = effnetv2.make_state(0)
-        self.hpe = HpeEngine(device=dev, max_batch=min(self.B, int(os.environ.get("ISB_HPE_MICROBATCH", "1024"))))
+        self.hpe = HpeEngine(device=dev, max_batch=min(self.B, int(os.environ.get("ISB_HPE_MICROBATCH", "1024"))),
+                             precision=getattr(args, "hpe_precision", "f16"))
+        self.precision = self.hpe.precision if self.hpe.precision != "bf16_f16tail" else "bf16"
         self.hpe.load_weights(self.bb_state)
         self.hpe.set_joint_map(np.load(os.path.join(_ASSETS, "32_to_122.npy")), None)   # skeleton=None -> 122 joints
         self.frames_host = synth.frames(self.B, seed=10_000 * rank)

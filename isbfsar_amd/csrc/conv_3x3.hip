@@ -11,6 +11,7 @@ namespace isb {
 // (12 instead of 20 KiB per k-step). Same (tap, channel) order: bit-identical.
 template <int TM, int TN, int WGM, int WGN, bool HALO = false, bool F16 = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_dma_kernel(ConvArgs p) {
+    T16<F16>::enter();
     constexpr int NW = WGM * WGN;
     constexpr int BM = 32 * TM * WGM;
     constexpr int BN = 32 * TN * WGN;
@@ -213,6 +214,7 @@ constexpr int HALO_RING = 6 * HALO_ROWB;
 constexpr int HALO_LDS = HALO_RING + 256 * 64;       // + the step's output tile (residual in, result out: in place)
 template <bool F16>
 __global__ __launch_bounds__(512, 2) void conv3x3_c32_rows_kernel(ConvArgs p, int band) {
+    T16<F16>::enter();
     constexpr int W_ = 128;
     unsigned char* const lds = conv_lds_dyn;
     unsigned char* const Cs = lds + HALO_RING;           // [256 pixels][64 B], chunk-swizzled like the ring

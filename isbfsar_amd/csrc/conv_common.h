@@ -38,24 +38,34 @@ __device__ __forceinline__ uint4 gate_bf16x8(uint4 v, float4 g0, float4 g1) {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float h2f_(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
-// round to nearest even, saturating at the largest finite fp16 (an inf would poison every later layer)
+// round to nearest even, saturating at the largest finite fp16 (an inf would poison every later layer). Two ways:
+//  * f2h_: an explicit clamp in front of the conversion (kernels that learn the storage type at run time: stem, weight conversion);
+//  * the kernels templated on `bool F16` set MODE.FP16_OVFL once at their start (T16<F16>::enter()): with that bit every fp16
+//    VALU result that would overflow is clamped to +-65504 by the conversion itself (true infinities pass; probed on gfx950,
+//    tools/probes/fp16_ovfl.hip), so an fp16 pair costs ONE v_cvt_pk_f16_f32 like a bf16 pair -- the two v_med3 per pair of the
+//    explicit clamp made fp16 storage 2.9 % slower than bf16 on the 256-frame pose step (epilogue-bound expand GEMMs).
 __device__ __forceinline__ float f16_sat(float x) { return __builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f); }
 __device__ __forceinline__ uint16_t f2h_(float x) { return __builtin_bit_cast(uint16_t, (_Float16)f16_sat(x)); }
+__device__ __forceinline__ void fp16_ovfl_on() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1"); }
 
 template <bool F16>
 struct T16 {
+    // first statement of every kernel that stores through this struct: fp16 conversions saturate from here on (see above)
+    static __device__ __forceinline__ void enter() {
+        if constexpr (F16) fp16_ovfl_on();
+    }
     static __device__ __forceinline__ float to_f32(uint16_t h) {
         if constexpr (F16) return h2f_(h); else return bf2f_(h);
     }
     static __device__ __forceinline__ uint16_t from_f32(float x) {
-        if constexpr (F16) return f2h_(x); else return f2bf_(x);
+        if constexpr (F16) return __builtin_bit_cast(uint16_t, (_Float16)x); else return f2bf_(x);      // (saturating: enter())
     }
     static __device__ __forceinline__ float lo(uint32_t w) { return to_f32((uint16_t)(w & 0xffffu)); }
     static __device__ __forceinline__ float hi(uint32_t w) { return to_f32((uint16_t)(w >> 16)); }
     static __device__ __forceinline__ uint32_t pack2(float a, float b) {
         if constexpr (F16) {
-            const f32x2_t v = {f16_sat(a), f16_sat(b)};
-            return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+            const f32x2_t v = {a, b};
+            return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));      // (saturating: enter())
         } else {
             const f32x2_t v = {a, b};
             return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));

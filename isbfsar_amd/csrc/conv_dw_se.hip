@@ -11,6 +11,7 @@ namespace isb {
 
 // split-K reduction: out[m][n] = bf16( sum_s part[s][m][n] (in split order) + bias[n] (+ res[m][n]) )
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs p) {
+    if (p.f16) fp16_ovfl_on();
     const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x;       // one thread = 4 consecutive channels
     const size_t total4 = (size_t)p.M * p.Cout / 4;
     if (i4 >= total4) return;
@@ -77,6 +78,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 // IN_F16 / OUT_F16: input + taps / output in fp16 instead of bf16 (DwArgs.in_f16 / out_f16)
 template <int S, bool FC1 = false, bool IN_F16 = false, bool OUT_F16 = false>
 __global__ __launch_bounds__(256) void dwconv3x3_pool_kernel(DwArgs p) {
+    T16<OUT_F16>::enter();
     __shared__ float red[32][129];
     __shared__ __attribute__((aligned(16))) float pmean[FC1 ? 128 : 4];
     constexpr int NCOL = 3 * S + 3;
@@ -218,6 +220,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_pool_kernel(DwArgs p) {
 // dwconv3x3_pool_kernel<1>: bit-identical (tested). 8 x 8: 3.5 -> 4.7 TB/s.
 template <bool F16, int HW, bool FC1 = false>
 __global__ __launch_bounds__(256) void dwconv3x3_map_kernel(DwArgs p) {
+    T16<F16>::enter();
     constexpr int NQ = HW * HW / 4;                        // pixel quads per sample
     constexpr int PQ = NQ >= 32 ? 32 : NQ;                 // quad slots in the workgroup (16 on 8 x 8 maps)
     constexpr int CH = 256 / PQ;                           // 8-channel chunks per workgroup: 16 (128 channels) / 8 (64 channels)

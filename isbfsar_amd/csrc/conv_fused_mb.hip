@@ -24,6 +24,7 @@ namespace isb {
 // then streams only the weights: 16 instead of 24 KiB per k-step. Same (tap, channel) order: bit-identical.
 template <int WGM, int TN, int WPR, bool HALO = false, bool F16 = false>
 __global__ __launch_bounds__(128 * WGM) void fused_mb_kernel(ConvArgs p) {
+    T16<F16>::enter();
     constexpr int WGN = 2, NW = WGM * WGN;
     constexpr int TN2 = (WPR / 32 + 1) / 2;                  // 32-channel tiles of the projection per wave
     constexpr int BM = 32 * WGM, BN = 64 * TN;               // BN = Cexp

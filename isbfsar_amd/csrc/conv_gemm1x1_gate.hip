@@ -19,6 +19,7 @@ namespace isb {
 // WGM x WGN consumer waves of 32 x (32 TN) sub-tiles + 4 loader waves; NP pair buffers in the ring
 template <int WGM, int WGN, int TN, int NP, bool F16>
 __global__ __launch_bounds__(64 * (WGM * WGN + 4)) void gemm1x1_lw_kernel(ConvArgs p) {
+    T16<F16>::enter();
     constexpr int NCW = WGM * WGN, NLW = 4;                            // consumer / loader waves
     constexpr int NTH = 64 * (NCW + NLW);
     constexpr int BM = 32 * WGM, BN = 32 * TN * WGN;

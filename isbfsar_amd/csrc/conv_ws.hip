@@ -309,6 +309,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // F16: operands and output in fp16 instead of bf16 (ConvArgs.f16; 32x32x16 form only)
 template <int NK, bool ACT, bool STAMPS = false, int TMB = 4, int WPC = (TMB == 4 ? 1 : 2), int NWM = 1, bool M16 = false, bool F16 = false>
 __global__ __launch_bounds__(256 * NWM, WPC) void gemm1x1_wspipe_kernel(ConvArgs p) {
+    T16<F16>::enter();
     static_assert(!(M16 && F16), "the fp16 form exists on the 32x32x16 MFMA");
     constexpr int K = 32 * NK, NW = 4, NWT = NW * NWM;
     constexpr int BM = 32 * TMB * NWM, BN = 32 * NW;

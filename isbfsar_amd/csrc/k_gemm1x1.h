@@ -27,6 +27,7 @@ namespace isb {
 // the step after it may still fly) instead of vmcnt(0).
 template <int TM, int TN, int WGM, int WGN, int GATE = 0, bool STAMPS = false, int NBUF = 2, bool F16 = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_dma_kernel(ConvArgs p) {
+    T16<F16>::enter();
     uint64_t st_t0 = 0, st_wait = 0, st_bar = 0, st_loop0 = 0, st_loop1 = 0;
     if constexpr (STAMPS) st_t0 = __builtin_amdgcn_s_memtime();
     constexpr int NW = WGM * WGN;

@@ -571,3 +571,51 @@ def test_gated_projection_with_loader_waves_is_bit_identical(shape, f16):
     ref_v = 146 if Cout % 192 == 0 else 144
     b, _ = conv_debug(cvt(x), w, scale, shift, 1, 1, 0, cvt(res), gate, variant=ref_v, f16=f16)
     assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("kind", ["g1_131", "g1_138", "gate_146", "gate_155", "ws_184", "ws_186", "c3_161", "c3_171", "c3_167", "fused", "dw1", "dw2", "splitk"])
+def test_f16_storage_saturates_instead_of_overflowing(kind):
+    """fp16 storage must never produce an inf (it would poison every later layer): the kernels templated on the storage type set
+    MODE.FP16_OVFL at their start, so conversions clamp to +-65504 (conv_common.h T16::enter). Every fp16 kernel family is driven
+    past the fp16 range here: finite outputs, the largest exactly 65504, and in-range values untouched."""
+    from isbfsar_amd.hpe_engine import dwconv_debug, f16_to_f32, f32_to_f16, fused_mb_debug
+    rng = np.random.default_rng(len(kind))
+    big = 3.0e4
+
+    def check(out):
+        got = f16_to_f32(out)
+        assert np.isfinite(got).all()
+        assert np.abs(got).max() == 65504.0
+        assert (np.abs(got) < 6.0e4).mean() > 0.2            # not everything saturated: the clamp is per value
+
+    if kind.startswith(("g1", "gate", "ws", "splitk")):
+        B, H, Cin, Cout, gate, act = {"g1_131": (9, 8, 160, 384, False, 0), "g1_138": (1, 8, 160, 128, False, 0), "gate_146": (5, 8, 256, 384, True, 0),
+                                      "gate_155": (70, 8, 256, 384, True, 0), "ws_184": (40, 16, 224, 256, False, 1),
+                                      "ws_186": (300, 8, 384, 256, False, 1), "splitk": (1, 8, 512, 128, True, 0)}[kind]
+        x = rng.normal(0, 1, (B, H, H, Cin)).astype(np.float32)
+        w = (rng.normal(0, 1, (Cout, 1, 1, Cin)) / np.sqrt(Cin)).astype(np.float32)
+        g = rng.uniform(0.5, 1.0, (B, Cin)).astype(np.float32) if gate else None
+        v = {"g1_131": 131, "g1_138": 138, "gate_146": 146, "gate_155": 155, "ws_184": 184, "ws_186": 186, "splitk": 4147}[kind]
+        out, _ = conv_debug(f32_to_f16(x), w, np.full(Cout, big, np.float32), np.zeros(Cout, np.float32), 1, 1, act, None, g, variant=v, f16=True)
+        check(out)
+    elif kind.startswith("c3"):
+        B, H, W, Cin, Cout, v = {"c3_161": (2, 16, 16, 64, 192, 161), "c3_171": (1, 8, 128, 32, 32, 171), "c3_167": (1, 32, 32, 96, 192, 167)}[kind]
+        x = rng.normal(0, 1, (B, H, W, Cin)).astype(np.float32)
+        w = (rng.normal(0, 1, (Cout, 3, 3, Cin)) / np.sqrt(9 * Cin)).astype(np.float32)
+        out, _ = conv_debug(f32_to_f16(x), w, np.full(Cout, big, np.float32), np.zeros(Cout, np.float32), 3, 1, 1, None, None, variant=v, f16=True)
+        check(out)
+    elif kind == "fused":
+        x = rng.normal(0, 1, (1, 64, 64, 64)).astype(np.float32)
+        w1 = (rng.normal(0, 1, (256, 3, 3, 64)) / 24.0).astype(np.float32)
+        w2 = (rng.normal(0, 1, (64, 256)) / 16.0).astype(np.float32)
+        one, zero = np.ones(256, np.float32), np.zeros(256, np.float32)
+        out, _ = fused_mb_debug(f32_to_f16(x), w1, 300.0 * one, zero, w2, 300.0 * one[:64], zero[:64], None, 1, f16=True)   # the E tile saturates too
+        check(out)
+    else:
+        stride = 1 if kind == "dw1" else 2
+        C_ = 256
+        x = rng.normal(0, 1, (2, 8 * stride, 8 * stride, C_)).astype(np.float32)
+        w = (rng.normal(0, 1, (C_, 3, 3)) / 3.0).astype(np.float32)
+        out, pooled, _ = dwconv_debug(f32_to_f16(x), w, np.full(C_, big, np.float32), np.zeros(C_, np.float32), stride=stride, in_f16=True, out_f16=True)
+        check(out)
+        assert np.isfinite(pooled).all()
