@@ -280,6 +280,11 @@ int isb_debug_conv(int32_t device, const uint16_t* h_x, const float* h_w, const 
                    int32_t k, int32_t stride, int32_t act, int32_t variant, int32_t iters, uint16_t* h_out,
                    float* ms_per_iter);
 
+/* tuning probe of the fused 8 x 8 chain (conv_mb8.hip): enable != 0 arms in-kernel s_memtime stamps (the following forward passes
+ * write them), enable == 0 copies them to host_out ([32 workgroups][2 blocks][32 marks] uint64_t: marks 0-9 of wave 0, 16-25 of the
+ * last wave; block 0 = a 384 -> 2304 -> 384 block, block 1 = a 640 -> 3840 -> 640 block) and disarms. tools/exp_mb8.py */
+int isb_debug_hpe_mb8_stamps(isb_hpe* h, int32_t enable, uint64_t* host_out);
+
 /* test / tuning hook: a whole Fused-MBConv block (3x3 expand + BN + SiLU -> 1x1 project + BN [+ residual]) in ONE
  * launch on host tensors. h_x bf16 [B,H,H,Cin], h_w1 f32 [Cexp,3,3,Cin] (Cexp = 128, 256 or 384), h_w2 f32 [Cout2,Cexp]
  * (Cout2 <= 128), optional residual h_res bf16 [B,H/stride,H/stride,Cout2]; out bf16 of that shape. */

@@ -1,0 +1,521 @@
+// The MBConv blocks of the two 8 x 8 stages of EfficientNetV2-L (stride 1: 24 x 384 -> 2304 -> 384, 1 x 384 -> 2304 -> 640,
+// 6 x 640 -> 3840 -> 640; 31 of the backbone's 79 blocks, 31 % of its FLOPs) as ONE launch: mb8_chain_kernel.
+//
+// At 8 x 8 a sample is 64 pixels = two 32-row MFMA blocks, and nothing in an MBConv block couples samples: the depthwise 3 x 3
+// needs no halo beyond the sample, the squeeze-excite pool / FC1 / FC2 / gate are per sample. So ONE workgroup owns ONE sample for
+// the whole chain of blocks and never meets another workgroup. Per launch of the five-kernel form (expand GEMM, depthwise + pool,
+// FC1, FC2, gated projection) a block costs 35-55 us per GEMM for 11-13 us of work at either floor (first-tile latency, gate rows,
+// epilogue, the tail of a single round of workgroups) and sends the expanded tensor (295 KB per sample) through HBM twice. Here:
+//
+//   residual stream X [64 px][Cin]   lives in LDS for the whole chain (A-operand tiles of the expand GEMM, 4 KiB per 32 channels)
+//   phase 1-3, per WAVE and 32-channel block of the expanded tensor, no barrier at all:
+//       expand: the wave streams the block's weights global -> REGISTERS (pre-packed in MFMA fragment order: one coalesced 1-KiB
+//               load per k16 step, each fragment feeds the two row blocks; the next batch travels under the current one's MFMAs
+//               and the next block's first batch under this block's vector phase) -- weights never touch LDS;
+//       SiLU -> 16-bit -> the wave's private [10 x 10 padded px][32 ch] tile in LDS (the zero ring is TF-SAME's padding);
+//       depthwise 3 x 3 from that tile (the taps of dwconv3x3_map_kernel in its order), SiLU, one rounding;
+//       D block -> global scratch AS THE 4-KiB A-TILE the projection will DMA back (L2-resident: written and re-read by this CU);
+//       pool: quad partial sums -> 16-term sums in quad order -> mean (the order of the depthwise kernel: same bits);
+//   phase 4  squeeze-excite for the one sample in the arithmetic AND ORDER of se_fc1_part_kernel / se_fc2_kernel (256-channel
+//            chains, partials in chunk order; four j-quarters in wave order), weights streamed to registers from packed layouts;
+//   phase 5  gated projection: 2-3 helper waves DMA the D tiles into an LDS ring (one barrier per four k-steps), the projection
+//            waves stream W2 through registers like phase 1, gate the A fragments as they leave LDS (gemm1x1's arithmetic);
+//   phase 6  bias + residual (from X in LDS) + one rounding -> X in place (the next block's operand), last block -> global.
+//
+// Every sum runs in the order of the five-kernel path: the chain's output is BIT-IDENTICAL to it (tests/test_hpe_gpu.py).
+// What bounds it: per block a workgroup pulls ALL the block's weights through its CU's L2 port (3.5 MB 16-bit + 1.8 MB f32
+// squeeze-excite for 384 channels) for 64 rows -- 128 FLOP per 16-bit weight byte against the 127 a CU's matrix pipe needs per
+// byte delivered at 32 B/clk; DESIGN.md section 3 has the arithmetic and the measured stamps.
+#include "conv_tiles.h"
+
+namespace isb {
+
+namespace {
+
+constexpr int MB8_NW = 8;                       // waves per workgroup (two per SIMD)
+constexpr int MB8_NT = 64 * MB8_NW;
+constexpr int MB8_XBYTES = 20 * 4096;           // residual stream: up to 640 channels = 20 tiles of [64 rows][64 B]
+constexpr int MB8_ET_PIX = 100;                 // 10 x 10 padded pixels
+constexpr int MB8_ET_BYTES = MB8_ET_PIX * 64;   // per wave: [pixel][32 ch x 2 B]
+constexpr int MB8_ET_OFF = MB8_XBYTES;
+constexpr int MB8_POOL_OFF = MB8_ET_OFF + MB8_NW * MB8_ET_BYTES;      // f32 [Cexp]: pooled means, later the gate
+constexpr int MB8_MID_OFF = MB8_POOL_OFF + 3840 * 4;                  // f32 [160] squeeze-excite hidden units
+constexpr int MB8_PART_OFF = MB8_MID_OFF + 160 * 4;                   // f32 [15][160] FC1 partial sums per 256-channel chunk
+constexpr int MB8_LDS = MB8_PART_OFF + 15 * 160 * 4;                  // 158 720 B
+constexpr int MB8_RING_OFF = MB8_ET_OFF;        // phase 5: 8 D tiles of 4 KiB (two halves of four k-steps) overlay the E tiles
+static_assert(8 * 4096 <= MB8_NW * MB8_ET_BYTES, "the D ring fits the E tiles' region");
+static_assert(MB8_LDS <= 160 * 1024, "LDS");
+
+template <int CIN, int COUT, bool F16>
+struct Mb8Shape {
+    static constexpr int CEXP = 6 * CIN, CSE = CIN / 4;
+    static constexpr int NCB = CEXP / 32;                   // 32-channel blocks of the expanded tensor = k-steps of the projection
+    static constexpr int NK16 = CIN / 16;                   // k16 steps of the expand GEMM
+    static constexpr int KB = NK16 / 4;                     // ... in four register batches (two in flight)
+    static constexpr int CBW = COUT == 384 ? 2 : 4;         // 32-channel blocks per projection wave
+    static constexpr int NPW = COUT / 32 / CBW;             // projection waves: 6 (384 outputs) / 5 (640)
+    static constexpr int NHELP = MB8_NW - NPW;              // helper waves (D-tile DMA)
+    static_assert(NK16 % 4 == 0 && NCB % MB8_NW == 0 && NCB % 4 == 0 && COUT % (32 * CBW) == 0 && NPW < MB8_NW, "shape");
+};
+
+template <int I0, int N, class F>
+__device__ __forceinline__ void mb8_static_for(F&& f) {
+    if constexpr (I0 < N) {
+        f(std::integral_constant<int, I0>{});
+        mb8_static_for<I0 + 1, N>(f);
+    }
+}
+
+__device__ __forceinline__ int et_pix(int m) { return ((m >> 3) + 1) * 10 + (m & 7) + 1; }      // pixel m of the 8 x 8 map in the padded tile
+
+// One MBConv block for the workgroup's sample. X (LDS) in: the block's input, out: its output.
+template <int CIN, int COUT, bool F16>
+__device__ __forceinline__ void mb8_block(const Mb8Block& bk, unsigned char* lds, unsigned char* dscr, uint16_t* out_g, int tid, uint64_t* stamps) {
+    using S = Mb8Shape<CIN, COUT, F16>;
+    constexpr int CEXP = S::CEXP, CSE = S::CSE, NCB = S::NCB, NK16 = S::NK16, KB = S::KB, CBW = S::CBW, NPW = S::NPW, NHELP = S::NHELP;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    float* const pooled = reinterpret_cast<float*>(lds + MB8_POOL_OFF);
+    float* const mid = reinterpret_cast<float*>(lds + MB8_MID_OFF);
+    float* const part = reinterpret_cast<float*>(lds + MB8_PART_OFF);
+    // tuning probe (Mb8Args.stamps): wave 0 and the last wave of the first workgroups mark the phase boundaries with s_memtime
+    auto stamp = [&](int slot) {
+        if (stamps && (wave == 0 || wave == MB8_NW - 1)) {
+            const uint64_t t = __builtin_amdgcn_s_memtime();
+            if (lane == 0) stamps[(wave == 0 ? 0 : 16) + slot] = t;
+        }
+    };
+    stamp(0);
+
+    // ------------------------------------------------------------------ phases 1-3: per wave, per 32-channel block
+    {
+        unsigned char* const et = lds + MB8_ET_OFF + wave * MB8_ET_BYTES;
+        // the zero ring (36 of the 100 padded pixels; the projection's D ring overlays this region, so once per block)
+        for (int i = lane; i < 36 * 4; i += 64) {
+            const int q = i >> 2, ch = i & 3;
+            const int pix = q < 10 ? q : (q < 20 ? 90 + (q - 10) : (q < 28 ? 10 * (q - 19) : 10 * (q - 27) + 9));
+            *reinterpret_cast<uint4*>(et + pix * 64 + ch * 16) = make_uint4(0, 0, 0, 0);
+        }
+        const int a_sw0 = swz(r, h), a_sw1 = swz(r, 2 + h);            // A fragment of row block 0, k16 half 0 / 1 of a k-step tile
+        const int pq = lane >> 2, cl = lane & 3;                        // depthwise: pixel quad (16 per map), 8-channel chunk
+        const int oy = pq >> 1, ox0 = (pq & 1) * 4;
+        uint32_t one_lo, one_hi;                                        // (1, 0) / (0, 1) pairs in the storage type (see dwconv3x3_pool_kernel)
+        if constexpr (F16) asm volatile("v_mov_b32 %0, 0x3c00\n\tv_lshlrev_b32 %1, 16, %0" : "=v"(one_lo), "=v"(one_hi));
+        else asm volatile("v_mov_b32 %0, 0x3f80\n\tv_lshlrev_b32 %1, 16, %0" : "=v"(one_lo), "=v"(one_hi));
+
+        uint4 wb[2][KB];
+        auto load_batch = [&](auto bufc, int cb, int b) {               // k16 steps b KB .. of channel block cb
+            constexpr int buf = decltype(bufc)::value;
+            const uint4* src = bk.w1p + ((size_t)cb * NK16 + (size_t)b * KB) * 64 + lane;
+#pragma unroll
+            for (int s = 0; s < KB; ++s) wb[buf][s] = src[s * 64];
+        };
+        // every workgroup walks the channel blocks in its own rotation: at any moment the 32 CUs of an XCD then stream 32 x 8
+        // DIFFERENT weight regions instead of hammering the same eight through one or two L2 channels (no sum depends on the order
+        // of the channel blocks)
+        constexpr int NIT = NCB / MB8_NW;
+        const int rot = (int)(blockIdx.x >> 3) % NIT;
+        auto cb_of = [&](int it) { return wave + MB8_NW * ((it + rot) % NIT); };
+        load_batch(std::integral_constant<int, 0>{}, cb_of(0), 0);
+        for (int it = 0; it < NIT; ++it) {
+            const int cb = cb_of(it);
+            // the block's small operands: requested now, used after the MFMAs
+            const int c0 = cb * 32;
+            float4 bias1[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bias1[q] = *reinterpret_cast<const float4*>(bk.b1 + c0 + 8 * q + 4 * h);
+            uint4 taps[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) taps[t] = *reinterpret_cast<const uint4*>(bk.dww + (size_t)t * CEXP + c0 + cl * 8);
+            const float4 db0 = *reinterpret_cast<const float4*>(bk.dwb + c0 + cl * 8), db1 = *reinterpret_cast<const float4*>(bk.dwb + c0 + cl * 8 + 4);
+
+            f32x16 acc[2];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[0][e] = acc[1][e] = 0.f;
+            auto mma_batch = [&](auto bufc, int b) {
+                constexpr int buf = decltype(bufc)::value;
+#pragma unroll
+                for (int s = 0; s < KB; ++s) {
+                    const int k16 = b * KB + s;
+                    const unsigned char* xt = lds + (k16 >> 1) * 4096 + ((k16 & 1) ? a_sw1 : a_sw0);
+                    const uint4 a0 = *reinterpret_cast<const uint4*>(xt), a1 = *reinterpret_cast<const uint4*>(xt + 2048);
+                    acc[0] = T16<F16>::mfma32(wb[buf][s], a0, acc[0]);
+                    acc[1] = T16<F16>::mfma32(wb[buf][s], a1, acc[1]);
+                }
+            };
+            const int cbn = it + 1 < NIT ? cb_of(it + 1) : NCB;
+            load_batch(std::integral_constant<int, 1>{}, cb, 1);
+            mma_batch(std::integral_constant<int, 0>{}, 0);
+            load_batch(std::integral_constant<int, 0>{}, cb, 2);
+            mma_batch(std::integral_constant<int, 1>{}, 1);
+            load_batch(std::integral_constant<int, 1>{}, cb, 3);
+            mma_batch(std::integral_constant<int, 0>{}, 2);
+            if (cbn < NCB) load_batch(std::integral_constant<int, 0>{}, cbn, 0);     // travels under this block's vector phase
+            mma_batch(std::integral_constant<int, 1>{}, 3);
+
+            // ---- E = T16(silu(acc + bias)) -> the wave's padded tile. acc[rb][e]: pixel 32 rb + r, channel c0 + 8 (e >> 2) + 4 h + (e & 3)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                unsigned char* cell = et + et_pix(rb * 32 + r) * 64 + h * 8;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float v0 = silu_fast(acc[rb][4 * q] + bias1[q].x), v1 = silu_fast(acc[rb][4 * q + 1] + bias1[q].y);
+                    const float v2 = silu_fast(acc[rb][4 * q + 2] + bias1[q].z), v3 = silu_fast(acc[rb][4 * q + 3] + bias1[q].w);
+                    uint2 pk;
+                    pk.x = (uint32_t)T16<F16>::from_f32(v0) | ((uint32_t)T16<F16>::from_f32(v1) << 16);
+                    pk.y = (uint32_t)T16<F16>::from_f32(v2) | ((uint32_t)T16<F16>::from_f32(v3) << 16);
+                    *reinterpret_cast<uint2*>(cell + q * 16) = pk;
+                }
+            }
+            // ---- depthwise 3 x 3 + bias + SiLU on the tile: lane = (pixel quad, 8-channel chunk), taps and order of dwconv3x3_map_kernel
+            uint32_t wlo[9][4], whi[9][4];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const uint32_t wp[4] = {taps[t].x, taps[t].y, taps[t].z, taps[t].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { wlo[t][e] = wp[e] & 0xffffu; whi[t][e] = wp[e] & 0xffff0000u; }
+            }
+            const float dbias[8] = {db0.x, db0.y, db0.z, db0.w, db1.x, db1.y, db1.z, db1.w};
+            float dacc[4][8], psum[8];
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dacc[o][e] = dbias[e];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) psum[e] = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                uint4 v[6];
+#pragma unroll
+                for (int col = 0; col < 6; ++col) v[col] = *reinterpret_cast<const uint4*>(et + ((oy + ky) * 10 + ox0 + col) * 64 + cl * 16);
+#pragma unroll
+                for (int col = 0; col < 6; ++col) {
+                    const uint32_t x[4] = {v[col].x, v[col].y, v[col].z, v[col].w};
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) {
+                        const int kx = col - o;
+                        if (kx >= 0 && kx < 3) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                dacc[o][2 * e] = T16<F16>::dot2(x[e], wlo[ky * 3 + kx][e], dacc[o][2 * e]);
+                                dacc[o][2 * e + 1] = T16<F16>::dot2(x[e], whi[ky * 3 + kx][e], dacc[o][2 * e + 1]);
+                            }
+                        }
+                    }
+                }
+            }
+            unsigned char* const dtile = dscr + (size_t)cb * 4096;      // the projection's A tile of k-step cb: [64 rows][64 B], swizzled
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                uint32_t pk[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint16_t lo = T16<F16>::from_f32(silu_fast(dacc[o][2 * e])), hi = T16<F16>::from_f32(silu_fast(dacc[o][2 * e + 1]));
+                    pk[e] = (uint32_t)lo | ((uint32_t)hi << 16);
+                    psum[2 * e] = T16<F16>::dot2(pk[e], one_lo, psum[2 * e]);
+                    psum[2 * e + 1] = T16<F16>::dot2(pk[e], one_hi, psum[2 * e + 1]);
+                }
+                *reinterpret_cast<uint4*>(dtile + swz(oy * 8 + ox0 + o, cl)) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            }
+            // ---- pool: 16 quad sums per channel, added in quad order, / 64 (dwconv3x3_map_kernel's red[][] walk). The interior of
+            // the tile is free now: the quad sums go there (pixels 11.., never the ring)
+            float* const red = reinterpret_cast<float*>(et + 11 * 64);        // [16][32] f32 = 2 KiB inside the tile's interior rows 1-4
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[pq * 32 + cl * 8 + e] = psum[e];
+            if (lane < 32) {
+                float t = 0.f;
+#pragma unroll
+                for (int s2 = 0; s2 < 16; ++s2) t += red[s2 * 32 + lane];
+                pooled[c0 + lane] = t / 64.0f;
+            }
+            // (the quad sums overlapped ring-free pixels 11 .. 42; the ring's zeros at 19, 20, 29, 30, 39, 40 must be restored)
+            if (lane < 24) {
+                const int q = lane >> 2, ch = lane & 3;
+                const int pix = 19 + 10 * (q >> 1) + (q & 1);
+                *reinterpret_cast<uint4*>(et + pix * 64 + ch * 16) = make_uint4(0, 0, 0, 0);
+            }
+        }
+    }
+    stamp(1);
+    __syncthreads();                                                    // D tiles written (vmcnt) and pooled complete
+    stamp(2);
+
+    // ------------------------------------------------------------------ phase 4: squeeze-excite for this sample
+    {
+        // FC1 partials: part[kc][j] = chain over the 256 channels of chunk kc (se_fc1_part_kernel's order)
+        constexpr int NKC = CEXP / 256;
+        for (int id = tid; id < NKC * CSE; id += MB8_NT) {
+            const int kc = id / CSE, j = id - kc * CSE;
+            const float4* wsrc = reinterpret_cast<const float4*>(bk.se_w1p) + (size_t)kc * 64 * CSE + j;
+            const float4* psrc = reinterpret_cast<const float4*>(pooled + kc * 256);
+            float a = 0.f;
+#pragma unroll 16
+            for (int c4 = 0; c4 < 64; ++c4) {
+                const float4 wv = wsrc[(size_t)c4 * CSE];
+                const float4 pv = psrc[c4];
+                a = fmaf(pv.x, wv.x, a);
+                a = fmaf(pv.y, wv.y, a);
+                a = fmaf(pv.z, wv.z, a);
+                a = fmaf(pv.w, wv.w, a);
+            }
+            part[kc * CSE + j] = a;
+        }
+        stamp(3);
+        __syncthreads();
+        if (tid < CSE) {                                                // se_fc2_kernel's prologue
+            float v = bk.se_b1[tid];
+#pragma unroll
+            for (int kc = 0; kc < NKC; ++kc) v += part[kc * CSE + tid];
+            mid[tid] = v / (1.0f + expf(-v));
+        }
+        __syncthreads();
+        stamp(4);
+        // FC2 + sigmoid: four j-quarters summed separately, then added in quarter order (the four waves of se_fc2_kernel)
+        constexpr int JQ = (CSE + 3) >> 2;
+        float* const gate = pooled;                                     // every reader of the pooled means is past the barrier above
+        for (int slot = tid; slot < CEXP / 4; slot += MB8_NT) {
+            const int c = slot * 4;
+            float4 pw[4];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int jb = w * JQ, je = jb + JQ < CSE ? jb + JQ : CSE;
+#pragma unroll 8
+                for (int j = jb; j < je; ++j) {
+                    const float4 wv = *reinterpret_cast<const float4*>(bk.se_w2t + (size_t)j * CEXP + c);
+                    const float mv = mid[j];
+                    a.x = fmaf(mv, wv.x, a.x);
+                    a.y = fmaf(mv, wv.y, a.y);
+                    a.z = fmaf(mv, wv.z, a.z);
+                    a.w = fmaf(mv, wv.w, a.w);
+                }
+                pw[w] = a;
+            }
+            float4 v = pw[0];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) { v.x += pw[w].x; v.y += pw[w].y; v.z += pw[w].z; v.w += pw[w].w; }
+            const float4 b2 = *reinterpret_cast<const float4*>(bk.se_b2 + c);
+            v.x = 1.0f / (1.0f + expf(-(v.x + b2.x)));
+            v.y = 1.0f / (1.0f + expf(-(v.y + b2.y)));
+            v.z = 1.0f / (1.0f + expf(-(v.z + b2.z)));
+            v.w = 1.0f / (1.0f + expf(-(v.w + b2.w)));
+            *reinterpret_cast<float4*>(gate + c) = v;
+        }
+    }
+    // (FC2 reads `mid` and writes the gate over the pooled means: the quarter loops above finished reading pooled two barriers ago)
+    stamp(5);
+    __syncthreads();
+    stamp(6);
+
+    // ------------------------------------------------------------------ phase 5: gated projection, K = Cexp in halves of four k-steps
+    {
+        constexpr int NH = NCB / 4;
+        const uint32_t ring_lds = (uint32_t)(uintptr_t)(lds_ptr_t)lds + MB8_RING_OFF;
+        const float* const gate = pooled;
+        if (wave >= NPW) {
+            // ---- helper waves: D tiles global -> ring by LDS-DMA, 16 KiB per half dealt to the helpers
+            const int hw = wave - NPW;
+            auto issue = [&](int hf) {
+                for (int pc = hw; pc < 16; pc += NHELP)
+                    dma16_s(dscr + (size_t)hf * 16384, (uint32_t)(pc * 1024 + lane * 16), ring_lds + (uint32_t)((hf & 1) * 16384 + pc * 1024));
+            };
+            issue(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            for (int hf = 0; hf < NH; ++hf) {
+                if (hf + 1 < NH) issue(hf + 1);                         // the other half was released by the barrier that ended hf - 1
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+        } else {
+            // ---- projection waves: CBW 32-channel blocks x both row blocks; W2 global -> registers (fragment-packed per wave)
+            f32x16 acc[2][CBW];
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int j = 0; j < CBW; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[rb][j][e] = 0.f;
+            const uint4* const wsrc = bk.w2p + (size_t)wave * (CEXP / 16) * CBW * 64 + lane;      // [k16][cbw][lane]
+            constexpr int QS = CBW == 2 ? 4 : 2, NQ = 8 / QS;          // k16 steps per register batch (two batches in flight), batches per half
+            uint4 wq[2][QS][CBW];
+            auto load_q = [&](auto bufc, int k16_0) {
+                constexpr int buf = decltype(bufc)::value;
+#pragma unroll
+                for (int s = 0; s < QS; ++s)
+#pragma unroll
+                    for (int j = 0; j < CBW; ++j) wq[buf][s][j] = wsrc[((size_t)(k16_0 + s) * CBW + j) * 64];
+            };
+            const int a_sw[2] = {swz(r, h), swz(r, 2 + h)};
+            auto mma_q = [&](auto bufc, int hf, int qi) {              // k16 steps QS qi .. of half hf
+                constexpr int buf = decltype(bufc)::value;
+#pragma unroll
+                for (int s = 0; s < QS; ++s) {
+                    const int k16h = qi * QS + s;
+                    const int ktl = k16h >> 1, ks = k16h & 1;           // tile in the half, k16 half of the tile
+                    const unsigned char* at = lds + MB8_RING_OFF + (hf & 1) * 16384 + ktl * 4096 + a_sw[ks];
+                    const float* gs = gate + (4 * hf + ktl) * 32 + ks * 16 + 8 * h;
+                    const float4 g0 = *reinterpret_cast<const float4*>(gs), g1 = *reinterpret_cast<const float4*>(gs + 4);
+                    const uint4 a0 = T16<F16>::gate8(*reinterpret_cast<const uint4*>(at), g0, g1);
+                    const uint4 a1 = T16<F16>::gate8(*reinterpret_cast<const uint4*>(at + 2048), g0, g1);
+#pragma unroll
+                    for (int j = 0; j < CBW; ++j) {
+                        acc[0][j] = T16<F16>::mfma32(wq[buf][s][j], a0, acc[0][j]);
+                        acc[1][j] = T16<F16>::mfma32(wq[buf][s][j], a1, acc[1][j]);
+                    }
+                }
+            };
+            load_q(std::integral_constant<int, 0>{}, 0);
+            __builtin_amdgcn_s_barrier();                               // half 0 landed
+            for (int hf = 0; hf < NH; ++hf) {
+                mb8_static_for<0, NQ>([&](auto qc) {
+                    constexpr int qi = decltype(qc)::value;
+                    const int next = 8 * hf + (qi + 1) * QS;
+                    if (next < CEXP / 16) load_q(std::integral_constant<int, (qi + 1) & 1>{}, next);
+                    mma_q(std::integral_constant<int, qi & 1>{}, hf, qi);
+                });
+                __builtin_amdgcn_s_barrier();
+            }
+            stamp(7);
+            // ---- phase 6: bias + residual + one rounding (conv_epilogue's order) -> X in place, and the chain's last block -> global
+            const int b_img = blockIdx.x;
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                const int m = rb * 32 + r;
+#pragma unroll
+                for (int j = 0; j < CBW; ++j) {
+                    const int kt = wave * CBW + j;                      // output channel block = tile of the next block's X
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int n = kt * 32 + 8 * q + 4 * h;
+                        const float4 bs = *reinterpret_cast<const float4*>(bk.b2 + n);
+                        float v0 = acc[rb][j][4 * q] + bs.x, v1 = acc[rb][j][4 * q + 1] + bs.y, v2 = acc[rb][j][4 * q + 2] + bs.z, v3 = acc[rb][j][4 * q + 3] + bs.w;
+                        unsigned char* cell = lds + kt * 4096 + swz(m, q) + 8 * h;
+                        if (bk.residual) {
+                            const uint2 rr = *reinterpret_cast<const uint2*>(cell);
+                            v0 += T16<F16>::lo(rr.x); v1 += T16<F16>::hi(rr.x);
+                            v2 += T16<F16>::lo(rr.y); v3 += T16<F16>::hi(rr.y);
+                        }
+                        uint2 pk;
+                        pk.x = (uint32_t)T16<F16>::from_f32(v0) | ((uint32_t)T16<F16>::from_f32(v1) << 16);
+                        pk.y = (uint32_t)T16<F16>::from_f32(v2) | ((uint32_t)T16<F16>::from_f32(v3) << 16);
+                        *reinterpret_cast<uint2*>(cell) = pk;
+                        if (out_g) *reinterpret_cast<uint2*>(out_g + ((size_t)b_img * 64 + m) * COUT + n) = pk;
+                    }
+                }
+            }
+        }
+    }
+    stamp(8);
+    __syncthreads();                                                    // X complete; ring region free for the next block's E tiles
+    stamp(9);
+}
+
+template <bool F16>
+__global__ __launch_bounds__(MB8_NT) void mb8_chain_kernel(Mb8Args p) {
+    T16<F16>::enter();
+    unsigned char* const lds = conv_lds_dyn;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x;
+    // the sample's input rows -> X tiles: tile kt = channels 32 kt .., [64 rows][64 B] swizzled (gemm1x1's A image)
+    {
+        const int cin = p.cin0;
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(p.x) + (size_t)b * 64 * cin * 2;
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)lds;
+        const int npieces = (cin / 32) * 4;
+        for (int pc = wave; pc < npieces; pc += MB8_NW) {
+            const int kt = pc >> 2, row = 16 * (pc & 3) + (lane >> 2);
+            const int logical = (lane & 3) ^ ((row >> 2) & 3);
+            dma16_s(src, (uint32_t)(row * cin * 2 + kt * 64 + logical * 16), lds0 + (uint32_t)(pc * 1024));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    unsigned char* const dscr = reinterpret_cast<unsigned char*>(p.dscratch) + (size_t)b * p.dscratch_stride;
+    for (int i = 0; i < p.nblocks; ++i) {
+        const Mb8Block& bk = p.blocks[i];
+        // the chain's output = its last block's; store_all (tests): every block's output, out_block_stride elements apart
+        uint16_t* const out_g = p.store_all ? p.out + (size_t)i * p.out_block_stride : (i + 1 == p.nblocks ? p.out : nullptr);
+        // stamps: blocks 1 (384 -> 384) and nblocks - 2 (640 -> 640) of the first 32 workgroups, 32 slots each
+        uint64_t* const stamps = (p.stamps && b < 32 && (i == 1 || i == p.nblocks - 2)) ? p.stamps + ((size_t)b * 2 + (i == 1 ? 0 : 1)) * 32 : nullptr;
+        if (bk.cin == 384 && bk.cout == 384) mb8_block<384, 384, F16>(bk, lds, dscr, out_g, tid, stamps);
+        else if (bk.cin == 384) mb8_block<384, 640, F16>(bk, lds, dscr, out_g, tid, stamps);
+        else mb8_block<640, 640, F16>(bk, lds, dscr, out_g, tid, stamps);
+    }
+}
+
+// 16-bit weights [N][K] row-major -> MFMA fragment order for register streaming: groups of G 32-channel blocks, k16-major inside
+// a group: dst[((grp * K/16 + s) * G + g) * 64 + lane] (16 bytes) = W[(grp G + g) 32 + (lane & 31)][16 s + 8 (lane >> 5) .. + 8]
+__global__ void mb8_pack_frag_kernel(const uint16_t* w, uint4* dst, int N, int K, int G) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)N * K / 8;
+    if (i >= total) return;
+    const int lane = (int)(i & 63);
+    size_t t = i >> 6;
+    const int g = (int)(t % G); t /= G;
+    const int nk16 = K / 16;
+    const int s = (int)(t % nk16);
+    const int grp = (int)(t / nk16);
+    const int n = (grp * G + g) * 32 + (lane & 31), k = 16 * s + 8 * (lane >> 5);
+    dst[i] = *reinterpret_cast<const uint4*>(w + (size_t)n * K + k);
+}
+
+// squeeze-excite FC1 weights f32 [cse][C] -> [C/256][64 c4][cse][4]: thread j of a chunk reads 16 contiguous bytes per step,
+// neighbouring threads neighbouring addresses
+__global__ void mb8_pack_se1_kernel(const float* w1, float* dst, int cse, int C) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)cse * C) return;
+    const int e = (int)(i & 3);
+    size_t t = i >> 2;
+    const int j = (int)(t % cse); t /= cse;
+    const int c4 = (int)(t & 63);
+    const int kc = (int)(t >> 6);
+    dst[i] = w1[(size_t)j * C + kc * 256 + c4 * 4 + e];
+}
+
+}  // namespace
+
+int launch_mb8_pack_frag(const uint16_t* w, void* dst, int N, int K, int G, hipStream_t st) {
+    if (N % (32 * G) != 0 || K % 16 != 0) {
+        set_error("mb8_pack_frag: N=%d K=%d G=%d", N, K, G);
+        return ISB_ERR_INVALID;
+    }
+    const size_t total = (size_t)N * K / 8;
+    hipLaunchKernelGGL(mb8_pack_frag_kernel, dim3((unsigned)cdivz(total, 256)), dim3(256), 0, st, w, reinterpret_cast<uint4*>(dst), N, K, G);
+    ISB_LAUNCHED("mb8_pack_frag", st);
+    return ISB_OK;
+}
+
+int launch_mb8_pack_se1(const float* w1, float* dst, int cse, int C, hipStream_t st) {
+    if (C % 256 != 0) {
+        set_error("mb8_pack_se1: C=%d is not a multiple of 256", C);
+        return ISB_ERR_INVALID;
+    }
+    hipLaunchKernelGGL(mb8_pack_se1_kernel, dim3((unsigned)cdivz((size_t)cse * C, 256)), dim3(256), 0, st, w1, dst, cse, C);
+    ISB_LAUNCHED("mb8_pack_se1", st);
+    return ISB_OK;
+}
+
+int mb8_proj_group(int cout) { return cout == 384 ? 2 : 4; }           // Mb8Shape::CBW (the packing of Mb8Block.w2p)
+
+int launch_mb8_chain(const Mb8Args& a, hipStream_t st) {
+    if (a.B < 1 || a.nblocks < 1 || !a.blocks || !a.x || !a.out || !a.dscratch || (a.cin0 != 384 && a.cin0 != 640) ||
+        a.dscratch_stride < (size_t)64 * 6 * 640 * 2) {
+        set_error("mb8_chain: bad arguments (B=%d nblocks=%d cin0=%d)", a.B, a.nblocks, a.cin0);
+        return ISB_ERR_INVALID;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        ISB_HIP(hipFuncSetAttribute((const void*)mb8_chain_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, MB8_LDS));
+        ISB_HIP(hipFuncSetAttribute((const void*)mb8_chain_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, MB8_LDS));
+        attr_set = true;
+    }
+    if (a.f16) hipLaunchKernelGGL(mb8_chain_kernel<true>, dim3(a.B), dim3(MB8_NT), MB8_LDS, st, a);
+    else hipLaunchKernelGGL(mb8_chain_kernel<false>, dim3(a.B), dim3(MB8_NT), MB8_LDS, st, a);
+    ISB_LAUNCHED("mb8_chain", st);
+    return ISB_OK;
+}
+
+}  // namespace isb

@@ -29,7 +29,8 @@ struct BlockW {
     bool f16_in = false, f16 = false;
     int cin = 0, cout = 0, cexp = 0, stride = 1, cse = 0, in_hw = 0, out_hw = 0;
     ConvW expand, project;
-    DevBuf dw_w, dw_w16, dw_b, se_w1, se_b1, se_w2, se_b2;   // dw_w: the bf16-rounded taps as f32 (fused kernel), dw_w16: bf16
+    DevBuf dw_w, dw_w16, dw_b, se_w1, se_b1, se_w2, se_b2;   // dw_w: the 16-bit-rounded taps as f32, dw_w16: the 16-bit taps
+    DevBuf mb_w1p, mb_w2p, mb_se1p;   // stride-1 blocks of the 8 x 8 stages: the weights in mb8_chain_kernel's streaming layouts (conv_mb8.hip)
 };
 
 // public efficientnetv2-l table (mirrors isbfsar_amd/effnetv2.py::STAGES)
@@ -66,6 +67,17 @@ struct isb_hpe {
     isb_hpe_cfg cfg{};
     hipStream_t own_stream = nullptr;
     bool weights = false, jointmap = false;
+    // the stride-1 MBConv blocks of the two 8 x 8 stages (blocks mb8_first .. + mb8_count) as ONE launch (conv_mb8.hip: a workgroup
+    // owns a sample for the whole chain; bit-identical to the five-launch path, tested). MEASURED SLOWER (round 4: 22.0 vs 16.7 ms per
+    // 256-frame pose step; a 384 -> 2304 -> 384 block 545 k cycles against ~310 k for its five launches): every workgroup pulls ALL of
+    // a block's weights -- 3.5 MB 16-bit + 1.8 MB f32 squeeze-excite -- through its own CU's L2 port for 64 rows, twice the L2 -> CU
+    // bytes of the tiled GEMMs, and receives them at 5-15 B/clk (stamps: EXPERIMENTS.md round 4). Off by default; ISB_MB8=1 selects
+    // it (this round's open experiment: the packed weights are only built then).
+    bool mb8_on = false;
+    int mb8_min_batch = 48;
+    int mb8_first = -1, mb8_count = 0;
+    DevBuf mb8_desc;
+    DevBuf mb8_stamps;            // tuning probe (isb_debug_hpe_mb8_stamps)
     bool fuse_se = true;          // single-frame split-K projections compute their SE gate in the GEMM; ISB_FUSE_SE=0 disables (tests)
     // 16-bit storage type per stage: stages >= f16_from (index into kStages) and the 640 -> 1280 convolution keep activations AND
     // weights in IEEE fp16 instead of bf16 -- same MFMA rate, 3 more mantissa bits (per-stage error budget: DESIGN.md section 4,
@@ -282,6 +294,27 @@ int backbone_blocks(isb_hpe* h, Lane& L, hipStream_t st, int B, size_t i0, size_
     void*& Y = L.Y;
     for (size_t bi = i0; bi < std::min(i1, h->blocks.size()); ++bi) {
         BlockW& b = *h->blocks[bi];
+        if (h->mb8_on && h->mb8_count > 0 && B >= h->mb8_min_batch && (int)bi >= h->mb8_first && (int)bi < h->mb8_first + h->mb8_count) {
+            if ((int)bi > h->mb8_first) continue;         // the chain ran when its first block came up
+            Mb8Args a{};
+            a.x = (const uint16_t*)X; a.out = (uint16_t*)Y; a.dscratch = L.bufE.p; a.dscratch_stride = (size_t)64 * 3840 * 2;
+            a.blocks = h->mb8_desc.as<Mb8Block>(); a.nblocks = h->mb8_count; a.B = B; a.cin0 = b.cin; a.f16 = b.f16 ? 1 : 0;
+            a.stamps = h->mb8_stamps.p ? h->mb8_stamps.as<uint64_t>() : nullptr;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (h->prof) {
+                ISB_HIP(hipEventCreate(&e0));
+                ISB_HIP(hipEventCreate(&e1));
+                ISB_HIP(hipEventRecord(e0, st));
+            }
+            ISB_TRY(launch_mb8_chain(a, st));
+            if (h->prof) {
+                ISB_HIP(hipEventRecord(e1, st));
+                h->prof_ev.emplace_back(e0, e1);
+                h->prof_launches += 1;
+            }
+            std::swap(X, Y);
+            continue;
+        }
         const void* res = b.residual ? X : nullptr;
         if (b.fused) {
             if (b.cexp == b.cin) {
@@ -422,6 +455,8 @@ extern "C" int isb_hpe_create(const isb_hpe_cfg* cfg, isb_hpe** out) {
     ISB_TRY(h->zeros.alloc(256));
     ISB_HIP(hipMemset(h->zeros.p, 0, 256));
     if (const char* e = getenv("ISB_FUSE_SE")) h->fuse_se = atoi(e) != 0;
+    if (const char* e = getenv("ISB_MB8")) h->mb8_on = atoi(e) != 0;
+    if (const char* e = getenv("ISB_MB8_MIN_BATCH")) h->mb8_min_batch = std::max(1, atoi(e));
     h->f16_from = cfg->precision == 1 ? 7 : (cfg->precision == 3 ? 5 : 0);
     if (const char* e = getenv("ISB_HPE_ROI")) h->roi_mode = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("ISB_HPE_LANES")) h->n_lanes = std::max(1, std::min(kMaxLanes, atoi(e)));
@@ -565,6 +600,36 @@ extern "C" int isb_hpe_load_weights(isb_hpe* h, const void* blob, size_t nbytes)
         }
     }
     ISB_REQUIRE(hw == 8, ISB_ERR_WEIGHTS, "internal: backbone plan ends at %dx%d", hw, hw);
+    // the chain of stride-1 MBConv blocks on 8 x 8 maps (the tail of the network): weights in the fused kernel's streaming layouts
+    {
+        h->mb8_first = -1; h->mb8_count = 0;
+        std::vector<Mb8Block> desc;
+        for (size_t bi = 0; bi < h->blocks.size(); ++bi) {
+            BlockW& b = *h->blocks[bi];
+            const bool fits = h->mb8_on && !b.fused && b.stride == 1 && b.in_hw == 8 && b.f16_in == b.f16 && (b.cin == 384 || b.cin == 640) &&
+                              (b.cout == 384 || b.cout == 640) && b.cexp == 6 * b.cin && b.cse == b.cin / 4 && !(b.cin == 640 && b.cout == 384);
+            if (!fits) {
+                ISB_REQUIRE(desc.empty(), ISB_ERR_WEIGHTS, "internal: the 8 x 8 chain is not the tail of the block list (block %zu)", bi);
+                continue;
+            }
+            if (desc.empty()) h->mb8_first = (int)bi;
+            ISB_TRY(b.mb_w1p.alloc((size_t)b.cexp * b.cin * 2));
+            ISB_TRY(b.mb_w2p.alloc((size_t)b.cout * b.cexp * 2));
+            ISB_TRY(b.mb_se1p.alloc((size_t)b.cse * b.cexp * 4));
+            ISB_TRY(launch_mb8_pack_frag(b.expand.w16.as<uint16_t>(), b.mb_w1p.p, b.cexp, b.cin, 1, st));
+            ISB_TRY(launch_mb8_pack_frag(b.project.w16.as<uint16_t>(), b.mb_w2p.p, b.cout, b.cexp, mb8_proj_group(b.cout), st));
+            ISB_TRY(launch_mb8_pack_se1(b.se_w1.as<float>(), b.mb_se1p.as<float>(), b.cse, b.cexp, st));
+            Mb8Block d{};
+            d.w1p = (const uint4*)b.mb_w1p.p; d.b1 = b.expand.bias.as<float>(); d.dww = b.dw_w16.as<uint16_t>(); d.dwb = b.dw_b.as<float>();
+            d.se_w1p = b.mb_se1p.as<float>(); d.se_b1 = b.se_b1.as<float>(); d.se_w2t = b.se_w2.as<float>(); d.se_b2 = b.se_b2.as<float>();
+            d.w2p = (const uint4*)b.mb_w2p.p; d.b2 = b.project.bias.as<float>();
+            d.cin = b.cin; d.cout = b.cout; d.residual = b.residual ? 1 : 0;
+            desc.push_back(d);
+        }
+        ISB_HIP(hipStreamSynchronize(st));
+        h->mb8_count = (int)desc.size();
+        if (!desc.empty()) ISB_TRY(upload(h->mb8_desc, desc.data(), desc.size() * sizeof(Mb8Block)));
+    }
     ISB_TRY(upload_conv(m, "bbone.head", 1280, 1, 640, h->headconv, st, stream_f16));
     const BlobTensor *hwt, *hb;
     ISB_TRY(blob_get(m, "head.weight", 288, 1280, &hwt));
@@ -573,6 +638,26 @@ extern "C" int isb_hpe_load_weights(isb_hpe* h, const void* blob, size_t nbytes)
     ISB_TRY(upload(h->head_b, hb->data, 288 * 4));
     h->weights = true;
     return ISB_OK;
+    });
+}
+
+// tuning probe: enable != 0 arms the s_memtime stamps of the fused 8 x 8 chain (the next forward passes write them), enable == 0
+// copies them out ([32 workgroups][2 blocks][32 marks] uint64) and disarms
+extern "C" int isb_debug_hpe_mb8_stamps(isb_hpe* h, int32_t enable, uint64_t* host_out) {
+    return isb::guard([&]() -> int {
+        ISB_REQUIRE(h, ISB_ERR_INVALID, "null handle");
+        ISB_HIP(hipSetDevice(h->cfg.device));
+        ISB_HIP(hipDeviceSynchronize());
+        const size_t bytes = (size_t)32 * 2 * 32 * 8;
+        if (enable) {
+            ISB_TRY(h->mb8_stamps.alloc(bytes));
+            ISB_HIP(hipMemset(h->mb8_stamps.p, 0, bytes));
+        } else {
+            ISB_REQUIRE(host_out && h->mb8_stamps.p, ISB_ERR_INVALID, "stamps were not armed");
+            ISB_HIP(hipMemcpy(host_out, h->mb8_stamps.p, bytes, hipMemcpyDeviceToHost));
+            h->mb8_stamps = DevBuf();
+        }
+        return ISB_OK;
     });
 }
 

@@ -179,6 +179,38 @@ int launch_conv_expand_dw(const ConvArgs& a, hipStream_t st);
 int launch_fused_mb(const ConvArgs& a, hipStream_t st);
 int launch_splitk_reduce(const ConvArgs& a, hipStream_t st);
 
+// ---------------------------------------------------------------- conv_mb8.hip: the stride-1 MBConv blocks of the 8 x 8 stages as one launch
+struct Mb8Block {           // one block of the chain (device-resident array); every pointer device memory
+    const uint4* w1p;       // expand weights [Cexp][Cin] 16-bit (BN scale folded), fragment-packed (launch_mb8_pack_frag, G = 1)
+    const float* b1;        // [Cexp] folded-BN shift of the expand convolution
+    const uint16_t* dww;    // depthwise taps [9][Cexp] 16-bit, tap-major (BlockW.dw_w16)
+    const float* dwb;       // [Cexp]
+    const float* se_w1p;    // squeeze-excite FC1 weights, packed (launch_mb8_pack_se1)
+    const float* se_b1;     // [cse]
+    const float* se_w2t;    // [cse][Cexp] (se.w2 transposed, as SeFcArgs.w2t)
+    const float* se_b2;     // [Cexp]
+    const uint4* w2p;       // projection weights [Cout][Cexp] 16-bit, fragment-packed (G = mb8_proj_group(Cout))
+    const float* b2;        // [Cout]
+    int cin, cout;          // 384 -> 384, 384 -> 640 or 640 -> 640 (Cexp = 6 Cin, cse = Cin / 4)
+    int residual;           // out += in (Cin == Cout)
+    int pad_;
+};
+struct Mb8Args {
+    const uint16_t* x;      // [B][64][cin0] 16-bit: input of the first block (NHWC, 8 x 8 map)
+    uint16_t* out;          // [B][64][cout of the last block]; store_all: block i's output at out + i * out_block_stride
+    void* dscratch;         // per sample dscratch_stride bytes (>= 64 x 3840 x 2): the depthwise outputs as projection A tiles
+    size_t dscratch_stride;
+    const Mb8Block* blocks;
+    int nblocks, B, cin0, f16;
+    int store_all;
+    size_t out_block_stride;
+    uint64_t* stamps;       // tuning probe or null: [32 workgroups][2 blocks][32] s_memtime marks of the phases (tools/exp_mb8.py)
+};
+int launch_mb8_chain(const Mb8Args& a, hipStream_t st);
+int launch_mb8_pack_frag(const uint16_t* w, void* dst, int N, int K, int G, hipStream_t st);
+int launch_mb8_pack_se1(const float* w1, float* dst, int cse, int C, hipStream_t st);
+int mb8_proj_group(int cout);
+
 struct DwArgs {
     const uint16_t* in;     // bf16 [B,H,W,C]
     const uint16_t* w;      // bf16 [9][C] tap-major, BN scale folded (rounded once at load, like every conv weight)

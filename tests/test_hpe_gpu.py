@@ -828,3 +828,37 @@ def test_submitted_host_batches_are_bit_identical(bbone_state, assets):
         assert want[0][1].sum() > 0
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("precision", ["f16", "bf16"])
+def test_fused_8x8_chain_is_bit_identical_to_the_five_launch_path(bbone_state, assets, monkeypatch, precision):
+    """conv_mb8.hip: the 31 stride-1 MBConv blocks of the two 8 x 8 stages as ONE launch (a workgroup owns a sample for the whole
+    chain: expand from register-streamed weights, depthwise from LDS, squeeze-excite in the workgroup, gated projection, residual
+    in LDS). Every sum keeps the order of the five-launch path, so features and poses are the same BITS. The chain measured 2x
+    SLOWER than the five launches (EXPERIMENTS.md round 4: per-sample weight streams are bound by L2 -> CU delivery), so it is off by
+    default and ISB_MB8=1 (read when the engine is created) selects it."""
+    from isbfsar_amd.hpe_engine import HpeEngine
+    from oracle import hpe_oracle as ho
+    W, st = assets
+    idx = st["smpl+head_30"]["indices"]
+    B = 70                                  # above the chain's batch threshold, not a multiple of anything
+    fr, bb = synth.frames(B, seed=3), synth.bboxes(B, seed=3)
+    crops = np.stack([ho.warp(fr[b], ho.crop_params(bb[b], _K())[2][0]) for b in range(4)])
+    crops = np.concatenate([crops] * 18)[:B]
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("ISB_MB8", flag)
+        e = HpeEngine(device=0, max_batch=128, precision=precision)
+        try:
+            e.set_joint_map(W, idx)
+            e.load_weights(bbone_state)
+            feat, logits = e.backbone(crops)
+            joints, valid = e.forward(fr, bb)
+            again, _ = e.forward(fr, bb)
+        finally:
+            e.close()
+        assert np.array_equal(joints, again)
+        res[flag] = (feat, logits, joints, valid)
+    assert np.isfinite(res["1"][0]).all() and float(np.abs(res["1"][0]).max()) > 0
+    for a, b in zip(res["1"], res["0"]):
+        assert np.array_equal(a, b)
