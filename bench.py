@@ -255,6 +255,15 @@ def main():
     # would wait on forever; only rank 0's numbers are reported
     roof = W.roofline(max(1, min(args.steps, 3)))
     barrier()
+    # N > 1: the gathered records of one step against an unsharded recomputation (rank 0), and RCCL's own count of the ranks
+    gather_check, rccl_ranks = None, None
+    if dist_on:
+        g = getattr(W, "gather", None)
+        if g is not None:
+            rccl_ranks = g.rccl_ranks()
+        if hasattr(W, "verify_gather"):
+            gather_check = W.verify_gather(rank, 2 if force_dist else world) if not force_dist else None
+        barrier()
     # extra measurements of the same run (N = 1): the fp32-grade AR precision, configs[3]'s whole 2048-frame batch
     extras = None
     if world == 1 and not force_dist and not args.no_extras and hasattr(W, "extras"):
@@ -281,11 +290,14 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": W.precision if hasattr(W, "precision") else "bf16", "data": "synthetic",
-            "config": dict(W.config(world), **(extras or {})), "roofline": roof, "cpu_baseline": cpu,
+            "config": dict(W.config(world), rccl_ranks=rccl_ranks, **(extras or {})), "roofline": roof, "cpu_baseline": cpu,
             # error half of BASELINE.json's metric ("...; open-set score L2 vs ref"): GPU outputs against the CPU oracle
             # on the cpu_baseline sample (same inputs); null when the CPU leg is skipped (N > 1, --no-cpu-baseline)
             "parity": getattr(W, "parity", None),
             "world_size": world, "devices": devices,
+            # N > 1: ranks in the library's RCCL communicator as ncclCommCount reports them (null: no RCCL collective in this run)
+            # and the bit-for-bit check of the gathered records against an unsharded recomputation
+            "rccl_ranks": rccl_ranks, "gather_check": gather_check,
         }
         print(json.dumps(line), flush=True)
     if dist_on:

@@ -300,6 +300,38 @@ class PipelineWorkload(_HpeBase):
     def roofline(self, steps):
         return self._hpe_roofline(steps)
 
+    def _initial_ring(self, rank):
+        hist = synth.skeleton_windows(self.N_CAM, self.L - 1, self.J, seed=555 + rank).reshape(self.N_CAM, self.L - 1, self.J, 3)
+        ring = self.torch.zeros((self.N_CAM, self.L - 1 + self.steps_per_cam, self.J, 3), dtype=self.torch.float32, device=f"cuda:{self.dev}")
+        ring[:, : self.L - 1] = self.torch.from_numpy(hist).cuda(self.dev)
+        return ring
+
+    def verify_gather(self, rank, world):
+        """N > 1 (every rank calls this: one collective step): the all-gathered records of one step from a known state must be,
+        BIT FOR BIT, what ONE process computes for every rank's frames without any collective (SURVEY.md 8e correctness check).
+        Rank 0 recomputes the other ranks' shards locally (their inputs are seeded by rank) and compares."""
+        torch = self.torch
+        self.ring = self._initial_ring(rank)
+        self.step()
+        torch.cuda.synchronize()
+        got = self.out
+        if rank != 0 or not torch.is_tensor(got):
+            return None
+        ref = []
+        for q in range(world):
+            frames = torch.from_numpy(synth.frames(self.B, seed=10_000 * q)).cuda(self.dev)
+            bbox = torch.from_numpy(synth.bboxes(self.B, seed=10_000 * q)).cuda(self.dev)
+            ring = self._initial_ring(q)
+            joints, _ = self.hpe.forward(frames, bbox)
+            ring[:, self.L - 1:] = joints.view(self.N_CAM, self.steps_per_cam, self.J, 3)
+            logits, is_true, embed = self.ar.infer(pose_windows(ring, self.L), want_embed=True)
+            ref.append(pack_records(logits, is_true, embed))
+        ref = torch.cat(ref, dim=0)
+        torch.cuda.synchronize()
+        same = bool(got.shape == ref.shape and torch.equal(got, ref))
+        return {"gathered_records": list(got.shape), "bit_equal_to_unsharded": same,
+                "how": "one step from the initial pose rings; rank 0 recomputed every rank's shard (inputs seeded by rank) without a collective"}
+
     def _timed(self, steps, warm=2):
         torch = self.torch
         for _ in range(warm):
@@ -351,6 +383,8 @@ class PipelineWorkload(_HpeBase):
             out["ms_per_step_bf16x3"] = round(dt * 1e3, 4)
             self.ar.close() if hasattr(self.ar, "close") else None
             self.ar = ar0
+        if self.B <= 256:
+            out.update(self.hpe_precision_report())
         if self.B == 256 and not args.batch:
             import copy
             a2 = copy.copy(args)
@@ -362,6 +396,59 @@ class PipelineWorkload(_HpeBase):
                                                "micro-batches of up to 1024 frames"}
             del big
             self.torch.cuda.empty_cache()
+        return out
+
+    def hpe_precision_report(self, n=8):
+        """The pose backbone's 16-bit storage layouts side by side: the pipeline's rate with each
+        (value_hpe_<precision>; the headline runs the default, fp16 everywhere) and every layout's distance to the fp32 CPU
+        definition on BOTH synthetic weight profiles -- "default" (near-constant features: benign) and "signal" (activations that
+        carry the input, peaked heat-maps: the regime of a trained MetrABS) -- for the first n frames of the batch."""
+        from oracle import hpe_oracle as ho
+        from oracle.effnetv2_oracle import EffNetV2LOracle
+        torch = self.torch
+        torch.set_num_threads(usable_cores())
+        K = ho.intrinsics_matrix(384.025146484375, 384.025146484375, 319.09661865234375, 237.75723266601562)
+        W = np.load(os.path.join(_ASSETS, "32_to_122.npy"))
+        fr, bb = self.frames_host[:n], self.bbox_host[:n]
+        crops = np.stack([ho.warp(fr[j], ho.crop_params(bb[j], K)[2][0]) for j in range(n)])
+        out, parity = {}, {}
+        states = {"default": self.bb_state, "signal": effnetv2.make_state(0, "signal", head_gain=0.5)}
+        refs = {}
+        for prof, state in states.items():
+            net = EffNetV2LOracle(state, "f32")
+            lg = net.head(net.backbone(crops))
+            p2, p3 = ho.decode(lg)
+            poses = [ho.postprocess(lg[j:j + 1], *ho.crop_params(bb[j], K)[:2], W, None) for j in range(n)]
+            refs[prof] = (p3, poses)
+        hpe0 = self.hpe
+        for prec in ("f16", "bf16_f16tail", "bf16"):
+            if prec == hpe0.precision:
+                e = hpe0
+            else:
+                e = HpeEngine(device=self.dev, max_batch=hpe0.max_batch, precision=prec)
+                e.set_joint_map(W, None)
+            for prof, state in states.items():
+                if not (e is hpe0 and prof == "default"):
+                    e.load_weights(state)
+                joints, valid = e.forward(fr, bb)
+                _, lg = e.backbone(crops)
+                p3_ref, poses = refs[prof]
+                ok = [j for j in range(n) if poses[j] is not None and valid[j]]
+                g = joints[ok].astype(np.float64)
+                ref = np.stack([poses[j] for j in ok])
+                parity.setdefault(prof, {})[prec] = {
+                    "decoded3d_maxabs": float(np.abs(ho.decode(lg)[1] - p3_ref).max()),
+                    "joints_maxabs": float(np.abs(g - ref).max()),
+                    "joints_rootcentred_maxabs": float(np.abs((g - g[:, :1]) - (ref - ref[:, :1])).max()), "n_frames": len(ok)}
+            e.load_weights(self.bb_state)
+            if e is not hpe0:
+                self.hpe = e
+                dt = self._timed(5)
+                out[f"value_hpe_{prec}"] = round(self.B / dt, 3)
+                out[f"ms_per_step_hpe_{prec}"] = round(dt * 1e3, 4)
+                self.hpe = hpe0
+                e.close()
+        out["parity_hpe_precisions_vs_fp32_oracle"] = parity
         return out
 
     def cpu_baseline(self, sample, iters=10):

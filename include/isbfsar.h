@@ -368,6 +368,8 @@ typedef struct isb_dist isb_dist;
 int isb_dist_unique_id(void* h_id_out /* ISB_DIST_ID_BYTES */);
 int isb_dist_create(const void* h_unique_id, int32_t rank, int32_t world, int32_t device, isb_dist** out);
 void isb_dist_destroy(isb_dist* d);
+/* ranks in the communicator as RCCL reports them (ncclCommCount) -- cited by bench.py's config.rccl_ranks */
+int isb_dist_comm_count(const isb_dist* d, int32_t* n_ranks);
 int isb_dist_info(const isb_dist* d, int32_t* rank, int32_t* world);
 /* d_recv[r * bytes_per_rank .. ] = rank r's d_send[0 .. bytes_per_rank) for every r; asynchronous on `stream`
  * (ncclAllGather over xGMI). Equal block sizes on every rank (ragged shards: pad to the largest, as the

@@ -89,6 +89,7 @@ SIGNATURES = {
     "isb_dist_create": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P)]),
     "isb_dist_destroy": (None, [_P]),
     "isb_dist_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "isb_dist_comm_count": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "isb_dist_all_gather": (C.c_int, [_P, _P, _P, C.c_size_t, _P]),
     "isb_det_create": (C.c_int, [C.POINTER(isb_det_cfg), C.POINTER(_P)]),
     "isb_det_destroy": (None, [_P]),

@@ -30,6 +30,7 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     std::string why;
 };
 
@@ -54,6 +55,7 @@ Rccl& rccl() {
         x.CommDestroy = (decltype(x.CommDestroy))dlsym(x.so, "ncclCommDestroy");
         x.AllGather = (decltype(x.AllGather))dlsym(x.so, "ncclAllGather");
         x.GetErrorString = (decltype(x.GetErrorString))dlsym(x.so, "ncclGetErrorString");
+        x.CommCount = (decltype(x.CommCount))dlsym(x.so, "ncclCommCount");
         if (!x.GetUniqueId || !x.CommInitRank || !x.CommDestroy || !x.AllGather) x.why = "librccl.so lacks the ncclAllGather entry points";
         return x;
     }();
@@ -121,6 +123,19 @@ extern "C" int isb_dist_all_gather(isb_dist* d, const void* d_send, void* d_recv
         ISB_HIP(hipSetDevice(d->device));
         // byte granularity: the records are opaque to the collective (no reduction anywhere on this path)
         ISB_NCCL(rccl().AllGather(d_send, d_recv, bytes_per_rank, kNcclInt8, d->comm, (hipStream_t)stream));
+        return ISB_OK;
+    });
+}
+
+// the number of ranks RCCL itself holds for the communicator (ncclCommCount): what a scaling record cites as proof that the
+// collective really spanned N processes, not what the launcher's flags said
+extern "C" int isb_dist_comm_count(const isb_dist* d, int32_t* n_ranks) {
+    return isb::guard([&]() -> int {
+        ISB_REQUIRE(d && n_ranks, ISB_ERR_INVALID, "null argument");
+        ISB_REQUIRE(rccl().CommCount, ISB_ERR_STATE, "librccl.so lacks ncclCommCount");
+        int n = 0;
+        ISB_NCCL(rccl().CommCount(d->comm, &n));
+        *n_ranks = n;
         return ISB_OK;
     });
 }

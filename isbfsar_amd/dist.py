@@ -65,6 +65,12 @@ class RecordGather:
         _lib.check(_lib.lib().isb_dist_create(ident[0], self.rank, self.world, device, C.byref(self._h)), "isb_dist_create")
         self._torch = torch
 
+    def rccl_ranks(self) -> int:
+        """ranks in the communicator as RCCL itself counts them (ncclCommCount)"""
+        n = C.c_int32()
+        self._lib.check(self._lib.lib().isb_dist_comm_count(self._h, C.byref(n)), "isb_dist_comm_count")
+        return int(n.value)
+
     def all_gather(self, rec):
         """rec [n, w] (equal n on every rank) -> [world * n, w], on the current stream"""
         torch = self._torch
