@@ -7,7 +7,9 @@ namespace isb {
 
 // HALO (stride 1, 96 input channels, 32-wide maps, 128-pixel tiles = four image rows: the body blocks of stage 3): the
 // A fragments come from the tile's input halo in LDS (6 rows x 34 pixels, 256-byte pixel rows of which 192 B are used,
-// chunk slot = chunk ^ (pixel & 7)), copied once, like fused_mb_kernel<.., HALO>; the k loop streams only the weights
+// chunk slot = chunk ^ (pixel & 15): 16 consecutive pixels of one chunk in 16 different 16-byte slots of the 64 banks -- with
+// `pixel & 7` every A read took two passes, SQ_LDS_BANK_CONFLICT 23 % of the LDS-active cycles), copied once, like
+// fused_mb_kernel<.., HALO>; the k loop streams only the weights
 // (12 instead of 20 KiB per k-step). Same (tap, channel) order: bit-identical.
 template <int TM, int TN, int WGM, int WGN, bool HALO = false, bool F16 = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_dma_kernel(ConvArgs p) {
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_dma_kernel(ConvArgs p)
             const int hp = i * 4 + (lane >> 4);
             const int hy = hp / HWD, hx = hp - hy * HWD;
             const int y = y0 - 1 + hy, x = hx - 1;
-            const int chunk = (lane & 15) ^ (hp & 7);
+            const int chunk = (lane & 15) ^ (hp & 15);
             const bool ok = chunk < 12 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)HW_;
             // relative to the shifted base (in - (W + 1) pixels): pixel (y, x) sits at ((b H + y + 1) W + x + 1) pixels
             const uint32_t voff = ok ? (uint32_t)((b * p.H + y + 1) * HW_ + x + 1) * 192u + (uint32_t)chunk * 16u : 0x80000000u;
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_dma_kernel(ConvArgs p)
             bf16x8 af[TM], bfr[TN];
             if constexpr (HALO) {
                 const int hp = hp0 + h_off;
-                af[0] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + hp * 256 + (((4 * h_cb + 2 * ks + h) ^ (hp & 7)) << 4)));
+                af[0] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + hp * 256 + (((4 * h_cb + 2 * ks + h) ^ (hp & 15)) << 4)));
             } else {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -205,7 +207,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_dma_kernel(ConvArgs p)
 // nine taps are read from the ring directly -- lane r's pixel shifted by the tap is just another 64-byte LDS row --
 // and the weights (18 KiB) live in registers as 18 B fragments per lane for the whole band.
 // LDS rows are pixels (144 per image row: x = -1 .. 142, nine 1-KiB pieces); chunk slot = logical chunk ^
-// ((pixel >> 1) & 3): eight consecutive pixels hit all 32 banks for any tap shift. A step's 256 outputs are
+// ((pixel >> 2) & 3): the 16 lanes a ds_read_b128 serves at a time (16 consecutive pixels, one chunk) hit 16 different 16-byte
+// slots of the 64 banks for any tap shift (round 4; `(pixel >> 1) & 3` let pixels p and p + 8 collide: SQ_LDS_BANK_CONFLICT 52 %
+// of this kernel's LDS-active cycles). A step's 256 outputs are
 // consecutive NHWC pixels, so the shared epilogue (bias, SiLU, residual, 16-byte row stores) applies unchanged.
 // Sums run in the (tap, channel) order of the implicit-GEMM kernels: bit-identical results.
 // -------------------------------------------------------------------------------------------
@@ -239,7 +243,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c32_rows_kernel(ConvArgs p, in
             const int y = y_first + row;
             const int hx = piece * 16 + (lane >> 2), x = hx - 1;
             const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)W_;
-            const int chunk = (lane & 3) ^ ((hx >> 1) & 3);
+            const int chunk = (lane & 3) ^ ((hx >> 2) & 3);
             const uint32_t voff = ok ? (uint32_t)((b * p.H + y) * W_ + x) * 64u + (uint32_t)chunk * 16u : 0x80000000u;
             dma16_buf(rsrc, voff, 0u, lds_base + (uint32_t)(((y + 1) % 6) * HALO_ROWB + piece * 1024));
         }
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c32_rows_kernel(ConvArgs p, in
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int px = wave * 32 + k * 16 + (lane >> 2);
-            const int chunk = (lane & 3) ^ ((px >> 1) & 3);
+            const int chunk = (lane & 3) ^ ((px >> 2) & 3);
             const uint32_t voff = (uint32_t)((b * p.H + y0) * W_ + px) * 64u + (uint32_t)chunk * 16u;
             dma16_buf(rres, voff, 0u, lds_base + (uint32_t)(HALO_RING + (wave * 2 + k) * 1024));
         }
@@ -273,7 +277,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c32_rows_kernel(ConvArgs p, in
     }
     const int q = wave * 32 + r;                        // output pixel of the step
     const int oy = wave >> 2, ox = q & (W_ - 1);        // waves 0-3: first output row, 4-7: second
-    const int swq = (q >> 1) & 3;
+    const int swq = (q >> 2) & 3;
     uint16_t* const out16 = reinterpret_cast<uint16_t*>(p.out);
     for (int y0 = ys; y0 < ye; y0 += 2) {
         // the rows of this step have landed: behind them in the queue are only the previous step's two row stores
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c32_rows_kernel(ConvArgs p, in
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int hx = ox + kx;
-                const int sw = (hx >> 1) & 3;
+                const int sw = (hx >> 2) & 3;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     const bf16x8 af = __builtin_bit_cast(
@@ -332,7 +336,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c32_rows_kernel(ConvArgs p, in
         for (int k = 0; k < 2; ++k) {
             const int px = wave * 32 + k * 16 + (lane >> 2), cc = lane & 3;
             const uint4 v = *reinterpret_cast<const uint4*>(Cs + px * 64 + cc * 16);
-            *reinterpret_cast<uint4*>(out16 + (m0 + px) * 32 + ((cc ^ ((px >> 1) & 3)) << 3)) = v;
+            *reinterpret_cast<uint4*>(out16 + (m0 + px) * 32 + ((cc ^ ((px >> 2) & 3)) << 3)) = v;
         }
         if (more && has_res) load_res(y0 + 2);
     }

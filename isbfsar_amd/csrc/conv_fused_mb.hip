@@ -20,7 +20,9 @@ namespace isb {
 // bytes per k-step (tools/kstep_probe.py) and a third of them are im2col rows of A. The tile's 128 pixels are two image
 // rows; their input HALO (4 rows x 66 pixels x 128 B = 33 KiB, out-of-image pixels zero-filled by the buffer bounds
 // check) is copied to LDS once and the A fragments of the 18 k-steps are read from it -- a tap shift is just another
-// 128-byte LDS row, chunk slot = chunk ^ (pixel & 7) keeps eight consecutive pixels on 32 different banks. The k loop
+// 128-byte LDS row, chunk slot = chunk ^ ((pixel >> 1) & 7): a ds_read_b128 is served 16 lanes at a time from 64 banks (256 B), and
+// 16 consecutive pixels of one chunk then sit in 16 different 16-byte slots (round 4; with `pixel & 7` pixels p and p + 8 shared a
+// slot: SQ_LDS_BANK_CONFLICT 19 % of the LDS-active cycles of this kernel, every A read two passes). The k loop
 // then streams only the weights: 16 instead of 24 KiB per k-step. Same (tap, channel) order: bit-identical.
 template <int WGM, int TN, int WPR, bool HALO = false, bool F16 = false>
 __global__ __launch_bounds__(128 * WGM) void fused_mb_kernel(ConvArgs p) {
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(128 * WGM) void fused_mb_kernel(ConvArgs p) {
             const int hy = hp / HWD, hx = hp - hy * HWD;
             const int y = y0 - 1 + hy, x = hx - 1;
             const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)HW_;
-            const uint32_t chunk = (uint32_t)((lane & 7) ^ (hp & 7));
+            const uint32_t chunk = (uint32_t)((lane & 7) ^ ((hp >> 1) & 7));
             // relative to the shifted base (in - (W + 1) pixels): pixel (y, x) sits at ((b H + y + 1) W + x + 1) pixels
             const uint32_t voff = ok ? (uint32_t)((b * p.H + y + 1) * HW_ + x + 1) * 128u + chunk * 16u : 0x80000000u;
             dma16_buf(rsrc, voff, 0u, ldsA + i * 1024);
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(128 * WGM) void fused_mb_kernel(ConvArgs p) {
             bf16x8 af;
             if constexpr (HALO) {
                 const int hp = hp0 + h_off;
-                af = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + hp * 128 + (((4 * buf + 2 * ks + h) ^ (hp & 7)) << 4)));
+                af = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + hp * 128 + (((4 * buf + 2 * ks + h) ^ ((hp >> 1) & 7)) << 4)));
             } else {
                 af = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + a_sw[ks] + buf * BUF));
             }

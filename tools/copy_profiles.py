@@ -22,6 +22,8 @@ for src, dst in (("bench_ar_bf16x3.json", "bench_ar_bf16x3.json"), ("bench_hpe_h
                  ("bench_hpe_host_wholeframes.json", "bench_hpe_host_input_wholeframes.json"),
                  ("bench_hpe_host_pipelined.json", "bench_hpe_host_input_pipelined.json"),
                  ("bench_hpe_bf16_everywhere.json", "bench_hpe_bf16_everywhere.json"), ("estimate_latency.json", "estimate_latency.json"),
+                 ("bench_hpe_bf16_f16tail.json", "bench_hpe_bf16_f16tail.json"), ("bench_ar_bf16.json", "bench_ar_bf16.json"),
+                 ("lds_hpe.json", "lds_counters_hpe_b256_onelane.json"),
                  ("prof_det/run_kernel_stats.csv", "det_b256_kernel_stats.csv")):
     if os.path.exists(f"{G}/{src}"):
         shutil.copy(f"{G}/{src}", f"{P}/{tag}_{dst}")

@@ -14,10 +14,12 @@ timeout -k 10 300 python bench.py --workload ar --precision bf16x3 --no-cpu-base
 timeout -k 10 300 python bench.py --workload hpe --host-input --no-cpu-baseline --min-gpu-seconds 0 2>/dev/null | tail -1 > gpurun_out/bench_hpe_host.json
 ISB_HPE_ROI=0 timeout -k 10 300 python bench.py --workload hpe --host-input --no-cpu-baseline --min-gpu-seconds 0 2>/dev/null | tail -1 > gpurun_out/bench_hpe_host_wholeframes.json
 timeout -k 10 300 python bench.py --workload hpe --host-input --pipelined --no-cpu-baseline --min-gpu-seconds 0 2>/dev/null | tail -1 > gpurun_out/bench_hpe_host_pipelined.json
-ISB_HPE_F16=0 timeout -k 10 300 python bench.py --workload hpe --min-gpu-seconds 0 2>/dev/null | tail -1 > gpurun_out/bench_hpe_bf16_everywhere.json
+timeout -k 10 300 python bench.py --workload hpe --hpe-precision bf16 --min-gpu-seconds 0 2>/dev/null | tail -1 > gpurun_out/bench_hpe_bf16_everywhere.json
+timeout -k 10 300 python bench.py --workload hpe --hpe-precision bf16_f16tail --min-gpu-seconds 0 2>/dev/null | tail -1 > gpurun_out/bench_hpe_bf16_f16tail.json
+timeout -k 10 300 python bench.py --workload ar --precision bf16 --no-cpu-baseline --min-gpu-seconds 0 2>/dev/null | tail -1 > gpurun_out/bench_ar_bf16.json
 timeout -k 10 400 python bench.py --workload pipeline --batch 2048 --steps 3 --warmup 1 --no-cpu-baseline --no-extras --min-gpu-seconds 0 2>/dev/null | tail -1 > gpurun_out/bench_pipe_b2048.json
 timeout -k 10 300 python tools/estimate_latency.py > gpurun_out/estimate_latency.json 2>gpurun_out/estimate_latency.err || true
-for f in ar_bf16x3 hpe_host hpe_host_wholeframes hpe_host_pipelined hpe_bf16_everywhere pipe_b2048; do python3 -c "import json;d=json.load(open('gpurun_out/bench_$f.json'));print('$f',d['value'],d['unit'],d['ms_per_step'],'ms')"; done
+for f in ar_bf16x3 ar_bf16 hpe_host hpe_host_wholeframes hpe_host_pipelined hpe_bf16_everywhere hpe_bf16_f16tail pipe_b2048; do python3 -c "import json;d=json.load(open('gpurun_out/bench_$f.json'));print('$f',d['value'],d['unit'],d['ms_per_step'],'ms')"; done
 echo "== kernel stats (pipeline)"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_pipe -o run -- python3 bench.py --workload pipeline --steps 5 --warmup 2 --no-cpu-baseline --no-extras --min-gpu-seconds 0 > gpurun_out/prof_pipe.log 2>&1
 echo "== kernel stats (hpe, one lane: every convolution launch is a 256-frame launch, as in bench.py's roofline pass)"
@@ -41,4 +43,7 @@ ISB_HPE_LANES=1 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_IN
 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_mfma_ar -o run -- python3 bench.py --workload ar --steps 1 --warmup 1 --no-cpu-baseline --no-extras --min-gpu-seconds 0 > gpurun_out/pmc_mfma_ar.log 2>&1
 python3 tools/collect_mfma.py gpurun_out/mfma_hpe.json gpurun_out/pmc_mfma_hpe/run_counter_collection.csv
 python3 tools/collect_mfma.py gpurun_out/mfma_ar.json gpurun_out/pmc_mfma_ar/run_counter_collection.csv
+echo "== SQ counters of the three MFMA-bound early-stage kernels (VERDICT r3 item 5), own pass"
+ISB_HPE_LANES=1 timeout -k 10 300 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d gpurun_out/pmc_lds_hpe -o run -- python3 bench.py --workload hpe --steps 1 --warmup 1 --no-cpu-baseline --no-extras --min-gpu-seconds 0 > gpurun_out/pmc_lds_hpe.log 2>&1 || true
+python3 tools/collect_lds.py gpurun_out/lds_hpe.json gpurun_out/pmc_lds_hpe/run_counter_collection.csv || true
 echo done
