@@ -11,9 +11,9 @@ sc = np.ones(cout, np.float32); sh = np.zeros(cout, np.float32)
 mode = sys.argv[1] if len(sys.argv) > 1 else "stamp"
 if mode == "stamp":
     _, ms = conv_debug(x, w, sc, sh, 1, 1, 1, None, None, variant=900000 + int(os.environ.get('EXP_V', '181')), iters=5)
-    print(f"stamped v181 probe={os.environ.get('ISB_WS_PROBE','0')} {ms*1e3:7.1f} us", flush=True)
+    print(f"stamped v181 {ms*1e3:7.1f} us", flush=True)
 else:
     for act in (1, 0):
         conv_debug(x, w, sc, sh, 1, 1, act, None, None, variant=181, iters=5)
         _, ms = conv_debug(x, w, sc, sh, 1, 1, act, None, None, variant=181, iters=20)
-        print(f"v181 probe={os.environ.get('ISB_WS_PROBE','0')} act={act} {ms*1e3:7.1f} us", flush=True)
+        print(f"v181 act={act} {ms*1e3:7.1f} us", flush=True)
