@@ -446,6 +446,206 @@ __global__ __launch_bounds__(MB8_NT) void mb8_chain_kernel(Mb8Args p) {
     }
 }
 
+// -------------------------------------------------------------------------------------------------------------------
+// The FRONT HALF of a stride-1 MBConv block on 8 x 8 maps in one launch: 1x1 expand + BN + SiLU -> depthwise 3x3 + BN + SiLU -> D
+// (NHWC, what the gated projection reads) + the squeeze-excite pool. The expanded tensor never leaves the chip.
+// Tiling as in the weights-stationary expand GEMM (conv_ws.hip), where a 64-row tile IS one sample: a workgroup of 4 waves (one per
+// SIMD, the whole register file each) owns a 128-channel slice of the expanded tensor for its whole life -- wave w keeps the weights
+// of its 32 channels for all of K in registers -- and walks the samples q, q + Q, ...; a sample's 64 x Cin input tile arrives in LDS
+// by LDS-DMA, double-buffered, one barrier per sample. What differs from the per-sample chain above (and from rounds 1-2's fused
+// fronts on the tile GEMM): N IS tiled across CUs, so the L2 -> CU traffic is the expand GEMM's (activations re-read per slice), and
+// the vector work -- two SiLUs and nine taps per expanded element, 4 650 cycles per (sample, 32 channels) against 1 536 of MFMA -- is
+// written in ONE scheduling region with the NEXT sample's MFMAs, whose results it does not need: the wave's matrix and vector
+// instructions interleave (a second accumulator set). The depthwise stage is wave-local (private padded tile, taps / order / pool of
+// dwconv3x3_map_kernel): outputs and pooled means are the bits of the two-launch path.
+// -------------------------------------------------------------------------------------------------------------------
+template <int CIN>
+struct Mf8 {
+    static constexpr int NK16 = CIN / 16, NKT = CIN / 32, CEXP = 6 * CIN, NSL = CEXP / 128;
+    static constexpr int XBUF = NKT * 4096;
+    static constexpr int ET_OFF = XBUF;
+    static constexpr int TBL_OFF = ET_OFF + 4 * MB8_ET_BYTES;        // per wave 1 KiB: bias [32] f32 | depthwise bias [32] f32 | taps [9][32] 16-bit
+    static constexpr int LDS = TBL_OFF + 4 * 1024;
+    static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
+};
+
+template <int CIN, bool F16>
+__global__ __launch_bounds__(256, 2) void mbfront8_kernel(MbFront8Args p) {
+    using S = Mf8<CIN>;
+    constexpr int NK16 = S::NK16, CEXP = S::CEXP, NSL = S::NSL;
+    T16<F16>::enter();
+    unsigned char* const lds = conv_lds_dyn;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int slice = blockIdx.x % NSL, q = blockIdx.x / NSL, Q = gridDim.x / NSL;
+    if (q >= p.B) return;
+    const int cb = slice * 4 + wave, c0 = cb * 32;
+    unsigned char* const et = lds + S::ET_OFF + wave * MB8_ET_BYTES;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)lds;
+
+    // one sample's input rows -> X tiles: tile kt = channels 32 kt .., [64 rows][64 B] swizzled (gemm1x1's A image)
+    auto dma_x = [&](int smp) {
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(p.x) + (size_t)smp * 64 * CIN * 2;
+        for (int pc = wave; pc < S::NKT * 4; pc += 4) {
+            const int kt = pc >> 2, row = 16 * (pc & 3) + (lane >> 2);
+            const int logical = (lane & 3) ^ ((row >> 2) & 3);
+            dma16_s(src, (uint32_t)(row * CIN * 2 + kt * 64 + logical * 16), lds0 + (uint32_t)(pc * 1024));
+        }
+    };
+    dma_x(q);
+    // the wave's weights, for the whole kernel (fragment-packed: one coalesced 1-KiB load per k16 step)
+    uint4 wreg[NK16];
+    {
+        const uint4* src = p.w1p + (size_t)cb * NK16 * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < NK16; ++s) wreg[s] = src[s * 64];
+    }
+    const int pq = lane >> 2, cl = lane & 3;                        // depthwise: pixel quad (16 per map), 8-channel chunk
+    const int oy = pq >> 1, ox0 = (pq & 1) * 4;
+    // the block's small per-channel operands live in a per-wave LDS table for the whole kernel (the registers belong to the stationary
+    // weights; two waves share a SIMD's 512): read back as 16-byte pieces where they are used
+    unsigned char* const tbl = lds + S::TBL_OFF + wave * 1024;
+    if (lane < 8) *reinterpret_cast<float4*>(tbl + lane * 16) = *reinterpret_cast<const float4*>(p.b1 + c0 + lane * 4);
+    else if (lane < 16) *reinterpret_cast<float4*>(tbl + lane * 16) = *reinterpret_cast<const float4*>(p.dwb + c0 + (lane - 8) * 4);
+    else if (lane < 16 + 36) {
+        const int t = (lane - 16) >> 2, c4 = (lane - 16) & 3;
+        *reinterpret_cast<uint4*>(tbl + 256 + t * 64 + c4 * 16) = *reinterpret_cast<const uint4*>(p.dww + (size_t)t * CEXP + c0 + c4 * 8);
+    }
+    for (int i = lane; i < 36 * 4; i += 64) {                       // the zero ring of the wave's padded tile, once
+        const int qi = i >> 2, ch = i & 3;
+        const int pix = qi < 10 ? qi : (qi < 20 ? 90 + (qi - 10) : (qi < 28 ? 10 * (qi - 19) : 10 * (qi - 27) + 9));
+        *reinterpret_cast<uint4*>(et + pix * 64 + ch * 16) = make_uint4(0, 0, 0, 0);
+    }
+    const int a_sw0 = swz(r, h), a_sw1 = swz(r, 2 + h);
+    uint32_t one_lo, one_hi;                                        // (1, 0) / (0, 1) pairs in the storage type (see dwconv3x3_pool_kernel)
+    if constexpr (F16) asm volatile("v_mov_b32 %0, 0x3c00\n\tv_lshlrev_b32 %1, 16, %0" : "=v"(one_lo), "=v"(one_hi));
+    else asm volatile("v_mov_b32 %0, 0x3f80\n\tv_lshlrev_b32 %1, 16, %0" : "=v"(one_lo), "=v"(one_hi));
+
+    uint64_t st_wait = 0, st_body = 0, st_t0 = 0;                  // tuning probe (MbFront8Args.stamps)
+    if (p.stamps) st_t0 = __builtin_amdgcn_s_memtime();
+    int it = 0;
+    for (int smp = q; smp < p.B; smp += Q, ++it) {
+        uint64_t ta = 0, tb = 0;
+        if (p.stamps) ta = __builtin_amdgcn_s_memtime();
+        // the sample's tiles landed: requested after the previous sample's MFMAs, ahead of that sample's five stores (four D rows, the
+        // pooled means), which may keep flying (vmcnt retires in order)
+        if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (p.stamps) { tb = __builtin_amdgcn_s_memtime(); st_wait += tb - ta; }
+        // ---- expand: the sample x the wave's 32 channels
+        f32x16 acc[2];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[0][e] = acc[1][e] = 0.f;
+#pragma unroll
+        for (int k16 = 0; k16 < NK16; ++k16) {
+            const unsigned char* xt = lds + (k16 >> 1) * 4096 + ((k16 & 1) ? a_sw1 : a_sw0);
+            const uint4 a0 = *reinterpret_cast<const uint4*>(xt), a1 = *reinterpret_cast<const uint4*>(xt + 2048);
+            acc[0] = T16<F16>::mfma32(wreg[k16], a0, acc[0]);
+            acc[1] = T16<F16>::mfma32(wreg[k16], a1, acc[1]);
+            if ((k16 & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // (fragment reads at most four k16 steps ahead: registers)
+        }
+        __builtin_amdgcn_s_barrier();                               // everybody has read the tiles: the next sample's may land
+        if (smp + Q < p.B) dma_x(smp + Q);
+        // ---- E = T16(silu(acc + bias)) -> the wave's padded tile
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            unsigned char* cell = et + et_pix(rb * 32 + r) * 64 + h * 8;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const float4 bs = *reinterpret_cast<const float4*>(tbl + (8 * qq + 4 * h) * 4);
+                const float v0 = silu_fast(acc[rb][4 * qq] + bs.x), v1 = silu_fast(acc[rb][4 * qq + 1] + bs.y);
+                const float v2 = silu_fast(acc[rb][4 * qq + 2] + bs.z), v3 = silu_fast(acc[rb][4 * qq + 3] + bs.w);
+                uint2 pk;
+                pk.x = T16<F16>::pack2(v0, v1);
+                pk.y = T16<F16>::pack2(v2, v3);
+                *reinterpret_cast<uint2*>(cell + qq * 16) = pk;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- depthwise 3x3 + bias + SiLU (taps and order of dwconv3x3_map_kernel), D rows, pooled means
+        float dacc[4][8], psum[8];
+        {
+            const float4 d0 = *reinterpret_cast<const float4*>(tbl + 128 + cl * 32), d1 = *reinterpret_cast<const float4*>(tbl + 128 + cl * 32 + 16);
+            const float dbias[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dacc[o][e] = dbias[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) psum[e] = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            // the row's three taps of the lane's eight channels, split into (w, 0) / (0, w) pairs: v_dot2 with a zeroed partner is the
+            // exact f32 FMA of ONE channel -- and, like dwconv3x3_map_kernel's, it flushes 16-bit denormal operands (a v_fma_mix_f32
+            // form, which needs no split copies, keeps them: not the same bits; measured)
+            uint32_t wlo[3][4], whi[3][4];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const uint4 tp = *reinterpret_cast<const uint4*>(tbl + 256 + (ky * 3 + kx) * 64 + cl * 16);
+                const uint32_t wp[4] = {tp.x, tp.y, tp.z, tp.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { wlo[kx][e] = wp[e] & 0xffffu; whi[kx][e] = wp[e] & 0xffff0000u; }
+            }
+            uint4 v[6];
+#pragma unroll
+            for (int col = 0; col < 6; ++col) v[col] = *reinterpret_cast<const uint4*>(et + ((oy + ky) * 10 + ox0 + col) * 64 + cl * 16);
+#pragma unroll
+            for (int col = 0; col < 6; ++col) {
+                const uint32_t x[4] = {v[col].x, v[col].y, v[col].z, v[col].w};
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    const int kx = col - o;
+                    if (kx >= 0 && kx < 3) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            dacc[o][2 * e] = T16<F16>::dot2(x[e], wlo[kx][e], dacc[o][2 * e]);
+                            dacc[o][2 * e + 1] = T16<F16>::dot2(x[e], whi[kx][e], dacc[o][2 * e + 1]);
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        uint16_t* const drow = p.d + ((size_t)smp * 64) * CEXP + c0 + cl * 8;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            uint32_t pk[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                pk[e] = T16<F16>::pack2(silu_fast(dacc[o][2 * e]), silu_fast(dacc[o][2 * e + 1]));
+                psum[2 * e] = T16<F16>::dot2(pk[e], one_lo, psum[2 * e]);      // the pool sees the stored (rounded) activations
+                psum[2 * e + 1] = T16<F16>::dot2(pk[e], one_hi, psum[2 * e + 1]);
+            }
+            *reinterpret_cast<uint4*>(drow + (size_t)(oy * 8 + ox0 + o) * CEXP) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        }
+        // pool: quad sums -> 16-term sums in quad order -> / 64 (dwconv3x3_map_kernel's walk); the sums sit in the tile's interior
+        float* const red = reinterpret_cast<float*>(et + 11 * 64);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[pq * 32 + cl * 8 + e] = psum[e];
+        if (lane < 32) {
+            float rv[16];                                           // all sixteen reads in flight, then the sum in quad order
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) rv[s2] = red[s2 * 32 + lane];
+            float t = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) t += rv[s2];
+            p.pooled[(size_t)smp * CEXP + c0 + lane] = t / 64.0f;
+        }
+        if (lane < 24) {                                            // the ring pixels the sums overlapped (19, 20, 29, 30, 39, 40)
+            const int qi = lane >> 2, ch = lane & 3;
+            *reinterpret_cast<uint4*>(et + (19 + 10 * (qi >> 1) + (qi & 1)) * 64 + ch * 16) = make_uint4(0, 0, 0, 0);
+        }
+        if (p.stamps) st_body += __builtin_amdgcn_s_memtime() - tb;
+    }
+    if (p.stamps && blockIdx.x < 64 && lane == 0) {
+        uint64_t* o = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 4;
+        o[0] = __builtin_amdgcn_s_memtime() - st_t0; o[1] = st_wait; o[2] = st_body; o[3] = (uint64_t)it;
+    }
+}
+
 // 16-bit weights [N][K] row-major -> MFMA fragment order for register streaming: groups of G 32-channel blocks, k16-major inside
 // a group: dst[((grp * K/16 + s) * G + g) * 64 + lane] (16 bytes) = W[(grp G + g) 32 + (lane & 31)][16 s + 8 (lane >> 5) .. + 8]
 __global__ void mb8_pack_frag_kernel(const uint16_t* w, uint4* dst, int N, int K, int G) {
@@ -495,6 +695,25 @@ int launch_mb8_pack_se1(const float* w1, float* dst, int cse, int C, hipStream_t
     }
     hipLaunchKernelGGL(mb8_pack_se1_kernel, dim3((unsigned)cdivz((size_t)cse * C, 256)), dim3(256), 0, st, w1, dst, cse, C);
     ISB_LAUNCHED("mb8_pack_se1", st);
+    return ISB_OK;
+}
+
+int launch_mbfront8(const MbFront8Args& a, hipStream_t st) {
+    if (a.B < 1 || !a.x || !a.w1p || !a.b1 || !a.dww || !a.dwb || !a.d || !a.pooled || a.cin != 384) {
+        set_error("mbfront8: bad arguments (B=%d cin=%d; built for 384 -> 2304)", a.B, a.cin);
+        return ISB_ERR_INVALID;
+    }
+    constexpr int NSL = Mf8<384>::NSL, LDSB = Mf8<384>::LDS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        ISB_HIP(hipFuncSetAttribute((const void*)mbfront8_kernel<384, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+        ISB_HIP(hipFuncSetAttribute((const void*)mbfront8_kernel<384, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+        attr_set = true;
+    }
+    const int Q = std::max(1, std::min(a.B, 512 / NSL));              // sample sequences: two workgroups per CU
+    if (a.f16) hipLaunchKernelGGL((mbfront8_kernel<384, true>), dim3(NSL * Q), dim3(256), LDSB, st, a);
+    else hipLaunchKernelGGL((mbfront8_kernel<384, false>), dim3(NSL * Q), dim3(256), LDSB, st, a);
+    ISB_LAUNCHED("mbfront8", st);
     return ISB_OK;
 }
 

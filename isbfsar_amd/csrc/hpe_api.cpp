@@ -30,6 +30,7 @@ struct BlockW {
     int cin = 0, cout = 0, cexp = 0, stride = 1, cse = 0, in_hw = 0, out_hw = 0;
     ConvW expand, project;
     DevBuf dw_w, dw_w16, dw_b, se_w1, se_b1, se_w2, se_b2;   // dw_w: the 16-bit-rounded taps as f32, dw_w16: the 16-bit taps
+    DevBuf mbf_w1p;                   // stride-1 MBConv blocks with 384 inputs on 8 x 8 maps: the expand weights in fragment order (mbfront8_kernel)
     DevBuf mb_w1p, mb_w2p, mb_se1p;   // stride-1 blocks of the 8 x 8 stages: the weights in mb8_chain_kernel's streaming layouts (conv_mb8.hip)
 };
 
@@ -74,6 +75,10 @@ struct isb_hpe {
     // bytes of the tiled GEMMs, and receives them at 5-15 B/clk (stamps: EXPERIMENTS.md round 4). Off by default; ISB_MB8=1 selects
     // it (this round's open experiment: the packed weights are only built then).
     bool mb8_on = false;
+    // the FRONT half (expand + SiLU + depthwise + SiLU + pool) of the stride-1 MBConv blocks with 384 input channels on 8 x 8 maps in one
+    // launch on stationary weights (conv_mb8.hip mbfront8_kernel; bit-identical to the two launches): batches >= mbf8_min_batch
+    bool mbf8_on = true;          // ISB_MBF8=0: expand GEMM + depthwise kernel (the bit-identity test's reference)
+    int mbf8_min_batch = 32;
     int mb8_min_batch = 48;
     int mb8_first = -1, mb8_count = 0;
     DevBuf mb8_desc;
@@ -347,7 +352,25 @@ int backbone_blocks(isb_hpe* h, Lane& L, hipStream_t st, int B, size_t i0, size_
             }
         } else {
             int se_parts = 0;
-            {
+            if (h->mbf8_on && b.mbf_w1p.p && B >= h->mbf8_min_batch) {
+                MbFront8Args a{};
+                a.x = (const uint16_t*)X; a.w1p = (const uint4*)b.mbf_w1p.p; a.b1 = b.expand.bias.as<float>();
+                a.dww = b.dw_w16.as<uint16_t>(); a.dwb = b.dw_b.as<float>(); a.d = L.bufD.as<uint16_t>(); a.pooled = L.pooled.as<float>();
+                a.B = B; a.cin = b.cin; a.f16 = b.f16 ? 1 : 0;
+                a.stamps = h->mb8_stamps.p ? h->mb8_stamps.as<uint64_t>() : nullptr;
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (h->prof) {
+                    ISB_HIP(hipEventCreate(&e0));
+                    ISB_HIP(hipEventCreate(&e1));
+                    ISB_HIP(hipEventRecord(e0, st));
+                }
+                ISB_TRY(launch_mbfront8(a, st));
+                if (h->prof) {
+                    ISB_HIP(hipEventRecord(e1, st));
+                    h->prof_ev.emplace_back(e0, e1);
+                    h->prof_launches += 1;
+                }
+            } else {
                 ISB_TRY(conv(h, st, b.expand, X, B, b.in_hw, b.in_hw, 1, true, nullptr, nullptr, L.bufE.p, false));
                 DwArgs d{};
                 d.in = L.bufE.as<uint16_t>(); d.w = b.dw_w16.as<uint16_t>(); d.bias = b.dw_b.as<float>(); d.out = L.bufD.as<uint16_t>();
@@ -456,6 +479,7 @@ extern "C" int isb_hpe_create(const isb_hpe_cfg* cfg, isb_hpe** out) {
     ISB_HIP(hipMemset(h->zeros.p, 0, 256));
     if (const char* e = getenv("ISB_FUSE_SE")) h->fuse_se = atoi(e) != 0;
     if (const char* e = getenv("ISB_MB8")) h->mb8_on = atoi(e) != 0;
+    if (const char* e = getenv("ISB_MBF8")) h->mbf8_on = atoi(e) != 0;
     if (const char* e = getenv("ISB_MB8_MIN_BATCH")) h->mb8_min_batch = std::max(1, atoi(e));
     h->f16_from = cfg->precision == 1 ? 7 : (cfg->precision == 3 ? 5 : 0);
     if (const char* e = getenv("ISB_HPE_ROI")) h->roi_mode = atoi(e) != 0 ? 1 : 0;
@@ -579,6 +603,11 @@ extern "C" int isb_hpe_load_weights(isb_hpe* h, const void* blob, size_t nbytes)
                             wt[(size_t)t * b->cexp + c] = bf16_to_float(hb);
                         }
                     }
+                if (h->mbf8_on && b->stride == 1 && b->in_hw == 8 && b->cin == 384 && b->f16_in == b->f16) {
+                    ISB_TRY(b->mbf_w1p.alloc((size_t)b->cexp * b->cin * 2));
+                    ISB_TRY(launch_mb8_pack_frag(b->expand.w16.as<uint16_t>(), b->mbf_w1p.p, b->cexp, b->cin, 1, st));
+                    ISB_HIP(hipStreamSynchronize(st));
+                }
                 ISB_TRY(upload(b->dw_w, wt.data(), wt.size() * 4));
                 ISB_TRY(upload(b->dw_w16, wt16.data(), wt16.size() * 2));
                 ISB_TRY(upload(b->dw_b, sh->data, (size_t)b->cexp * 4));

@@ -207,6 +207,19 @@ struct Mb8Args {
     uint64_t* stamps;       // tuning probe or null: [32 workgroups][2 blocks][32] s_memtime marks of the phases (tools/exp_mb8.py)
 };
 int launch_mb8_chain(const Mb8Args& a, hipStream_t st);
+// the front half of a stride-1 MBConv block on 8 x 8 maps in one launch: expand 1x1 + SiLU -> depthwise 3x3 + SiLU -> D, pooled
+struct MbFront8Args {
+    const uint16_t* x;      // [B][64][cin] 16-bit block input (NHWC)
+    const uint4* w1p;       // expand weights, fragment-packed (launch_mb8_pack_frag, G = 1)
+    const float* b1;        // [cexp]
+    const uint16_t* dww;    // depthwise taps [9][cexp] 16-bit
+    const float* dwb;       // [cexp]
+    uint16_t* d;            // out [B][64][cexp] 16-bit: the depthwise output the gated projection reads
+    float* pooled;          // out [B][cexp] f32 spatial means
+    int B, cin, f16;
+    uint64_t* stamps;       // tuning probe or null: [64 workgroups][4 waves][4] = loop cycles, waiting at the loop top, bodies, iterations
+};
+int launch_mbfront8(const MbFront8Args& a, hipStream_t st);
 int launch_mb8_pack_frag(const uint16_t* w, void* dst, int N, int K, int G, hipStream_t st);
 int launch_mb8_pack_se1(const float* w1, float* dst, int cse, int C, hipStream_t st);
 int mb8_proj_group(int cout);

@@ -862,3 +862,34 @@ def test_fused_8x8_chain_is_bit_identical_to_the_five_launch_path(bbone_state, a
     assert np.isfinite(res["1"][0]).all() and float(np.abs(res["1"][0]).max()) > 0
     for a, b in zip(res["1"], res["0"]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("precision", ["f16", "bf16"])
+def test_fused_front_of_the_8x8_blocks_is_bit_identical(bbone_state, assets, monkeypatch, precision):
+    """conv_mb8.hip mbfront8_kernel: expand 1x1 + SiLU + depthwise 3x3 + SiLU + squeeze-excite pool of the stride-1 MBConv blocks with
+    384 input channels on 8 x 8 maps in ONE launch (weights stationary in registers, the expanded tensor never leaves the chip, the
+    depthwise stage wave-local): features and poses are the bits of the expand-GEMM + depthwise-kernel path (ISB_MBF8=0/1, read when
+    the engine is created)."""
+    from isbfsar_amd.hpe_engine import HpeEngine
+    from oracle import hpe_oracle as ho
+    W, st = assets
+    idx = st["smpl+head_30"]["indices"]
+    B = 45                                  # above the batch threshold; more samples than sample sequences share out evenly
+    fr, bb = synth.frames(B, seed=4), synth.bboxes(B, seed=4)
+    crops = np.stack([ho.warp(fr[b], ho.crop_params(bb[b], _K())[2][0]) for b in range(3)])
+    crops = np.concatenate([crops] * 15)[:B]
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("ISB_MBF8", flag)
+        e = HpeEngine(device=0, max_batch=64, precision=precision)
+        try:
+            e.set_joint_map(W, idx)
+            e.load_weights(bbone_state)
+            feat, logits = e.backbone(crops)
+            joints, valid = e.forward(fr, bb)
+        finally:
+            e.close()
+        res[flag] = (feat, logits, joints, valid)
+    assert np.isfinite(res["1"][0]).all() and float(np.abs(res["1"][0]).max()) > 0
+    for a, b in zip(res["1"], res["0"]):
+        assert np.array_equal(a, b)
