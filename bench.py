@@ -140,7 +140,7 @@ class ArWorkload:
         if tj and chunk == 1024 and self.way == 60 and self.precision in ("bf16", "f16"):
             with open(tj) as f:       # HBM bytes of one ar_proto launch (PMC passes, profiles/README.md)
                 traffic = json.load(f).get("ar_b1024", {}).get("ar_proto", {}).get("hbm_bytes_per_launch")
-        return {"bound": "mfma", "kernel": "ar_proto_kernel", "achieved": round(achieved, 2), "peak": peak,
+        return {"bound": "mfma", "kernel": "ar_proto_all_kernel", "achieved": round(achieved, 2), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                 "avg_launch_ms": round(ms / max(launches, 1), 4), "launches": int(launches)}
 

@@ -285,6 +285,11 @@ int isb_debug_conv(int32_t device, const uint16_t* h_x, const float* h_w, const 
  * last wave; block 0 = a 384 -> 2304 -> 384 block, block 1 = a 640 -> 3840 -> 640 block) and disarms. tools/exp_mb8.py */
 int isb_debug_hpe_mb8_stamps(isb_hpe* h, int32_t enable, uint64_t* host_out);
 
+/* tuning probe of the all-classes attention pass (ar_kernels.hip ar_proto_kernel): enable != 0 arms in-kernel s_memtime stamps (the
+ * following isb_ar_forward calls write them), enable == 0 copies them to host_out ([64 workgroups][8 waves][4] uint64_t: cycles of
+ * the prologue, of the tile loop, of the epilogue, and the start clock) and disarms. tools/exp_ar_stamps.py */
+int isb_debug_ar_stamps(isb_ar* h, int32_t enable, uint64_t* host_out);
+
 /* test / tuning hook: a whole Fused-MBConv block (3x3 expand + BN + SiLU -> 1x1 project + BN [+ residual]) in ONE
  * launch on host tensors. h_x bf16 [B,H,H,Cin], h_w1 f32 [Cexp,3,3,Cin] (Cexp = 128, 256 or 384), h_w2 f32 [Cout2,Cexp]
  * (Cout2 <= 128), optional residual h_res bf16 [B,H/stride,H/stride,Cout2]; out bf16 of that shape. */

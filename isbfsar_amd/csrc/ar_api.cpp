@@ -40,6 +40,7 @@ struct isb_ar {
 
     // profiling of the tuple-attention kernels
     bool prof = false;
+    DevBuf stamps;                 // tuning probe (isb_debug_ar_stamps)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
     double prof_ms = 0.0;
     int64_t prof_launches = 0;
@@ -429,6 +430,7 @@ static int infer_impl(isb_ar* h, const float* d_windows, const float* d_trunk, i
         pa.VqF = h->VqF.as<float>();
         pa.chosen = nullptr; pa.part = h->part.as<float>(); pa.diff = nullptr;
         pa.B = Bc; pa.n = n; pa.L = L; pa.T = T; pa.NT = NT; pa.x3 = h->x3; pa.f16 = h->f16;
+        pa.stamps = h->stamps.p ? h->stamps.as<uint64_t>() : nullptr;
         ISB_TRY(launch_ar_proto(pa, st));
         if (h->prof) {
             ISB_HIP(hipEventRecord(e1, st));
@@ -535,6 +537,24 @@ extern "C" int isb_ar_profile_read(isb_ar* h, double* ms_total, int64_t* launche
     *launches = h->prof_launches;
     h->prof_ms = 0.0;
     h->prof_launches = 0;
+    return ISB_OK;
+    });
+}
+
+extern "C" int isb_debug_ar_stamps(isb_ar* h, int32_t enable, uint64_t* host_out) {
+    return isb::guard([&]() -> int {
+    ISB_REQUIRE(h, ISB_ERR_INVALID, "null handle");
+    ISB_HIP(hipSetDevice(h->cfg.device));
+    ISB_HIP(hipDeviceSynchronize());
+    const size_t bytes = (size_t)64 * 8 * 4 * 8;
+    if (enable) {
+        ISB_TRY(h->stamps.alloc(bytes));
+        ISB_HIP(hipMemset(h->stamps.p, 0, bytes));
+    } else {
+        ISB_REQUIRE(host_out && h->stamps.p, ISB_ERR_INVALID, "stamps were not armed");
+        ISB_HIP(hipMemcpy(host_out, h->stamps.p, bytes, hipMemcpyDeviceToHost));
+        h->stamps = DevBuf();
+    }
     return ISB_OK;
     });
 }

@@ -21,15 +21,17 @@
 //     i on the lane), P^T = V^T A^T, so the softmax axis (i) runs across lanes + i-tiles and the
 //     prototype contraction (j) runs down accumulator rows.
 //   * the softmax normaliser needs ALL i of a window before any P can be formed, so the work is two
-//     launches: `ar_stats` writes lse2[b,c,j] = log2 sum_i exp2(s'[i,j]) (s' already carries
-//     log2(e)/sqrt(128), folded into Kq), `ar_proto` recomputes S^T tiles, forms A^T = exp2(s' - lse2)
-//     in registers, contracts with V^T and reduces ||Vq - P||^2 on the fly.  Vq is never stored:
-//     it is re-formed from the per-frame projections in the epilogue.
-//   * no running max is needed in the common case: |kq'|.|kc_j| bounds s' from LayerNorm's norm
-//     bound, `ub[c,j]` is that bound and exp2(s' - ub) cannot overflow; the host picks the ONLINE
-//     (running max) variant when the bound is too loose to rule out underflow.
+//     launches: `ar_stats` writes lse2[b,c,j] = -log2 sum_i exp2(s'[i,j]) (s' already carries
+//     log2(e)/sqrt(128), folded into Kq), `ar_proto` recomputes S^T tiles ONTO that row (the MFMA
+//     chain's C operand), forms A^T = exp2(.) in registers, contracts with V^T and reduces
+//     ||Vq - P||^2 on the fly against the query V image `ar_tuples` wrote.
+//   * no running max and no other stabiliser in the common case: LayerNorm's norm bound gives
+//     |s'| <= |kq'|.|kc_j| <= 50, so exp2(s') and its sums stay in f32's normal range; the host
+//     picks the ONLINE (running max) variant when the bound is looser than that.
 //   * bf16x3: operands split hi+lo, three MFMAs per product (lo*lo dropped) -> ~2^-16 relative.
 #include <algorithm>
+#include <cstdlib>
+#include <type_traits>
 #include "isb_common.h"
 #include "kernels.h"
 
@@ -73,7 +75,10 @@ __device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_addr) {
 
 __device__ __forceinline__ void wait_tiles_in_flight(int tiles, int per_tile) {   // wave-uniform arguments
     const int n = tiles * per_tile;
-    if (n >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if (n >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if (n >= 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else if (n >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (n >= 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     else if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if (n >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else if (n >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -250,7 +255,7 @@ int launch_ar_tuples(const ArTupleArgs& a, hipStream_t st) {
 }
 
 // =====================================================================================
-// stats: lse2[b,c,j] = log2 sum_{i<T} exp2(s'[j,i]),  s' = Kc_j . Kq'_i
+// stats: lse2[b,c,j] = -log2 sum_{i<T} exp2(s'[j,i]),  s' = Kc_j . Kq'_i   (stored NEGATED: ar_proto accumulates S^T onto it)
 // 1-D grid (see the decode below), block 512 = 8 waves; wave = one (class, j-tile) slot of window b.
 // The window's Kq fragment tiles stream through a double-buffered LDS ring shared by the 8 waves.
 // =====================================================================================
@@ -293,19 +298,15 @@ __global__ __launch_bounds__(512, 2) void ar_stats_kernel(ArStatsArgs p) {
             for (int ks = 0; ks < 8; ++ks) a_lo[ks] = ld_frag(bl + ks * 512);
         }
     }
-    float ubr[16], lsum[16], mrun[16];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float4 u = *reinterpret_cast<const float4*>(p.ub + (size_t)c * Tp + jt * 32 + 8 * q + 4 * h);
-        ubr[4 * q + 0] = u.x; ubr[4 * q + 1] = u.y; ubr[4 * q + 2] = u.z; ubr[4 * q + 3] = u.w;
-    }
+    // no stabiliser in the plain variant: the host selects it only when LayerNorm's norm bound gives |s'| <= 50 (ar_api.cpp), so
+    // exp2(s') and its 448-term sums stay inside f32's normal range at full relative precision -- and this loop, which is bound by its
+    // vector issue slots (not by the matrix pipe), saves a subtraction per exponential. ONLINE keeps a running maximum.
+    float lsum[16], mrun[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { lsum[i] = 0.f; mrun[i] = -3.0e38f; }
 
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) { ISB_PIN(a_hi[ks]); if (X3) ISB_PIN(a_lo[ks]); }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) ISB_PIN(ubr[i]);
 
     // the window's Kq fragment tiles go global -> LDS by LDS-DMA (lane-linear images: wave w fills
     // KiB w of the 8-KiB tile)
@@ -330,9 +331,6 @@ __global__ __launch_bounds__(512, 2) void ar_stats_kernel(ArStatsArgs p) {
         if (it + NB - 1 < p.NT) dma_tile(it + NB - 1);
         if (active) {
             const uint16_t* bt = lds + (it % NB) * NBUF_U16 + lane * 8;
-            f32x16 acc;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
             // all fragment reads of the tile first (one LDS round trip), then the MFMA chain: left to itself the
             // compiler reads one fragment, waits for it, issues one MFMA, and pays the LDS latency 8 times
             bf16x8 bh[8], bl[X3 ? 8 : 1];
@@ -342,6 +340,9 @@ __global__ __launch_bounds__(512, 2) void ar_stats_kernel(ArStatsArgs p) {
                 if (X3) bl[ks] = ld_frag(bt + TILE_U16 + ks * 512);
             }
             __builtin_amdgcn_sched_barrier(0);
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
                 acc = mfma16<F16>(a_hi[ks], bh[ks], acc);
@@ -352,10 +353,15 @@ __global__ __launch_bounds__(512, 2) void ar_stats_kernel(ArStatsArgs p) {
             }
             const bool ivalid = it * 32 + r < p.T;
             if (!ONLINE) {
+                if (it * 32 + 32 <= p.T) {                 // (wave-uniform) only the last tile has padded query tuples
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float e = __builtin_amdgcn_exp2f(acc[i] - ubr[i]);
-                    lsum[i] += ivalid ? e : 0.f;
+                    for (int i = 0; i < 16; ++i) lsum[i] += __builtin_amdgcn_exp2f(acc[i]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float e = __builtin_amdgcn_exp2f(acc[i]);
+                        lsum[i] += ivalid ? e : 0.f;
+                    }
                 }
             } else {
 #pragma unroll
@@ -383,13 +389,13 @@ __global__ __launch_bounds__(512, 2) void ar_stats_kernel(ArStatsArgs p) {
         if (r == 0) {
 #pragma unroll
             for (int i = 0; i < 16; ++i)
-                p.lse2[((size_t)b * ncls + cidx) * Tp + jt * 32 + acc_row(i, h)] = ubr[i] + log2f(rs[i] + other[i]);
+                p.lse2[((size_t)b * ncls + cidx) * Tp + jt * 32 + acc_row(i, h)] = -log2f(rs[i] + other[i]);
         }
         return;
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        float l = lsum[i], m = ONLINE ? mrun[i] : ubr[i];
+        float l = lsum[i], m = mrun[i];
 #pragma unroll
         for (int sh = 1; sh < 32; sh <<= 1) {
             const float lo = __shfl_xor(l, sh, 64);
@@ -402,7 +408,7 @@ __global__ __launch_bounds__(512, 2) void ar_stats_kernel(ArStatsArgs p) {
                 l += lo;
             }
         }
-        if (r == 0) p.lse2[((size_t)b * ncls + cidx) * Tp + jt * 32 + acc_row(i, h)] = m + log2f(l);
+        if (r == 0) p.lse2[((size_t)b * ncls + cidx) * Tp + jt * 32 + acc_row(i, h)] = -(m + log2f(l));
     }
 }
 
@@ -432,46 +438,142 @@ int launch_ar_stats(const ArStatsArgs& a0, hipStream_t st) {
 
 // =====================================================================================
 // proto: P^T = V^T A^T with A^T = exp2(S^T - lse2), fused distance / diff epilogue.
-// ALL mode   : 1-D grid over (window group, class) blocks; wave = one (window, i-tile) slot of its class;
-//              the class's Kc / V^T fragment tiles stream through LDS shared by the 8 waves;
+// all classes (ar_proto_all_kernel): 1-D grid over (class group, window group); wave = one (window, i-tile) slot for the whole
+//              kernel, the workgroup walks through its group's classes: their Kc / V^T fragment tiles stream through an LDS ring
+//              shared by the 8 waves, ONE stream across the class boundaries;
 //              out: part[b,c,it] = sum_{i in tile, d} (Vq - P)^2
-// CHOSEN mode: grid (ceil(B*NT/8), 1); class = chosen[b] per wave, operands straight from L2;
+// chosen class (ar_proto_chosen_kernel): grid ceil(B*NT/8); class = chosen[b] per wave, operands straight from L2;
 //              out: diff[b,i,:] (input of the Discriminator, model.py:324)
 // =====================================================================================
-constexpr int PROTO_WT = 16, PROTO_CT = 8;
+constexpr int PROTO_WT = 16, PROTO_CT = 8;      // L2 block of the all-classes pass: window groups x classes
 
-template <bool X3, bool CHOSEN, bool F16 = false>
-__global__ __launch_bounds__(512, 2) void ar_proto_kernel(ArProtoArgs p) {
+// the three pieces of a tile's work. S^T tile = Kc[jt] * Kq[it]^T accumulated ONTO -lse2 (the chain's C operand: the subtraction
+// costs no vector instruction); A^T = exp2(.): accumulator rows 8s..8s+7 become k-step s of the B operand; P^T += V^T[jt] * A^T
+template <bool X3, bool F16>
+__device__ __forceinline__ f32x16 proto_s_chain(const f32x16& nl, const bf16x8 (&ah)[8], const bf16x8 (&al)[X3 ? 8 : 1],
+                                                const bf16x8 (&q_hi)[8], const bf16x8 (&q_lo)[8]) {
+    f32x16 acc = mfma16<F16>(ah[0], q_hi[0], nl);
+    if (X3) {
+        acc = MFMA_BF16(ah[0], q_lo[0], acc);
+        acc = MFMA_BF16(al[0], q_hi[0], acc);
+    }
+#pragma unroll
+    for (int ks = 1; ks < 8; ++ks) {
+        acc = mfma16<F16>(ah[ks], q_hi[ks], acc);
+        if (X3) {
+            acc = MFMA_BF16(ah[ks], q_lo[ks], acc);
+            acc = MFMA_BF16(al[ks], q_hi[ks], acc);
+        }
+    }
+    return acc;
+}
+
+template <bool X3, bool F16>
+__device__ __forceinline__ void proto_exp(const f32x16& acc, bf16x8 (&a_hi)[2], bf16x8 (&a_lo)[2]) {
+    if constexpr (F16) {
+        // pairs through v_cvt_pk_f16_f32 (A^T <= 1: no saturation needed)
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            uint32_t w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f32x2 pe = {__builtin_amdgcn_exp2f(acc[8 * s + 2 * e]), __builtin_amdgcn_exp2f(acc[8 * s + 2 * e + 1])};
+                w[e] = __builtin_bit_cast(uint32_t, __builtin_convertvector(pe, f16x2));
+            }
+            a_hi[s] = __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float pe = __builtin_amdgcn_exp2f(acc[8 * s + e]);
+                const __bf16 ph = (__bf16)pe;
+                a_hi[s][e] = ph;
+                if (X3) a_lo[s][e] = (__bf16)(pe - (float)ph);
+            }
+    }
+}
+
+template <bool X3, bool F16>
+__device__ __forceinline__ void proto_p_chain(f32x16 (&pacc)[4], const bf16x8 (&vh)[8], const bf16x8 (&vl)[X3 ? 8 : 1],
+                                              const bf16x8 (&a_hi)[2], const bf16x8 (&a_lo)[2]) {
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            pacc[dt] = mfma16<F16>(vh[dt * 2 + s], a_hi[s], pacc[dt]);
+            if (X3) {
+                pacc[dt] = MFMA_BF16(vh[dt * 2 + s], a_lo[s], pacc[dt]);
+                pacc[dt] = MFMA_BF16(vl[dt * 2 + s], a_hi[s], pacc[dt]);
+            }
+        }
+}
+
+// All classes. The workgroup is PERSISTENT over its class group: the Kq fragments are loaded once, the tile ring keeps streaming across
+// the class boundaries (class-major fragment images: one linear stream), and a class ends with its distance epilogue and zeroed
+// accumulators (-7 % against one class per workgroup). What else was measured on this kernel this round and did not pay -- four-wave
+// workgroups two or three to a CU, the next tile's fragments read ahead of the P^T chain, S^T of tile t+1 interleaved with the
+// exponentials of tile t, the two waves of a SIMD skewed around the barrier, class order rotated per workgroup -- is in EXPERIMENTS.md
+// (round 4, "AR attention"); every form lands at 5.9-6.7 ms per 1 024 windows x 60 classes.
+template <bool X3, bool F16>
+__global__ __launch_bounds__(512, 2) void ar_proto_all_kernel(ArProtoArgs p) {
     static_assert(!(X3 && F16), "fp16 fragments have no lo part");
     constexpr int KT_U16 = 8 * 64 * 8;                    // Kc tile (8 KiB)
     constexpr int VT_U16 = 4 * 2 * 64 * 8;                // V^T tile (8 KiB)
     constexpr int PART_U16 = KT_U16 + VT_U16;
     constexpr int NBUF_U16 = PART_U16 * (X3 ? 2 : 1);
-    constexpr int NB = 3;                                 // ring: tile jt is consumed while jt+1, jt+2 are in flight
+    constexpr int NB = 4;                                 // ring: tile t is consumed while t+1 (landed at the barrier), t+2, t+3 are in flight
     constexpr int PER = X3 ? 5 : 3;                       // DMA instructions per wave and tile (K, V^T [, lo parts], lse2)
     constexpr int LSE_U16 = 8 * NB * 64;                  // per wave and ring slot: the tile's 32 lse2 values (128 B)
-    __shared__ __attribute__((aligned(16))) uint16_t lds[CHOSEN ? 8 : NB * NBUF_U16 + LSE_U16];
+    __shared__ __attribute__((aligned(16))) uint16_t lds[NB * NBUF_U16 + LSE_U16];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, r = lane & 31;
-    // ALL mode: 1-D grid decoded per XCD (workgroup id % 8 = XCD) into blocks of PROTO_WT window groups x PROTO_CT
-    // classes, classes fastest: a block's Kq fragments (1 MiB) and its classes' K / V^T tiles (1.8 MiB) stay in
-    // that XCD's 4-MiB L2 while they are reused, instead of every class streaming all windows from HBM again
-    int bx = blockIdx.x, cls = 0;
-    if constexpr (!CHOSEN) {
-        const int id = blockIdx.x, xcd = id & 7, sl = id >> 3;
-        const int nx = (p.B * p.NT + 7) >> 3;                       // window groups
-        const int ncg = (p.n + PROTO_CT - 1) / PROTO_CT;
-        const int blk = sl / (p.wt * PROTO_CT), within = sl - blk * (p.wt * PROTO_CT);
-        const int wb = blk / ncg, cg = blk - wb * ncg;
-        bx = ((wb * p.wt + within / PROTO_CT) << 3) + xcd;
-        cls = cg * PROTO_CT + within % PROTO_CT;
-        if (bx >= nx || cls >= p.n) return;
-    }
+    // 1-D grid decoded per XCD (workgroup id % 8 = XCD) into blocks of p.wt window groups, one class group each, window groups
+    // fastest: the workgroups an XCD runs at one time walk through the same PROTO_CT classes, whose K / V^T tiles (1.8 MiB) stay in
+    // that XCD's 4-MiB L2 next to the block's Kq fragments (1 MiB), instead of every class streaming all windows from HBM again
+    const int id = blockIdx.x, xcd = id & 7, sl = id >> 3;
+    const int nx = (p.B * p.NT + 7) >> 3;                           // window groups (8 slots)
+    const int ncg = (p.n + PROTO_CT - 1) / PROTO_CT;                // class groups
+    const int blk = sl / p.wt, within = sl - blk * p.wt;
+    const int wb = blk / ncg, cg = blk - wb * ncg;
+    const int bx = ((wb * p.wt + within) << 3) + xcd;
+    if (bx >= nx) return;
+    const int cls0 = cg * PROTO_CT;
+    const int TT = min(PROTO_CT, p.n - cls0) * p.NT;                // tiles of the stream
     const int slot = bx * 8 + wave;
     const bool active = slot < p.B * p.NT;
-    const int b = active ? slot / p.NT : 0, it = active ? slot % p.NT : 0;
-    const int c = CHOSEN ? p.chosen[b] : cls;
+    const int b = active ? slot / p.NT : 0, it = active ? slot % p.NT : 0;   // (idle waves compute slot 0 and store nothing)
     const int Tp = p.NT * 32;
+    uint64_t st0 = 0, st1 = 0, st_epi = 0;                 // tuning probe (ArProtoArgs.stamps)
+    if (p.stamps) st0 = __builtin_amdgcn_s_memtime();
 
+    // staging: the fragment tiles go global -> LDS by LDS-DMA (the images are lane-linear, so wave w simply fills KiB w of each
+    // 8-KiB tile), and so do the 32 lse2 values of the wave's own (window, class) row for that tile
+    const uint16_t* gk = p.KcF + (size_t)cls0 * p.NT * KT_U16 + tid * 8;
+    const uint16_t* gv = p.VtF + (size_t)cls0 * p.NT * VT_U16 + tid * 8;
+    const uint16_t* gk_lo = X3 ? p.KcF_lo + (size_t)cls0 * p.NT * KT_U16 + tid * 8 : nullptr;
+    const uint16_t* gv_lo = X3 ? p.VtF_lo + (size_t)cls0 * p.NT * VT_U16 + tid * 8 : nullptr;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)lds;
+    const uint32_t lds0 = lds_base + wave_u * 1024;
+    const float* lse_src = p.lse2 + ((size_t)b * p.n + cls0) * Tp + (lane & 7) * 4;     // (class stride Tp = NT tiles of 32: linear in t)
+    const uint32_t lse0 = lds_base + NB * NBUF_U16 * 2 + wave_u * (NB * 128);
+    auto dma_tile = [&](int t) {                           // (class-major fragment images: the unit's tiles are ONE linear stream)
+        const uint32_t base = lds0 + (t % NB) * (NBUF_U16 * 2);
+        dma16(gk + (size_t)t * KT_U16, base);
+        dma16(gv + (size_t)t * VT_U16, base + KT_U16 * 2);
+        if (X3) {
+            dma16(gk_lo + (size_t)t * KT_U16, base + PART_U16 * 2);
+            dma16(gv_lo + (size_t)t * VT_U16, base + (PART_U16 + KT_U16) * 2);
+        }
+        if (lane < 8) dma16(lse_src + (size_t)t * 32, lse0 + (t % NB) * 128);
+    };
+    // the first tiles are requested BEFORE the wave's Kq fragments: the two latencies overlap
+#pragma unroll
+    for (int t = 0; t < NB - 1; ++t)
+        if (t < TT) dma_tile(t);
     bf16x8 q_hi[8], q_lo[8];
     {
         const uint16_t* base = p.KqF + (((size_t)b * p.NT + it) * 8 * 64 + lane) * 8;
@@ -488,212 +590,194 @@ __global__ __launch_bounds__(512, 2) void ar_proto_kernel(ArProtoArgs p) {
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) pacc[dt][i] = 0.f;
-
-    const float* lse_row = p.lse2 + (p.lse_per_window ? (size_t)b : (size_t)b * p.n + c) * Tp + 4 * h;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) { ISB_PIN(q_hi[ks]); if (X3) ISB_PIN(q_lo[ks]); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the first tiles too: nothing in flight that the loop's counted waits do not know
+    __builtin_amdgcn_s_barrier();
+    if (p.stamps) st1 = __builtin_amdgcn_s_memtime();
 
-    // staging (ALL mode): the class's Kc / V^T fragment tiles go global -> LDS by LDS-DMA (the fragment
-    // images are lane-linear, so wave w simply fills bytes [w KiB, (w+1) KiB) of each 8-KiB tile), and so do the 32
-    // lse2 values of the wave's own (window, class) row for that tile: nothing in the loop is an ordinary global load
-    const uint16_t* gk = p.KcF + (size_t)c * p.NT * KT_U16 + tid * 8;
-    const uint16_t* gv = p.VtF + (size_t)c * p.NT * VT_U16 + tid * 8;
-    const uint16_t* gk_lo = X3 ? p.KcF_lo + (size_t)c * p.NT * KT_U16 + tid * 8 : nullptr;
-    const uint16_t* gv_lo = X3 ? p.VtF_lo + (size_t)c * p.NT * VT_U16 + tid * 8 : nullptr;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)lds;
-    const uint32_t lds0 = lds_base + wave_u * 1024;
-    const float* lse_src = p.lse2 + ((size_t)b * p.n + c) * Tp + (lane & 7) * 4;
-    const uint32_t lse0 = lds_base + NB * NBUF_U16 * 2 + wave_u * (NB * 128);
-    auto dma_tile = [&](int jt2) {
-        const uint32_t base = lds0 + (jt2 % NB) * (NBUF_U16 * 2);
-        dma16(gk + (size_t)jt2 * KT_U16, base);
-        dma16(gv + (size_t)jt2 * VT_U16, base + KT_U16 * 2);
-        if (X3) {
-            dma16(gk_lo + (size_t)jt2 * KT_U16, base + PART_U16 * 2);
-            dma16(gv_lo + (size_t)jt2 * VT_U16, base + (PART_U16 + KT_U16) * 2);
-        }
-        if (lane < 8) dma16(lse_src + jt2 * 32, lse0 + (jt2 % NB) * 128);
-    };
     const float* lse_lds = reinterpret_cast<const float*>(lds + NB * NBUF_U16) + wave * (NB * 32) + 4 * h;
+    // epilogue operands: lane owns query tuple i = 32 it + r; pacc[dt][reg] = P[i][32 dt + acc_row(reg, h)]; Vq of the lane's
+    // tuple comes from the fragment image ar_tuples wrote (16 fully coalesced 1-KiB wave loads)
+    const bool ivalid = it * 32 + r < p.T;
+    // (a buffer resource over the slot's 16 KiB + one lane offset: the 16 loads address through scalar registers, not 16 VGPR pairs)
+    const float* vq = p.VqF + (size_t)__builtin_amdgcn_readfirstlane(b * p.NT + it) * (16 * 64 * 4);
+    const __amdgpu_buffer_rsrc_t vq_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vq), 0, 16 * 64 * 16, 0x00020000);
+    const int vq_lane = lane * 16;
+    int t = 0;
+    for (int cc = 0; cc * p.NT < TT; ++cc) {
+        for (int jt = 0; jt < p.NT; ++jt, ++t) {
+            bf16x8 ah[8], al[X3 ? 8 : 1], vh[8], vl[X3 ? 8 : 1];
+            f32x16 nl;                                      // the tile's -lse2 row
+            {
+                const uint16_t* kt = lds + (t % NB) * NBUF_U16 + lane * 8;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {           // all fragment reads first, then the MFMA chain (see ar_stats)
+                    ah[ks] = ld_frag(kt + ks * 512);
+                    if (X3) al[ks] = ld_frag(kt + PART_U16 + ks * 512);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 u = *reinterpret_cast<const float4*>(lse_lds + (t % NB) * 32 + 8 * q);
+                    nl[4 * q + 0] = u.x; nl[4 * q + 1] = u.y; nl[4 * q + 2] = u.z; nl[4 * q + 3] = u.w;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x16 acc = proto_s_chain<X3, F16>(nl, ah, al, q_hi, q_lo);
+            {   // the V^T fragments are requested before the barrier: their LDS latency hides there and under the exponentials
+                const uint16_t* vt = lds + (t % NB) * NBUF_U16 + KT_U16 + lane * 8;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    vh[i] = ld_frag(vt + i * 512);
+                    if (X3) vl[i] = ld_frag(vt + PART_U16 + i * 512);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < TT) {
+                // tile t+1 has landed when at most the tiles behind it are still in flight; behind the barrier every wave has
+                // consumed tile t-1 (its P^T chain precedes this tile's S^T chain), whose buffer the next request overwrites
+                wait_tiles_in_flight(min(NB - 3, TT - 2 - t), PER);
+                __builtin_amdgcn_s_barrier();
+                if (t + NB - 1 < TT) dma_tile(t + NB - 1);
+            }
+            bf16x8 a_hi[2], a_lo[2];
+            proto_exp<X3, F16>(acc, a_hi, a_lo);
+            proto_p_chain<X3, F16>(pacc, vh, vl, a_hi, a_lo);
+        }
+        // the class's distance. (Ordinary loads inside the ring: waiting for them also waits for the tiles requested before them --
+        // which the next iterations would have waited for anyway -- and nothing is requested in between.)
+        uint64_t te = 0;
+        if (p.stamps) te = __builtin_amdgcn_s_memtime();
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 x[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) x[k] = __builtin_amdgcn_raw_buffer_load_b128(vq_rsrc, vq_lane, k * 1024, 0);
+        float ss = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const u32x4 v = x[dt * 4 + q];
+                const float d0 = __uint_as_float(v.x) - pacc[dt][4 * q + 0], d1 = __uint_as_float(v.y) - pacc[dt][4 * q + 1];
+                const float d2 = __uint_as_float(v.z) - pacc[dt][4 * q + 2], d3 = __uint_as_float(v.w) - pacc[dt][4 * q + 3];
+                ss += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+                pacc[dt][4 * q + 0] = 0.f; pacc[dt][4 * q + 1] = 0.f; pacc[dt][4 * q + 2] = 0.f; pacc[dt][4 * q + 3] = 0.f;
+            }
+        if (!ivalid) ss = 0.f;
+#pragma unroll
+        for (int sh = 32; sh >= 1; sh >>= 1) ss += __shfl_xor(ss, sh, 64);
+        if (active && lane == 0) p.part[((size_t)b * p.n + cls0 + cc) * p.NT + it] = ss;
+        if (p.stamps) st_epi += __builtin_amdgcn_s_memtime() - te;
+    }
+    if (p.stamps && blockIdx.x < 64 && lane == 0) {
+        uint64_t* o = p.stamps + ((size_t)blockIdx.x * 8 + wave) * 4;
+        const uint64_t te = __builtin_amdgcn_s_memtime();
+        o[0] = st1 - st0; o[1] = te - st1; o[2] = st_epi; o[3] = (uint64_t)TT;
+    }
+}
+
+// The arg-max class only (bf16 hi + lo images, model.py:324's input): one class per window, no sharing between waves -- operands
+// straight from L2.
+template <bool X3>
+__global__ __launch_bounds__(512, 2) void ar_proto_chosen_kernel(ArProtoArgs p) {
+    constexpr int KT_U16 = 8 * 64 * 8, VT_U16 = 4 * 2 * 64 * 8;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, r = lane & 31;
+    const int slot = blockIdx.x * 8 + wave;
+    if (slot >= p.B * p.NT) return;
+    const int b = slot / p.NT, it = slot % p.NT;
+    const int c = p.chosen[b];
+    const int Tp = p.NT * 32;
+    bf16x8 q_hi[8], q_lo[8];
+    {
+        const uint16_t* base = p.KqF + (((size_t)b * p.NT + it) * 8 * 64 + lane) * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) q_hi[ks] = ld_frag(base + ks * 512);
+        if (X3) {
+            const uint16_t* bl = p.KqF_lo + (((size_t)b * p.NT + it) * 8 * 64 + lane) * 8;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) q_lo[ks] = ld_frag(bl + ks * 512);
+        }
+    }
+    f32x16 pacc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pacc[dt][i] = 0.f;
+    const float* lse_row = p.lse2 + (p.lse_per_window ? (size_t)b : (size_t)b * p.n + c) * Tp + 4 * h;
     float lse_nx[16];
-    auto load_lse = [&](int jt2) {                         // CHOSEN mode only (no DMA ring there)
+    auto load_lse = [&](int jt2) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 u = *reinterpret_cast<const float4*>(lse_row + jt2 * 32 + 8 * q);
             lse_nx[4 * q + 0] = u.x; lse_nx[4 * q + 1] = u.y; lse_nx[4 * q + 2] = u.z; lse_nx[4 * q + 3] = u.w;
         }
     };
-    if constexpr (CHOSEN) {
-        load_lse(0);
-    } else {
-#pragma unroll
-        for (int t = 0; t < NB - 1; ++t)
-            if (t < p.NT) dma_tile(t);
-    }
-
+    load_lse(0);
     for (int jt = 0; jt < p.NT; ++jt) {
-        const bool more = jt + 1 < p.NT;
-        float lse[16];
-        if constexpr (CHOSEN) {
+        f32x16 nl;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) lse[e] = lse_nx[e];
-            if (more) load_lse(jt + 1);                    // next tile's lse2 arrives under this tile's MFMAs
-        } else {
-            // tile jt has landed when at most the newer tile is still in flight;
-            // behind the barrier every wave is done with tile jt-1, whose buffer the next request overwrites
-            wait_tiles_in_flight(min(NB - 2, p.NT - 1 - jt), PER);
-            __builtin_amdgcn_s_barrier();
-            if (jt + NB - 1 < p.NT) dma_tile(jt + NB - 1);
+        for (int e = 0; e < 16; ++e) nl[e] = lse_nx[e];
+        if (jt + 1 < p.NT) load_lse(jt + 1);               // next tile's -lse2 arrives under this tile's MFMAs
+        const uint16_t* kt = p.KcF + ((size_t)c * p.NT + jt) * KT_U16 + lane * 8;
+        const uint16_t* vt = p.VtF + ((size_t)c * p.NT + jt) * VT_U16 + lane * 8;
+        const uint16_t* kt_lo = X3 ? p.KcF_lo + ((size_t)c * p.NT + jt) * KT_U16 + lane * 8 : nullptr;
+        const uint16_t* vt_lo = X3 ? p.VtF_lo + ((size_t)c * p.NT + jt) * VT_U16 + lane * 8 : nullptr;
+        bf16x8 ah[8], al[X3 ? 8 : 1];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 u = *reinterpret_cast<const float4*>(lse_lds + (jt % NB) * 32 + 8 * q);
-                lse[4 * q + 0] = u.x; lse[4 * q + 1] = u.y; lse[4 * q + 2] = u.z; lse[4 * q + 3] = u.w;
-            }
+        for (int ks = 0; ks < 8; ++ks) {                   // fragment reads first, then the MFMA chain (see ar_stats)
+            ah[ks] = ld_frag(kt + ks * 512);
+            if (X3) al[ks] = ld_frag(kt_lo + ks * 512);
         }
-        if (active) {
-            const uint16_t* kt;
-            const uint16_t* vt;
-            const uint16_t* kt_lo = nullptr;
-            const uint16_t* vt_lo = nullptr;
-            if (CHOSEN) {
-                kt = p.KcF + ((size_t)c * p.NT + jt) * KT_U16 + lane * 8;
-                vt = p.VtF + ((size_t)c * p.NT + jt) * VT_U16 + lane * 8;
-                if (X3) {
-                    kt_lo = p.KcF_lo + ((size_t)c * p.NT + jt) * KT_U16 + lane * 8;
-                    vt_lo = p.VtF_lo + ((size_t)c * p.NT + jt) * VT_U16 + lane * 8;
-                }
-            } else {
-                kt = lds + (jt % NB) * NBUF_U16 + lane * 8;
-                vt = kt + KT_U16;
-                if (X3) { kt_lo = kt + PART_U16; vt_lo = vt + PART_U16; }
-            }
-            // S^T tile = Kc[jt] * Kq[it]^T
-            f32x16 acc;
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x16 acc = proto_s_chain<X3, false>(nl, ah, al, q_hi, q_lo);
+        bf16x8 vh[8], vl[X3 ? 8 : 1];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-            {   // fragment reads first, then the MFMA chain (see ar_stats)
-                bf16x8 ah[8], al[X3 ? 8 : 1];
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks) {
-                    ah[ks] = ld_frag(kt + ks * 512);
-                    if (X3) al[ks] = ld_frag(kt_lo + ks * 512);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks) {
-                    acc = mfma16<F16>(ah[ks], q_hi[ks], acc);
-                    if (X3) {
-                        acc = MFMA_BF16(ah[ks], q_lo[ks], acc);
-                        acc = MFMA_BF16(al[ks], q_hi[ks], acc);
-                    }
-                }
-            }
-            // the V^T fragments are requested before the exponentials: their LDS latency hides under the vector work
-            bf16x8 vh[8], vl[X3 ? 8 : 1];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                vh[i] = ld_frag(vt + i * 512);
-                if (X3) vl[i] = ld_frag(vt_lo + i * 512);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // A^T = exp2(S^T - lse2): accumulator rows 8s..8s+7 become k-step s of the B operand
-            bf16x8 a_hi[2], a_lo[2];
-            if constexpr (F16) {
-                // pairs through v_cvt_pk_f16_f32 (A^T <= 1: no saturation needed)
-                typedef float f32x2 __attribute__((ext_vector_type(2)));
-                typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    uint32_t w[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const f32x2 pe = {__builtin_amdgcn_exp2f(acc[8 * s + 2 * e] - lse[8 * s + 2 * e]),
-                                          __builtin_amdgcn_exp2f(acc[8 * s + 2 * e + 1] - lse[8 * s + 2 * e + 1])};
-                        w[e] = __builtin_bit_cast(uint32_t, __builtin_convertvector(pe, f16x2));
-                    }
-                    a_hi[s] = __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
-                }
-            } else {
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float pe = __builtin_amdgcn_exp2f(acc[8 * s + e] - lse[8 * s + e]);
-                        const __bf16 ph = (__bf16)pe;
-                        a_hi[s][e] = ph;
-                        if (X3) a_lo[s][e] = (__bf16)(pe - (float)ph);
-                    }
-            }
-            // P^T += V^T[jt] * A^T
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    pacc[dt] = mfma16<F16>(vh[dt * 2 + s], a_hi[s], pacc[dt]);
-                    if (X3) {
-                        pacc[dt] = MFMA_BF16(vh[dt * 2 + s], a_lo[s], pacc[dt]);
-                        pacc[dt] = MFMA_BF16(vl[dt * 2 + s], a_hi[s], pacc[dt]);
-                    }
-                }
+        for (int i = 0; i < 8; ++i) {
+            vh[i] = ld_frag(vt + i * 512);
+            if (X3) vl[i] = ld_frag(vt_lo + i * 512);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 a_hi[2], a_lo[2];
+        proto_exp<X3, false>(acc, a_hi, a_lo);
+        proto_p_chain<X3, false>(pacc, vh, vl, a_hi, a_lo);
     }
-    if (!active) return;
-
     // epilogue: lane owns query tuple i = 32 it + r; pacc[dt][reg] = P[i][32 dt + acc_row(reg,h)]
     const int i = it * 32 + r;
-    const bool ivalid = i < p.T;
-    float ss = 0.f;
-    if (ivalid) {
-        // Vq of the lane's tuple comes from the fragment image ar_tuples wrote: 16 fully coalesced 1-KiB wave loads.
-        // (Rebuilding it here from the per-frame projections -- 48 loads per lane, every lane another 512-byte row --
-        // kept the CU's address unit busier than the matrix cores: the kernel was bound by its epilogue.)
-        const float* vq = p.VqF + (((size_t)b * p.NT + it) * 16 * 64 + lane) * 4;
-        float* dout = CHOSEN ? p.diff + ((size_t)b * p.T + i) * 128 + 4 * h : nullptr;
+    if (i >= p.T) return;
+    const float* vq = p.VqF + (((size_t)b * p.NT + it) * 16 * 64 + lane) * 4;
+    float* dout = p.diff + ((size_t)b * p.T + i) * 128 + 4 * h;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
+    for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int d = 32 * dt + 8 * q;
-                const float4 x = *reinterpret_cast<const float4*>(vq + (dt * 4 + q) * 256);
-                float4 df;
-                df.x = x.x - pacc[dt][4 * q + 0];
-                df.y = x.y - pacc[dt][4 * q + 1];
-                df.z = x.z - pacc[dt][4 * q + 2];
-                df.w = x.w - pacc[dt][4 * q + 3];
-                if (CHOSEN) *reinterpret_cast<float4*>(dout + d) = df;
-                ss += df.x * df.x + df.y * df.y + df.z * df.z + df.w * df.w;
-            }
-    }
-    if (!CHOSEN) {
-#pragma unroll
-        for (int sh = 32; sh >= 1; sh >>= 1) ss += __shfl_xor(ss, sh, 64);
-        if (lane == 0) p.part[((size_t)b * p.n + c) * p.NT + it] = ss;
-    }
+        for (int q = 0; q < 4; ++q) {
+            const float4 x = *reinterpret_cast<const float4*>(vq + (dt * 4 + q) * 256);
+            float4 df;
+            df.x = x.x - pacc[dt][4 * q + 0];
+            df.y = x.y - pacc[dt][4 * q + 1];
+            df.z = x.z - pacc[dt][4 * q + 2];
+            df.w = x.w - pacc[dt][4 * q + 3];
+            *reinterpret_cast<float4*>(dout + 32 * dt + 8 * q) = df;
+        }
 }
 
-int launch_ar_proto(const ArProtoArgs& a0, hipStream_t st) {
-    ArProtoArgs a = a0;
+int launch_ar_proto(const ArProtoArgs& a, hipStream_t st) {
     const bool chosen = a.chosen != nullptr;
-    dim3 grid(cdiv(a.B * a.NT, 8));
-    a.wt = PROTO_WT;
-    if (!chosen) {
-        const int nxl = cdiv(cdiv(a.B * a.NT, 8), 8);               // window groups per XCD
-        a.wt = std::min(PROTO_WT, nxl);                             // a few windows: no grid padding to a full L2 block
-        grid = dim3(8 * cdiv(nxl, a.wt) * cdiv(a.n, PROTO_CT) * (a.wt * PROTO_CT));
-    }
     if (a.f16 && (a.x3 || chosen)) {
         set_error("ar_proto: fp16 fragments are the all-classes pass's; the arg-max class's pass runs on the bf16 hi + lo images");
         return ISB_ERR_INVALID;
     }
-    if (a.f16) {
-        hipLaunchKernelGGL((ar_proto_kernel<false, false, true>), grid, dim3(512), 0, st, a);
-    } else if (a.x3) {
-        if (chosen) hipLaunchKernelGGL((ar_proto_kernel<true, true>), grid, dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((ar_proto_kernel<true, false>), grid, dim3(512), 0, st, a);
+    if (chosen) {
+        dim3 grid(cdiv(a.B * a.NT, 8));
+        if (a.x3) hipLaunchKernelGGL((ar_proto_chosen_kernel<true>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((ar_proto_chosen_kernel<false>), grid, dim3(512), 0, st, a);
     } else {
-        if (chosen) hipLaunchKernelGGL((ar_proto_kernel<false, true>), grid, dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((ar_proto_kernel<false, false>), grid, dim3(512), 0, st, a);
+        ArProtoArgs b = a;
+        const int nxl = cdiv(cdiv(a.B * a.NT, 8), 8);               // window groups per XCD
+        b.wt = std::min(PROTO_WT, nxl);                             // a few windows: no grid padding to a full L2 block
+        dim3 grid(8 * cdiv(nxl, b.wt) * cdiv(a.n, PROTO_CT) * b.wt);
+        if (a.f16) hipLaunchKernelGGL((ar_proto_all_kernel<false, true>), grid, dim3(512), 0, st, b);
+        else if (a.x3) hipLaunchKernelGGL((ar_proto_all_kernel<true, false>), grid, dim3(512), 0, st, b);
+        else hipLaunchKernelGGL((ar_proto_all_kernel<false, false>), grid, dim3(512), 0, st, b);
     }
     ISB_LAUNCHED("ar_proto", st);
     return ISB_OK;

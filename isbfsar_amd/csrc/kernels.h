@@ -65,7 +65,7 @@ struct ArStatsArgs {
     const uint16_t* KcF;    // [n][NT][8][64][8]
     const uint16_t* KcF_lo;
     const float* ub;        // [n][Tp]
-    float* lse2;            // out [B][n][Tp]: log2 sum_i exp2(s'[i,j])
+    float* lse2;            // out [B][n][Tp]: -log2 sum_i exp2(s'[i,j])  (negated: the C operand of ar_proto's S^T chain)
     int B, n, T, NT;
     int x3;
     int f16;                // KqF / KcF hold fp16 fragments (ArTupleArgs.KF16): v_mfma_f32_32x32x16_f16; not with x3 / chosen
@@ -82,7 +82,7 @@ struct ArProtoArgs {
     const uint16_t* KcF_lo;
     const uint16_t* VtF;
     const uint16_t* VtF_lo;
-    const float* lse2;      // [B][n][Tp]
+    const float* lse2;      // [B][n][Tp], negated (ArStatsArgs.lse2)
     const float* proj;      // [B*L,512] query projections (Av at +256, Bv at +384)
     const float* VqF;       // query V in epilogue order (ArTupleArgs.VqF)
     const float* bv;        // [128]
@@ -95,6 +95,7 @@ struct ArProtoArgs {
     int f16;                // KqF / KcF / VtF hold fp16 fragments and A^T is formed in fp16; not with x3 / chosen
     int wt;                 // grid decode: window groups per L2 block (set by the launcher, <= PROTO_WT)
     int lse_per_window;     // chosen mode: lse2 is [B][Tp] (ArStatsArgs.chosen), not [B][n][Tp]
+    uint64_t* stamps;       // tuning probe (all-classes pass): per wave of the first 64 workgroups [prologue, tile loop, epilogue] cycles + start
 };
 int launch_ar_proto(const ArProtoArgs& a, hipStream_t st);
 

@@ -48,9 +48,9 @@ for f in sorted(set(fetch) | set(write)):
 if len(sys.argv) > 5:
     import re
 
-    # the all-classes instantiation, whatever its operand type: ar_proto_kernel<X3, CHOSEN = false, F16> -- the second template
-    # argument (round 3's fp16 operands added a third one, which a literal "<false, false>" no longer matched)
-    ALL_CLASSES = {"ar_proto": re.compile(r"ar_proto_kernel<\s*(?:true|false)\s*,\s*false\b"), "ar_stats": re.compile(r"ar_stats_kernel<")}
+    # the all-classes pass, whatever its operand type (the arg-max class's pass is ar_proto_chosen_kernel / ar_stats_kernel<true, ..>:
+    # bf16 hi + lo images)
+    ALL_CLASSES = {"ar_proto": re.compile(r"ar_proto_all_kernel<"), "ar_stats": re.compile(r"ar_stats_kernel<\s*false\b")}
 
     def per_launch(path, counter, rx):
         tot = n = 0
