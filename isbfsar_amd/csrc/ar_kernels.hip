@@ -147,7 +147,6 @@ __global__ __launch_bounds__(512) void ar_tuples_k_kernel(ArTupleArgs p) {
     var *= (1.f / 128.f);
     const float rstd = 1.0f / sqrtf(var + 1e-5f);
     uint16_t hi[8], lo[8], hf[8];
-    float nrm = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         float y = 0.f;
@@ -156,8 +155,6 @@ __global__ __launch_bounds__(512) void ar_tuples_k_kernel(ArTupleArgs p) {
         hi[e] = f2bf(y);
         const float yh = bf2f(hi[e]);
         lo[e] = f2bf(y - yh);
-        const float used = p.KF_lo ? yh + bf2f(lo[e]) : yh;
-        nrm += used * used;
     }
     if (p.VqF) {
         // query side: V of the tuple in f32, (Av[f0] + Bv[f1]) + bv as ar_proto's epilogue used to rebuild it for every
@@ -193,17 +190,6 @@ __global__ __launch_bounds__(512) void ar_tuples_k_kernel(ArTupleArgs p) {
         o.x = hf[0] | ((uint32_t)hf[1] << 16); o.y = hf[2] | ((uint32_t)hf[3] << 16);
         o.z = hf[4] | ((uint32_t)hf[5] << 16); o.w = hf[6] | ((uint32_t)hf[7] << 16);
         *reinterpret_cast<uint4*>(p.KF16 + off) = o;
-    }
-    if (p.ub) {   // support side: ub[item][t] = |kc_t| * bound(|kq'|)
-        __syncthreads();
-        red[slot][r] = nrm;
-        __syncthreads();
-        if (slot == 0) {
-            float n2 = 0.f;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) n2 += red[q][r];
-            p.ub[(size_t)item * p.NT * 32 + t] = sqrtf(n2) * p.qnorm_bound;
-        }
     }
 }
 

@@ -50,11 +50,9 @@ struct ArTupleArgs {
     uint16_t* VtF_lo;       // out or null
     uint16_t* KF16;         // out or null: the same K image in IEEE fp16 (ISB_AR_PREC_F16: operands of the all-classes pass)
     uint16_t* VtF16;        // out or null: the V^T image in fp16
-    float* ub;              // out (support only): [n_items][Tp] = |kc_j| * qnorm_bound, or null
     float* VqF;             // out (query only) or null: f32 V of every tuple in ar_proto's epilogue order,
                             // [item][it][piece = 4 dt + q][lane = 32 h + r][4] = V[32 it + r][32 dt + 8 q + 4 h ..+4]
     float kscale;           // folded into K before rounding (query: log2(e)/sqrt(128); support: 1)
-    float qnorm_bound;      // upper bound of |kq'| (support side only)
     int n_items, L, T, NT;
 };
 int launch_ar_tuples(const ArTupleArgs& a, hipStream_t st);
@@ -64,7 +62,6 @@ struct ArStatsArgs {
     const uint16_t* KqF_lo;
     const uint16_t* KcF;    // [n][NT][8][64][8]
     const uint16_t* KcF_lo;
-    const float* ub;        // [n][Tp]
     float* lse2;            // out [B][n][Tp]: -log2 sum_i exp2(s'[i,j])  (negated: the C operand of ar_proto's S^T chain)
     int B, n, T, NT;
     int x3;
