@@ -16,7 +16,7 @@ for path in sys.argv[2:]:
         k = r["Kernel_Name"]
         if "isb::" not in k:
             continue
-        k = k.replace("void ", "").split("(")[0]
+        k = k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         disp[(k, r["Counter_Name"])].add(r["Dispatch_Id"])
 out = {"_how": __doc__, "kernels": {}}

@@ -48,7 +48,7 @@ tot = 0.0
 sol = 0.0
 for (label, fl, by), r in zip(seq, last):
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
-    a = agg.setdefault(label, [0.0, 0.0, 0, r["Kernel_Name"].replace("void isb::", "")[:36], 0.0, 0.0])
+    a = agg.setdefault(label, [0.0, 0.0, 0, r["Kernel_Name"].replace("void isb::", "").replace("(anonymous namespace)::", "")[:36], 0.0, 0.0])
     a[0] += d; a[1] += fl; a[2] += 1; a[4] += by
     a[5] += max(fl / PEAK_F, by / PEAK_B) * 1e3
     tot += d
