@@ -29,7 +29,7 @@ struct BlockW {
     bool f16_in = false, f16 = false;
     int cin = 0, cout = 0, cexp = 0, stride = 1, cse = 0, in_hw = 0, out_hw = 0;
     ConvW expand, project;
-    DevBuf dw_w, dw_w16, dw_b, se_w1, se_b1, se_w2, se_b2;   // dw_w: the 16-bit-rounded taps as f32, dw_w16: the 16-bit taps
+    DevBuf dw_w16, dw_b, se_w1, se_b1, se_w2, se_b2;   // dw_w16: the depthwise taps in the stage's 16-bit type
     DevBuf mbf_w1p;                   // stride-1 MBConv blocks with 384 inputs on 8 x 8 maps: the expand weights in fragment order (mbfront8_kernel)
     DevBuf mb_w1p, mb_w2p, mb_se1p;   // stride-1 blocks of the 8 x 8 stages: the weights in mb8_chain_kernel's streaming layouts (conv_mb8.hip)
 };
@@ -586,8 +586,7 @@ extern "C" int isb_hpe_load_weights(isb_hpe* h, const void* blob, size_t nbytes)
                 const BlobTensor *sc, *sh, *w1, *b1, *w2, *b2;
                 ISB_TRY(blob_get(m, (p + ".dw.scale").c_str(), b->cexp, 1, &sc));
                 ISB_TRY(blob_get(m, (p + ".dw.shift").c_str(), b->cexp, 1, &sh));
-                std::vector<float> wt((size_t)9 * b->cexp);      // tap-major, scale folded, rounded to bf16 (fp16 in the fp16 stages) like every conv weight
-                std::vector<uint16_t> wt16(wt.size());
+                std::vector<uint16_t> wt16((size_t)9 * b->cexp);  // tap-major, scale folded, rounded to bf16 (fp16 in the fp16 stages) like every conv weight
                 for (int c = 0; c < b->cexp; ++c)
                     for (int t = 0; t < 9; ++t) {
                         const float wf = it->second.data[(size_t)c * 9 + t] * sc->data[c];
@@ -596,11 +595,9 @@ extern "C" int isb_hpe_load_weights(isb_hpe* h, const void* blob, size_t nbytes)
                             uint16_t hb;
                             memcpy(&hb, &hh, 2);
                             wt16[(size_t)t * b->cexp + c] = hb;
-                            wt[(size_t)t * b->cexp + c] = (float)hh;
                         } else {
                             const uint16_t hb = bf16_rne(wf);
                             wt16[(size_t)t * b->cexp + c] = hb;
-                            wt[(size_t)t * b->cexp + c] = bf16_to_float(hb);
                         }
                     }
                 if (h->mbf8_on && b->stride == 1 && b->in_hw == 8 && b->cin == 384 && b->f16_in == b->f16) {
@@ -608,7 +605,6 @@ extern "C" int isb_hpe_load_weights(isb_hpe* h, const void* blob, size_t nbytes)
                     ISB_TRY(launch_mb8_pack_frag(b->expand.w16.as<uint16_t>(), b->mbf_w1p.p, b->cexp, b->cin, 1, st));
                     ISB_HIP(hipStreamSynchronize(st));
                 }
-                ISB_TRY(upload(b->dw_w, wt.data(), wt.size() * 4));
                 ISB_TRY(upload(b->dw_w16, wt16.data(), wt16.size() * 2));
                 ISB_TRY(upload(b->dw_b, sh->data, (size_t)b->cexp * 4));
                 ISB_TRY(blob_get(m, (p + ".se.w1").c_str(), b->cse, b->cexp, &w1));

@@ -140,11 +140,6 @@ struct ConvArgs {
     int f16;
     int variant;            // tile variant, 0 = choose by Cout (conv_kernels.hip)
     const uint16_t* zeros;  // >= 16 bytes of zeros (source of padding taps for the LDS-DMA kernels)
-    // fused MBConv front half (launch_conv_expand_dw): depthwise 3x3 + SE pool applied to the staged tile
-    const float* dw_w;      // f32 [9][Cout] tap-major, BN scale folded
-    const float* dw_bias;   // f32 [Cout]
-    uint16_t* dw_out;       // bf16 [B,OH,OW,Cout] depthwise output D
-    float* pooled;          // f32 [B,Cout] spatial mean of D
     // workgroup -> tile mapping (set by launch_conv_igemm): 0 = (blockIdx.x, blockIdx.y) = (M tile, N tile);
     // 1/2 = 1-D grid decoded per XCD (workgroup id % 8 = XCD): all N tiles of an M tile run back to back on
     // ONE XCD, so its L2 fetches the A rows once (1: M tiles interleaved over XCDs, 2: contiguous M ranges)
@@ -173,7 +168,6 @@ struct ConvArgs {
 int launch_conv_igemm(const ConvArgs& a, hipStream_t st);
 // conv_ws.hip: the weights-stationary expand GEMMs (tile variants 181 - 188); aa = a with the grid fields the launcher fills
 int launch_conv_ws(const ConvArgs& a, ConvArgs& aa, int v, hipStream_t st);
-int launch_conv_expand_dw(const ConvArgs& a, hipStream_t st);
 int launch_fused_mb(const ConvArgs& a, hipStream_t st);
 int launch_splitk_reduce(const ConvArgs& a, hipStream_t st);
 
