@@ -12,6 +12,8 @@ template <int OP>
 __global__ __launch_bounds__(512) void rate_kernel(uint64_t* out, const uint32_t* in, float* sink) {
     uint32_t x = in[threadIdx.x & 63], w = in[64 + (threadIdx.x & 63)];
     float a[16];
+    float pk[2] = {1.0f, 1.0f};
+    asm volatile("" : "+v"(*reinterpret_cast<float2*>(&pk)));
 #pragma unroll
     for (int i = 0; i < 16; ++i) a[i] = (float)i;
     const uint64_t t0 = __builtin_amdgcn_s_memtime();
@@ -24,6 +26,10 @@ __global__ __launch_bounds__(512) void rate_kernel(uint64_t* out, const uint32_t
 #define RCP(i) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
 #define CVT(i) asm volatile("v_cvt_pk_f16_f32 %0, %0, %1" : "+v"(a[i]) : "v"(x));
 #define AND(i) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[i]) : "v"(x));
+#define PKMUL(i) if ((i) % 2 == 0) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(*reinterpret_cast<float2*>(&a[i])) : "v"(*reinterpret_cast<float2*>(&pk)));
+#define PKFMA(i) if ((i) % 2 == 0) asm volatile("v_pk_fma_f32 %0, %0, %1, %0" : "+v"(*reinterpret_cast<float2*>(&a[i])) : "v"(*reinterpret_cast<float2*>(&pk)));
+#define PKADD(i) if ((i) % 2 == 0) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(*reinterpret_cast<float2*>(&a[i])) : "v"(*reinterpret_cast<float2*>(&pk)));
+#define MUL(i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(x));
         if constexpr (OP == 0) { REP16(DOT2C) }
         if constexpr (OP == 1) { REP16(FMAMIX) }
         if constexpr (OP == 2) { REP16(FMA) }
@@ -32,6 +38,10 @@ __global__ __launch_bounds__(512) void rate_kernel(uint64_t* out, const uint32_t
         if constexpr (OP == 5) { REP16(CVT) }
         if constexpr (OP == 6) { REP16(DOT2CB) }
         if constexpr (OP == 7) { REP16(AND) }
+        if constexpr (OP == 8) { REP16(PKMUL) REP16(PKMUL) }
+        if constexpr (OP == 9) { REP16(PKFMA) REP16(PKFMA) }
+        if constexpr (OP == 10) { REP16(PKADD) REP16(PKADD) }
+        if constexpr (OP == 11) { REP16(MUL) }
     }
     const uint64_t t1 = __builtin_amdgcn_s_memtime();
     float s = 0.f;
@@ -68,5 +78,9 @@ int main() {
     run<4>("v_rcp_f32", d_out, d_in, d_sink);
     run<5>("v_cvt_pk_f16_f32", d_out, d_in, d_sink);
     run<7>("v_and_b32", d_out, d_in, d_sink);
+    run<11>("v_mul_f32", d_out, d_in, d_sink);
+    run<8>("v_pk_mul_f32", d_out, d_in, d_sink);
+    run<10>("v_pk_add_f32", d_out, d_in, d_sink);
+    run<9>("v_pk_fma_f32", d_out, d_in, d_sink);
     return 0;
 }
