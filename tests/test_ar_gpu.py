@@ -348,3 +348,28 @@ def test_hybrid_input_type_matches_reference_golden(golden_dir, precision):
     # the skeleton-only calls are refused on a hybrid handle, loudly
     with pytest.raises(Exception):
         eng.set_support(poses=ss)
+
+
+def test_phase_clocks_of_the_all_classes_pass_do_not_change_results():
+    """isb_debug_ar_stamps (tools/exp_ar_stamps.py): arming the in-kernel clocks of ar_proto_all_kernel leaves the logits bit for
+    bit as they were, and the first workgroups report a prologue, a tile loop over their class group (13 classes = a group of 8 and a
+    group of 5, 14 tiles each) and one distance epilogue per class."""
+    import ctypes as C
+    from isbfsar_amd import _lib
+    L, J, way, B = 30, 122, 13, 5
+    eng = _engine(L, J, way, precision="f16", max_batch=8)
+    eng.set_support(poses=synth.skeleton_windows(way, L, J, seed=3))
+    q = synth.skeleton_windows(B, L, J, seed=4)
+    ref = eng.infer(q)[0].copy()
+    _lib.check(_lib.lib().isb_debug_ar_stamps(eng._h, 1, None), "stamps on")
+    armed = eng.infer(q)[0].copy()
+    out = np.zeros((64 * 8 * 4,), np.uint64)
+    _lib.check(_lib.lib().isb_debug_ar_stamps(eng._h, 0, out.ctypes.data_as(C.c_void_p)), "stamps off")
+    assert np.array_equal(ref, armed)
+    t = out.reshape(64, 8, 4).astype(np.int64)
+    ok = t[:, :, 1] > 0
+    assert ok.any()
+    tiles = t[:, :, 3][ok]
+    assert set(np.unique(tiles)) <= {8 * 14, 5 * 14}
+    assert (t[:, :, 0][ok] > 0).all() and (t[:, :, 2][ok] > 0).all() and (t[:, :, 2][ok] < t[:, :, 1][ok]).all()
+    assert np.array_equal(eng.infer(q)[0], ref)            # disarmed again
