@@ -511,10 +511,16 @@ __global__ __launch_bounds__(512, 2) void ar_proto_all_kernel(ArProtoArgs p) {
     constexpr int VT_U16 = 4 * 2 * 64 * 8;                // V^T tile (8 KiB)
     constexpr int PART_U16 = KT_U16 + VT_U16;
     constexpr int NBUF_U16 = PART_U16 * (X3 ? 2 : 1);
-    constexpr int NB = 4;                                 // ring: tile t is consumed while t+1 (landed at the barrier), t+2, t+3 are in flight
+    constexpr int NB = X3 ? 4 : 3;                        // ring: tile t is consumed while t+1 (landed at the barrier) .. t+NB-1 are in flight
+                                                          // (a ring of 3 leaves room for 13 resident query-V pieces: +3 % over 4 and 10)
     constexpr int PER = X3 ? 5 : 3;                       // DMA instructions per wave and tile (K, V^T [, lo parts], lse2)
     constexpr int LSE_U16 = 8 * NB * 64;                  // per wave and ring slot: the tile's 32 lse2 values (128 B)
-    __shared__ __attribute__((aligned(16))) uint16_t lds[NB * NBUF_U16 + LSE_U16];
+    // the LDS the ring leaves free holds the first NVQ of each slot's 16 query-V pieces (1 KiB each, f32, the epilogue's lane order)
+    // for the whole kernel: a slot's 16 KiB are needed once per class, at moments too far apart for L2 to keep them
+    constexpr int NVQ = X3 ? 3 : 13;
+    constexpr int VQ_U16 = 8 * NVQ * 512;
+    __shared__ __attribute__((aligned(16))) uint16_t lds[NB * NBUF_U16 + LSE_U16 + VQ_U16];
+    static_assert((NB * NBUF_U16 + LSE_U16 + VQ_U16) * 2 <= 160 * 1024, "LDS");
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, r = lane & 31;
     // 1-D grid decoded per XCD (workgroup id % 8 = XCD) into blocks of p.wt window groups, one class group each, window groups
     // fastest: the workgroups an XCD runs at one time walk through the same PROTO_CT classes, whose K / V^T tiles (1.8 MiB) stay in
@@ -556,10 +562,14 @@ __global__ __launch_bounds__(512, 2) void ar_proto_all_kernel(ArProtoArgs p) {
         }
         if (lane < 8) dma16(lse_src + (size_t)t * 32, lse0 + (t % NB) * 128);
     };
-    // the first tiles are requested BEFORE the wave's Kq fragments: the two latencies overlap
+    // the first tiles (and the slot's resident query-V pieces) are requested BEFORE the wave's Kq fragments: the latencies overlap
 #pragma unroll
     for (int t = 0; t < NB - 1; ++t)
         if (t < TT) dma_tile(t);
+    const float* vq = p.VqF + (size_t)__builtin_amdgcn_readfirstlane(b * p.NT + it) * (16 * 64 * 4);
+    const uint32_t vq_lds0 = lds_base + (NB * NBUF_U16 + LSE_U16) * 2 + wave_u * (NVQ * 1024);
+#pragma unroll
+    for (int k = 0; k < NVQ; ++k) dma16(vq + k * 256 + lane * 4, vq_lds0 + k * 1024);
     bf16x8 q_hi[8], q_lo[8];
     {
         const uint16_t* base = p.KqF + (((size_t)b * p.NT + it) * 8 * 64 + lane) * 8;
@@ -586,10 +596,10 @@ __global__ __launch_bounds__(512, 2) void ar_proto_all_kernel(ArProtoArgs p) {
     // epilogue operands: lane owns query tuple i = 32 it + r; pacc[dt][reg] = P[i][32 dt + acc_row(reg, h)]; Vq of the lane's
     // tuple comes from the fragment image ar_tuples wrote (16 fully coalesced 1-KiB wave loads)
     const bool ivalid = it * 32 + r < p.T;
-    // (a buffer resource over the slot's 16 KiB + one lane offset: the 16 loads address through scalar registers, not 16 VGPR pairs)
-    const float* vq = p.VqF + (size_t)__builtin_amdgcn_readfirstlane(b * p.NT + it) * (16 * 64 * 4);
+    // (a buffer resource over the slot's 16 KiB + one lane offset: the loads address through scalar registers, not 16 VGPR pairs)
     const __amdgpu_buffer_rsrc_t vq_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vq), 0, 16 * 64 * 16, 0x00020000);
     const int vq_lane = lane * 16;
+    const unsigned char* vq_res = reinterpret_cast<const unsigned char*>(lds + NB * NBUF_U16 + LSE_U16) + wave * (NVQ * 1024) + lane * 16;
     int t = 0;
     for (int cc = 0; cc * p.NT < TT; ++cc) {
         for (int jt = 0; jt < p.NT; ++jt, ++t) {
@@ -637,7 +647,9 @@ __global__ __launch_bounds__(512, 2) void ar_proto_all_kernel(ArProtoArgs p) {
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         u32x4 x[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) x[k] = __builtin_amdgcn_raw_buffer_load_b128(vq_rsrc, vq_lane, k * 1024, 0);
+        for (int k = NVQ; k < 16; ++k) x[k] = __builtin_amdgcn_raw_buffer_load_b128(vq_rsrc, vq_lane, k * 1024, 0);
+#pragma unroll
+        for (int k = 0; k < NVQ; ++k) x[k] = *reinterpret_cast<const u32x4*>(vq_res + k * 1024);
         float ss = 0.f;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)

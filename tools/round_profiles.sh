@@ -1,8 +1,17 @@
 #!/bin/bash
-# Regenerates the round's evidence under gpurun_out/ (copy into profiles/ afterwards: tools/copy_profiles.py rNN). Run on the MI355X box.
+# Regenerates the round's evidence under gpurun_out/ (copy into profiles/ afterwards: tools/copy_profiles.py rNN). Run on the MI355X box:
+#   bash tools/round_profiles.sh rNN
+ROUND=${1:?usage: round_profiles.sh rNN}
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
+echo "== PMC traffic"
+ISB_HPE_LANES=1 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o run -- python3 bench.py --workload hpe --steps 1 --warmup 1 --no-cpu-baseline --no-extras --min-gpu-seconds 0 > gpurun_out/pmc_fetch.log 2>&1
+ISB_HPE_LANES=1 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o run -- python3 bench.py --workload hpe --steps 1 --warmup 1 --no-cpu-baseline --no-extras --min-gpu-seconds 0 > gpurun_out/pmc_write.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_ar_fetch -o run -- python3 bench.py --workload ar --steps 1 --warmup 1 --no-cpu-baseline --no-extras --min-gpu-seconds 0 > gpurun_out/pmc_ar_fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_ar_write -o run -- python3 bench.py --workload ar --steps 1 --warmup 1 --no-cpu-baseline --no-extras --min-gpu-seconds 0 > gpurun_out/pmc_ar_write.log 2>&1
+python3 tools/collect_traffic.py gpurun_out/pmc_fetch/run_counter_collection.csv gpurun_out/pmc_write/run_counter_collection.csv gpurun_out/traffic.json gpurun_out/pmc_ar_fetch/run_counter_collection.csv gpurun_out/pmc_ar_write/run_counter_collection.csv
+cp gpurun_out/traffic.json profiles/${ROUND}_traffic.json   # bench.py reads the latest profiles/rNN_traffic.json: the lines below carry THIS session's bytes
 echo "== bench lines"
 for w in pipeline hpe ar stream det; do
   timeout -k 10 400 python bench.py --workload $w $( [ $w = stream ] && echo "--steps 300 --warmup 20" ) $( [ $w != pipeline ] && echo "--min-gpu-seconds 0" ) > gpurun_out/bench_$w.log 2>&1
@@ -32,12 +41,6 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun
 python3 tools/det_breakdown.py gpurun_out/prof_det/run_kernel_trace.csv > gpurun_out/det_breakdown.txt 2>&1 || true
 echo "== kernel stats (ar)"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_ar -o run -- python3 bench.py --workload ar --steps 3 --warmup 1 --no-cpu-baseline --min-gpu-seconds 0 > gpurun_out/prof_ar.log 2>&1
-echo "== PMC traffic"
-ISB_HPE_LANES=1 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o run -- python3 bench.py --workload hpe --steps 1 --warmup 1 --no-cpu-baseline --no-extras --min-gpu-seconds 0 > gpurun_out/pmc_fetch.log 2>&1
-ISB_HPE_LANES=1 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o run -- python3 bench.py --workload hpe --steps 1 --warmup 1 --no-cpu-baseline --no-extras --min-gpu-seconds 0 > gpurun_out/pmc_write.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_ar_fetch -o run -- python3 bench.py --workload ar --steps 1 --warmup 1 --no-cpu-baseline --no-extras --min-gpu-seconds 0 > gpurun_out/pmc_ar_fetch.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_ar_write -o run -- python3 bench.py --workload ar --steps 1 --warmup 1 --no-cpu-baseline --no-extras --min-gpu-seconds 0 > gpurun_out/pmc_ar_write.log 2>&1
-python3 tools/collect_traffic.py gpurun_out/pmc_fetch/run_counter_collection.csv gpurun_out/pmc_write/run_counter_collection.csv gpurun_out/traffic.json gpurun_out/pmc_ar_fetch/run_counter_collection.csv gpurun_out/pmc_ar_write/run_counter_collection.csv
 echo "== PMC matrix-pipe utilisation (SQ counters + GRBM_GUI_ACTIVE, own passes)"
 ISB_HPE_LANES=1 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_mfma_hpe -o run -- python3 bench.py --workload hpe --steps 1 --warmup 1 --no-cpu-baseline --no-extras --min-gpu-seconds 0 > gpurun_out/pmc_mfma_hpe.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_mfma_ar -o run -- python3 bench.py --workload ar --steps 1 --warmup 1 --no-cpu-baseline --no-extras --min-gpu-seconds 0 > gpurun_out/pmc_mfma_ar.log 2>&1
