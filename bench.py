@@ -30,7 +30,7 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "bf16x3": 2500.0 / 3.0, "f32"
 HBM_PEAK_GBS = 8000.0
 
 
-def parse():
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -57,7 +57,11 @@ def parse():
     ap.add_argument("--min-gpu-seconds", type=float, default=12.0,
                     help="keep stepping (untimed, after all measurements) until the GPU phase has lasted this long, so that a coarse "
                          "utilisation sampler sees it (N = 1 only; 0 = off)")
-    return ap.parse_args()
+    return ap
+
+
+def parse():
+    return build_parser().parse_args()
 
 
 def self_launch(args) -> int:

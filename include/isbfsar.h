@@ -42,11 +42,16 @@ extern "C" {
 #define ISB_ERR_NOMEM (-5)
 
 /* precision of the two tuple-attention contractions (K10). MLP/projection/discriminator
- * GEMMs always run on the exact f32 MFMA path. */
-#define ISB_AR_PREC_BF16 0     /* bf16 operands, f32 accumulate                      */
+ * GEMMs always run on the exact f32 MFMA path.
+ * ABI version 2 (isb_version() == 2): 0 is "the library's default" and the default is fp16 operands, as for
+ * isb_hpe_cfg.precision; bf16 operands moved from 0 to 3. (Version 1: 0 = bf16. A zero-initialised isb_ar_cfg therefore
+ * gets fp16 attention operands now -- logits 2-13x closer to the fp32 reference at the same matrix rate)
+ * isb_ar_precision() returns the resolved value of a handle. */
+#define ISB_AR_PREC_DEFAULT 0  /* = ISB_AR_PREC_F16 */
 #define ISB_AR_PREC_BF16X3 1   /* split-bf16 (hi+lo, 3 MFMA / product), ~2^-16 rel.  */
 #define ISB_AR_PREC_F16 2      /* IEEE fp16 operands (11 significant bits, 8x bf16's resolution) at bf16's rate: K, V^T and the
                                   attention weights of the all-classes pass; the arg-max class's pass stays split-bf16 */
+#define ISB_AR_PREC_BF16 3     /* bf16 operands, f32 accumulate (round 3's default)  */
 
 const char* isb_last_error(void);
 int isb_version(void);
@@ -75,6 +80,8 @@ typedef struct isb_ar_cfg {
 
 int isb_ar_create(const isb_ar_cfg* cfg, isb_ar** out);
 void isb_ar_destroy(isb_ar* h);
+/* the handle's attention precision with the default resolved: ISB_AR_PREC_BF16X3 / _F16 / _BF16 (never 0); < 0 on a null handle */
+int isb_ar_precision(const isb_ar* h);
 
 /* ISBW blob (see isbfsar_amd/weights.py) holding the TRXOS state-dict tensors
  * features_extractor.sk.fc{1,2}, transformers.0.{k_linear,v_linear,norm_k},
@@ -151,7 +158,9 @@ typedef struct isb_hpe_cfg {
                                * is 2 MiB per frame. Any B is accepted by isb_hpe_forward (it micro-batches). */
     int32_t n_out_joints;     /* informational: joints per pose after selection (30 / 122) */
     int32_t precision;        /* 16-bit storage type of the backbone (weights AND activations; f32 accumulate everywhere):
-                               * 0 = default = 2.
+                               * 0 = default = 2. (CHANGED in round 4 with no version marker: until then 0 meant layout 3 below;
+                               *     a caller that zero-initialises the struct gets different output bits, ~2 % lower rate and
+                               *     the better parity. isb_version() >= 2 implies this meaning.)
                                * 2 = IEEE fp16 in every stage -- the precision the reference runs its backbone at (TensorRT
                                *     engines built with fp16=True, 7_create_engines.py:10). Same MFMA rate and bytes as bf16,
                                *     3 more mantissa bits; conversions saturate at +-65504. Closest 16-bit layout to the fp32
@@ -287,7 +296,7 @@ int isb_debug_hpe_mb8_stamps(isb_hpe* h, int32_t enable, uint64_t* host_out);
 
 /* tuning probe of the all-classes attention pass (ar_kernels.hip ar_proto_kernel): enable != 0 arms in-kernel s_memtime stamps (the
  * following isb_ar_forward calls write them), enable == 0 copies them to host_out ([64 workgroups][8 waves][4] uint64_t: cycles of
- * the prologue, of the tile loop, of the epilogue, and the start clock) and disarms. tools/exp_ar_stamps.py */
+ * the prologue, of the tile loop, of the epilogue, and the number of tiles the wave walked) and disarms. tools/exp_ar_stamps.py */
 int isb_debug_ar_stamps(isb_ar* h, int32_t enable, uint64_t* host_out);
 
 /* test / tuning hook: a whole Fused-MBConv block (3x3 expand + BN + SiLU -> 1x1 project + BN [+ residual]) in ONE

@@ -11,9 +11,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # ISB_LIB_PATH: load another build of the SAME library (A/B timing of two builds inside one GPU session)
 LIB_PATH = os.environ.get("ISB_LIB_PATH") or os.path.join(_HERE, "csrc", "libisbfsar_hip.so")
 
-ISB_AR_PREC_BF16 = 0
+ISB_AR_PREC_DEFAULT = 0     # = ISB_AR_PREC_F16 (ABI version 2)
 ISB_AR_PREC_BF16X3 = 1
 ISB_AR_PREC_F16 = 2
+ISB_AR_PREC_BF16 = 3
 
 
 class IsbError(RuntimeError):
@@ -50,6 +51,7 @@ SIGNATURES = {
     "isb_device_count": (C.c_int, []),
     "isb_ar_create": (C.c_int, [C.POINTER(isb_ar_cfg), C.POINTER(_P)]),
     "isb_ar_destroy": (None, [_P]),
+    "isb_ar_precision": (C.c_int, [_P]),
     "isb_ar_load_weights": (C.c_int, [_P, _P, C.c_size_t]),
     "isb_ar_set_support": (C.c_int, [_P, _P, _P, C.c_int32]),
     "isb_ar_get_support_features": (C.c_int, [_P, _P]),

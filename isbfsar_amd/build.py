@@ -76,6 +76,65 @@ OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 GUARD_SRC = "wsreg_guard.cpp"          # defines isb_wsreg_verified(); compiled AFTER the check below with its result
 
 
+def _disassemble(lib_path: str) -> str:
+    """gfx950 disassembly of the library's code object, prefixed with a newline; on failure the reason (no leading newline)."""
+    if not os.path.exists(OBJDUMP):
+        return f"{OBJDUMP} not found: the built code cannot be verified"
+    with tempfile.TemporaryDirectory() as tmp:
+        so = os.path.join(tmp, "lib.so")
+        shutil.copy(lib_path, so)
+        r = subprocess.run([OBJDUMP, "--offloading", so], capture_output=True, cwd=tmp)
+        if r.returncode != 0:
+            return "llvm-objdump --offloading failed: " + r.stderr.decode(errors="replace")[-300:]
+        text = "\n"
+        for f in sorted(os.listdir(tmp)):
+            if f.startswith("lib.so.") and f.endswith("gfx950"):
+                d = subprocess.run([OBJDUMP, "-d", os.path.join(tmp, f)], capture_output=True, text=True)
+                if d.returncode != 0:
+                    return "llvm-objdump -d failed: " + d.stderr[-300:]
+                text += d.stdout
+    return text
+
+
+def mbfront8_wait_counted(lib_path: str):
+    """mbfront8_kernel (csrc/conv_mb8.hip) waits for the next sample's LDS-DMA input tiles with a hand-counted
+    `s_waitcnt vmcnt(5)`: exactly five vector-memory operations (four 16-byte D-row stores, one pooled-means store) may be
+    issued between those requests and the wait. A register spill (scratch traffic counts in vmcnt) or a store the compiler
+    split would leave tiles in flight at the barrier and the MFMAs would read stale LDS -- silently. So the built
+    code is checked: every instantiation must be free of scratch instructions and hold exactly four global_store_dwordx4 and
+    one global_store_dword between its loop's LDS-DMA requests and the end of the loop body (the stamp stores of the tuning
+    probe follow the loop). Returns None when the library passes, else the reason."""
+    text = _disassemble(lib_path)
+    if not text.startswith("\n"):
+        return text
+    kernels, cur = {}, None
+    for line in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            cur = m.group(1) if "mbfront8_kernel" in m.group(1) else None
+            if cur:
+                kernels[cur] = []
+        elif cur and line.strip():
+            kernels[cur].append(line.split("//")[0].split())
+    if len(kernels) < 2:
+        return f"only {len(kernels)} mbfront8_kernel instantiations found in the code object"
+    for name, lines in kernels.items():
+        ops = [t[0] for t in lines if t]
+        if any(o.startswith("scratch_") for o in ops):
+            return f"{name}: scratch (spill) instructions count in vmcnt"
+        if "vmcnt(5)" not in " ".join(" ".join(t) for t in lines):
+            return f"{name}: the counted wait is gone"
+        # the loop body: from the LAST LDS-DMA request (the next sample's tiles) to the backward branch; stamp stores come after it
+        last_dma = max(i for i, o in enumerate(ops) if o == "global_load_lds_dwordx4")
+        vm = [o for o in ops[last_dma + 1:] if o.startswith(("global_", "buffer_", "flat_"))]
+        body = vm[:5]
+        if sorted(body) != ["global_store_dword"] + ["global_store_dwordx4"] * 4:
+            return f"{name}: expected four global_store_dwordx4 + one global_store_dword behind the input requests, found {vm[:8]}"
+        if any(not o.startswith("global_store_dwordx") for o in vm[5:]):      # (behind the loop: only the probe's stamp stores)
+            return f"{name}: vector-memory operations besides the five stores behind the input requests: {vm[5:]}"
+    return None
+
+
 def wspipe_registers_private(lib_path: str):
     """gemm1x1_wspipe_kernel (csrc/conv_ws.hip) keeps global loads in flight in literally named registers -- a[200:255]
     with one wave per SIMD, v[228:255] with two -- that the register allocator sees only as clobbers of the request asm.
@@ -83,21 +142,9 @@ def wspipe_registers_private(lib_path: str):
     checked: disassemble every gemm1x1_wspipe_kernel instantiation and require that nothing but the requests
     (global_load_dwordx4) and their LDS writes (ds_write_b128) names a staging register. Returns None when the library
     passes, else the reason (also when llvm-objdump is missing: unverified = not trusted)."""
-    if not os.path.exists(OBJDUMP):
-        return f"{OBJDUMP} not found: the staging registers cannot be verified"
-    with tempfile.TemporaryDirectory() as tmp:
-        so = os.path.join(tmp, "lib.so")
-        shutil.copy(lib_path, so)
-        r = subprocess.run([OBJDUMP, "--offloading", so], capture_output=True, cwd=tmp)
-        if r.returncode != 0:
-            return "llvm-objdump --offloading failed: " + r.stderr.decode(errors="replace")[-300:]
-        text = ""
-        for f in sorted(os.listdir(tmp)):
-            if f.startswith("lib.so.") and f.endswith("gfx950"):
-                d = subprocess.run([OBJDUMP, "-d", os.path.join(tmp, f)], capture_output=True, text=True)
-                if d.returncode != 0:
-                    return "llvm-objdump -d failed: " + d.stderr[-300:]
-                text += d.stdout
+    text = _disassemble(lib_path)
+    if not text.startswith("\n"):
+        return text
     kernels, cur = {}, None
     for line in text.splitlines():
         m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
@@ -172,15 +219,19 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if jobs or force or not os.path.exists(LIB) or not os.path.exists(guard_o):
         # fail closed: link once without the guard's verdict, check the code the compiler actually produced,
         # then compile the verdict in. isb_wsreg_verified() == 0 makes conv_kernels.hip fall back to the tile kernels.
-        def guard(ok: int):
-            run([hipcc, "-O2", "-std=c++17", "-fPIC", f"-DISB_WSREG_VERIFIED={ok}", "-c", os.path.join(CSRC, GUARD_SRC), "-o", guard_o])
+        def guard(ok: int, ok8: int):
+            run([hipcc, "-O2", "-std=c++17", "-fPIC", f"-DISB_WSREG_VERIFIED={ok}", f"-DISB_MBF8_VERIFIED={ok8}", "-c",
+                 os.path.join(CSRC, GUARD_SRC), "-o", guard_o])
             run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", *objs, guard_o, "-ldl", "-o", LIB])
-        guard(0)
+        guard(0, 0)
         why = wspipe_registers_private(LIB)
-        if why is None:
-            guard(1)
-        else:
+        why8 = mbfront8_wait_counted(LIB)
+        if why is not None:
             print(f"[build] WARNING: weights-stationary expand kernels DISABLED (tile kernels are used instead): {why}", flush=True)
+        if why8 is not None:
+            print(f"[build] WARNING: fused front of the 8x8 MBConv blocks DISABLED (expand + depthwise launches run instead): {why8}", flush=True)
+        if why is None or why8 is None:
+            guard(int(why is None), int(why8 is None))
     return LIB
 
 

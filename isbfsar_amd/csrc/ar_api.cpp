@@ -116,8 +116,8 @@ extern "C" int isb_ar_create(const isb_ar_cfg* cfg, isb_ar** out) {
     ISB_REQUIRE(cfg->seq_len >= 2 && cfg->seq_len <= 64, ISB_ERR_INVALID, "seq_len %d outside [2,64]", cfg->seq_len);
     ISB_REQUIRE(cfg->n_joints >= 1 && cfg->n_joints <= 1024, ISB_ERR_INVALID, "n_joints %d outside [1,1024]", cfg->n_joints);
     ISB_REQUIRE(cfg->way_max >= 1 && cfg->way_max <= 4096, ISB_ERR_INVALID, "way_max %d outside [1,4096]", cfg->way_max);
-    ISB_REQUIRE(cfg->precision == ISB_AR_PREC_BF16 || cfg->precision == ISB_AR_PREC_BF16X3 || cfg->precision == ISB_AR_PREC_F16,
-                ISB_ERR_INVALID, "unknown precision %d", cfg->precision);
+    ISB_REQUIRE(cfg->precision >= ISB_AR_PREC_DEFAULT && cfg->precision <= ISB_AR_PREC_BF16, ISB_ERR_INVALID, "unknown precision %d",
+                cfg->precision);
     int ndev = 0;
     ISB_HIP(hipGetDeviceCount(&ndev));
     ISB_REQUIRE(cfg->device >= 0 && cfg->device < ndev, ISB_ERR_INVALID, "device %d not in [0,%d)", cfg->device, ndev);
@@ -126,6 +126,7 @@ extern "C" int isb_ar_create(const isb_ar_cfg* cfg, isb_ar** out) {
     ISB_REQUIRE(h, ISB_ERR_NOMEM, "out of host memory");
     h->cfg = *cfg;
     if (h->cfg.max_batch <= 0) h->cfg.max_batch = 1024;
+    if (h->cfg.precision == ISB_AR_PREC_DEFAULT) h->cfg.precision = ISB_AR_PREC_F16;     // one default end to end (include/isbfsar.h)
     h->L = cfg->seq_len;
     h->J = cfg->n_joints;
     h->D3 = 3 * h->J;
@@ -133,8 +134,8 @@ extern "C" int isb_ar_create(const isb_ar_cfg* cfg, isb_ar** out) {
     h->T = h->L * (h->L - 1) / 2;
     h->NT = cdiv(h->T, 32);
     h->Tp = h->NT * 32;
-    h->x3 = cfg->precision == ISB_AR_PREC_BF16X3;
-    h->f16 = cfg->precision == ISB_AR_PREC_F16;
+    h->x3 = h->cfg.precision == ISB_AR_PREC_BF16X3;
+    h->f16 = h->cfg.precision == ISB_AR_PREC_F16;
     ISB_HIP(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     *out = h.release();
     return ISB_OK;
@@ -152,6 +153,8 @@ extern "C" void isb_ar_destroy(isb_ar* h) {
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
+
+extern "C" int isb_ar_precision(const isb_ar* h) { return h ? h->cfg.precision : ISB_ERR_INVALID; }
 
 extern "C" int isb_ar_load_weights(isb_ar* h, const void* blob, size_t nbytes) {
     return isb::guard([&]() -> int {

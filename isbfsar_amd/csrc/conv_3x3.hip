@@ -181,6 +181,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_dma_kernel(ConvArgs p)
     const int nkt = p.K / CK;
     dma(std::integral_constant<int, 0>{});
     publish();
+    prio_matrix(p.exp);
     int kt = 0;
     for (; kt + 2 <= nkt; kt += 2) {
         dma(std::integral_constant<int, 1>{});
@@ -194,6 +195,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_dma_kernel(ConvArgs p)
         compute(std::integral_constant<int, 0>{});
         __syncthreads();
     }
+    prio_vector(p.exp);
     conv_epilogue<TM, TN, WGM, WGN, true, F16>(p, acc, lds, m0, n0, wm, wn, r, h, tid, bias_off);
 }
 
@@ -374,11 +376,11 @@ int launch_tiles_conv3x3(int v, const ConvArgs& a, ConvArgs& aa, hipStream_t st)
                 set_error("conv_igemm: variant 171 is the 3x3 stride-1 32 -> 32 convolution on 128-wide images (< 2 GiB)");
                 return ISB_ERR_INVALID;
             }
-            static bool attr_set = false;
-            if (!attr_set) {
+            static DevOnce attr_set;
+            if (attr_set.need()) {
                 ISB_HIP(hipFuncSetAttribute((const void*)conv3x3_c32_rows_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, HALO_LDS));
                 ISB_HIP(hipFuncSetAttribute((const void*)conv3x3_c32_rows_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, HALO_LDS));
-                attr_set = true;
+                attr_set.mark();
             }
             if (a.f16) hipLaunchKernelGGL(conv3x3_c32_rows_kernel<true>, dim3(a.B * (a.H / band)), dim3(512), HALO_LDS, st, aa, band);
             else hipLaunchKernelGGL(conv3x3_c32_rows_kernel<false>, dim3(a.B * (a.H / band)), dim3(512), HALO_LDS, st, aa, band);

@@ -35,7 +35,12 @@ static int choose_variant(const ConvArgs& a) {
         // tiles would leave most CUs idle -- 64 x 128 tiles of 4 waves double the workgroups
         return c3 ? 168 : 150;
     }
-    if (g1 && !a.gate && !a.res && !a.out_f32 && a.act <= 1 && a.splits <= 1 && ws_ok &&
+#ifdef ISB_BUILD_PROBES
+    const bool ws_act = a.act <= 1;                     // the probe build keeps the no-activation instantiations of 184 / 186
+#else
+    const bool ws_act = a.act == 1;                     // the product build holds the SiLU forms only (launch_conv_ws refuses the rest): act 0 -> 131 / 132
+#endif
+    if (g1 && !a.gate && !a.res && !a.out_f32 && ws_act && a.splits <= 1 && ws_ok &&
         (a.Cin == 96 || a.Cin == 192 || a.Cin == 224 || a.Cin == 384) && a.Cout % 32 == 0 && a.M >= 64 * 128 &&
         (size_t)a.M * a.Cin * 2 < 0xffffffffull) {
         // weights-stationary persistent GEMM (short-K expand convolutions), two waves per SIMD: 2 workgroups x 4 waves, or
@@ -95,6 +100,7 @@ static int choose_variant(const ConvArgs& a) {
 
 static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
     ConvArgs aa = a;
+    aa.exp = exp_flags();
     aa.grid_mode = 1;               // 1-D grid decoded per XCD (conv_tile_origin): +4 % over the 2-D grid
     if (a.Cin % 32 != 0 || a.Cout % 32 != 0 || a.K != a.KH * a.KW * a.Cin || a.M <= 0) {
         set_error("conv_igemm: unsupported shape Cin=%d Cout=%d K=%d M=%d", a.Cin, a.Cout, a.K, a.M);

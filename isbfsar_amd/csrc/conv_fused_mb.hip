@@ -186,6 +186,7 @@ __global__ __launch_bounds__(128 * WGM) void fused_mb_kernel(ConvArgs p) {
     const int nkt = p.K / CK;
     dma(std::integral_constant<int, 0>{});
     publish();
+    prio_matrix(p.exp);
     int kt = 0;
     for (; kt + 2 <= nkt; kt += 2) {
         dma(std::integral_constant<int, 1>{});
@@ -210,6 +211,7 @@ __global__ __launch_bounds__(128 * WGM) void fused_mb_kernel(ConvArgs p) {
         w2_base += CK * 2;
     };
     dma_w2(std::integral_constant<int, 0>{});
+    prio_vector(p.exp);
     {
         const int ml = wm * 32 + r;
 #pragma unroll
@@ -227,6 +229,7 @@ __global__ __launch_bounds__(128 * WGM) void fused_mb_kernel(ConvArgs p) {
             }
     }
     publish();
+    prio_matrix(p.exp);
 
     // ---- GEMM 2: out[128, Cout2] = E[128, Cexp] . w2[Cout2, Cexp]^T ; wave = 32 pixels x 32 * TN2 channels
     f32x16 acc2[1][TN2];
@@ -273,6 +276,7 @@ __global__ __launch_bounds__(128 * WGM) void fused_mb_kernel(ConvArgs p) {
     }
     static_assert(NKB == 4 || NKB == 8 || NKB == 12, "Cexp = 128, 256 or 384");
 
+    prio_vector(p.exp);
     ConvArgs p2 = p;                                         // epilogue of the projection: bias2, no activation, residual
     p2.Cout = p.Cout2;
     p2.act = 0;
@@ -289,6 +293,7 @@ int launch_fused_mb(const ConvArgs& a, hipStream_t st) {
     }
     ConvArgs aa = a;
     aa.grid_mode = 0;
+    aa.exp = exp_flags();
     const int wpr = a.Cout2 <= 64 ? 64 : a.Cout2 <= 96 ? 96 : 128;
 #define ISB_FMB(WGM, TN, WPR, HALO_)                                                                                         \
     do {                                                                                                                     \

@@ -155,10 +155,10 @@ int launch_tiles_gemm1x1_gate(int v, const ConvArgs& a, ConvArgs& aa, hipStream_
         aa.grid_bias_off = ring > stage ? ring : stage;                                                          \
         const int bytes = aa.grid_bias_off + BN_ * 4;                                                            \
         auto kern = gemm1x1_dma_kernel<TM, TN, WGM, WGN, true, false, NBUF_, F16_>;                              \
-        static int attr_bytes = 0;                                                                               \
-        if (bytes > attr_bytes) {                                                                                \
+        static DevMax attr_bytes;                                                                               \
+        if (attr_bytes.below(bytes)) {                                                                                \
             ISB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));  \
-            attr_bytes = bytes;                                                                                  \
+            attr_bytes.set(bytes);                                                                                  \
         }                                                                                                        \
         const dim3 g = conv_grid(aa, BM_, BN_);                                                                  \
         hipLaunchKernelGGL(kern, g, dim3(64 * WGM * WGN), bytes, st, aa);                                        \
@@ -217,11 +217,11 @@ int launch_tiles_gemm1x1_gate(int v, const ConvArgs& a, ConvArgs& aa, hipStream_
             const int bytes = aa.grid_bias_off + BN_ * 4;
             auto kern = gemm1x1_dma_kernel<1, 2, 2, 2, 2>;
             auto kern_h = gemm1x1_dma_kernel<1, 2, 2, 2, 2, false, 2, true>;
-            static bool attr_set = false;
-            if (!attr_set) {
+            static DevOnce attr_set;
+            if (attr_set.need()) {
                 ISB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
                 ISB_HIP(hipFuncSetAttribute((const void*)kern_h, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-                attr_set = true;
+                attr_set.mark();
             }
             const dim3 g = conv_grid(aa, BM_, BN_);
             if (a.f16) hipLaunchKernelGGL(kern_h, g, dim3(256), bytes, st, aa);
@@ -252,10 +252,10 @@ int launch_tiles_gemm1x1_gate(int v, const ConvArgs& a, ConvArgs& aa, hipStream_
 #define ISB_LW_GO(WGM_, WGN_, TN_, NP_, F16_)                                                                            \
     do {                                                                                                                 \
         auto kern = gemm1x1_lw_kernel<WGM_, WGN_, TN_, NP_, F16_>;                                                       \
-        static int attr_bytes = 0;                                                                                       \
-        if (bytes > attr_bytes) {                                                                                        \
+        static DevMax attr_bytes;                                                                                       \
+        if (attr_bytes.below(bytes)) {                                                                                        \
             ISB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));          \
-            attr_bytes = bytes;                                                                                          \
+            attr_bytes.set(bytes);                                                                                          \
         }                                                                                                                \
         hipLaunchKernelGGL(kern, g, dim3(64 * (WGM_ * WGN_ + 4)), bytes, st, aa);                                        \
     } while (0)

@@ -456,10 +456,10 @@ int launch_tiles_igemm(int v, const ConvArgs& a, ConvArgs& aa, hipStream_t st) {
         const int stage = BM_ * (BN_ * 2 + 16);                                                                     \
         const int bytes = ring > stage ? ring : stage;                                                              \
         auto kern = conv_igemm_dma_kernel<TM, TN, WGM, WGN, NB, true, KT>;                                   \
-        static int attr_bytes = 0;                                                                                  \
-        if (bytes > attr_bytes) {                                                                                   \
+        static DevMax attr_bytes;                                                                                  \
+        if (attr_bytes.below(bytes)) {                                                                                   \
             ISB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));     \
-            attr_bytes = bytes;                                                                                     \
+            attr_bytes.set(bytes);                                                                                     \
         }                                                                                                           \
         const dim3 g = conv_grid(aa, BM_, BN_);                                                                     \
         hipLaunchKernelGGL(kern, g, dim3(64 * WGM * WGN), bytes, st, aa);                                           \

@@ -464,8 +464,11 @@ struct Mf8 {
     static constexpr int NK16 = CIN / 16, NKT = CIN / 32, CEXP = 6 * CIN, NSL = CEXP / 128;
     static constexpr int XBUF = NKT * 4096;
     static constexpr int ET_OFF = XBUF;
-    static constexpr int TBL_OFF = ET_OFF + 4 * MB8_ET_BYTES;        // per wave 1 KiB: bias [32] f32 | depthwise bias [32] f32 | taps [9][32] 16-bit
-    static constexpr int LDS = TBL_OFF + 4 * 1024;
+    // per wave 1.5 KiB: bias [32] f32 | depthwise bias [32] f32 | taps [9][4 chunks][(w, 0) x 4 pairs | (0, w) x 4 pairs]: the split
+    // copies v_dot2 needs, made ONCE (round 5: masking them per sample was 72 of the ~840 vector instructions of a sample)
+    static constexpr int TBL_BYTES = 1536;
+    static constexpr int TBL_OFF = ET_OFF + 4 * MB8_ET_BYTES;
+    static constexpr int LDS = TBL_OFF + 4 * TBL_BYTES;
     static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
 };
 
@@ -505,12 +508,15 @@ __global__ __launch_bounds__(256, 2) void mbfront8_kernel(MbFront8Args p) {
     const int oy = pq >> 1, ox0 = (pq & 1) * 4;
     // the block's small per-channel operands live in a per-wave LDS table for the whole kernel (the registers belong to the stationary
     // weights; two waves share a SIMD's 512): read back as 16-byte pieces where they are used
-    unsigned char* const tbl = lds + S::TBL_OFF + wave * 1024;
+    unsigned char* const tbl = lds + S::TBL_OFF + wave * S::TBL_BYTES;
     if (lane < 8) *reinterpret_cast<float4*>(tbl + lane * 16) = *reinterpret_cast<const float4*>(p.b1 + c0 + lane * 4);
     else if (lane < 16) *reinterpret_cast<float4*>(tbl + lane * 16) = *reinterpret_cast<const float4*>(p.dwb + c0 + (lane - 8) * 4);
     else if (lane < 16 + 36) {
         const int t = (lane - 16) >> 2, c4 = (lane - 16) & 3;
-        *reinterpret_cast<uint4*>(tbl + 256 + t * 64 + c4 * 16) = *reinterpret_cast<const uint4*>(p.dww + (size_t)t * CEXP + c0 + c4 * 8);
+        const uint4 tp = *reinterpret_cast<const uint4*>(p.dww + (size_t)t * CEXP + c0 + c4 * 8);
+        *reinterpret_cast<uint4*>(tbl + 256 + t * 128 + c4 * 32) = make_uint4(tp.x & 0xffffu, tp.y & 0xffffu, tp.z & 0xffffu, tp.w & 0xffffu);
+        *reinterpret_cast<uint4*>(tbl + 256 + t * 128 + c4 * 32 + 16) =
+            make_uint4(tp.x & 0xffff0000u, tp.y & 0xffff0000u, tp.z & 0xffff0000u, tp.w & 0xffff0000u);
     }
     for (int i = lane; i < 36 * 4; i += 64) {                       // the zero ring of the wave's padded tile, once
         const int qi = i >> 2, ch = i & 3;
@@ -535,6 +541,7 @@ __global__ __launch_bounds__(256, 2) void mbfront8_kernel(MbFront8Args p) {
         __builtin_amdgcn_s_barrier();
         if (p.stamps) { tb = __builtin_amdgcn_s_memtime(); st_wait += tb - ta; }
         // ---- expand: the sample x the wave's 32 channels
+        prio_matrix(p.exp);
         f32x16 acc[2];
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[0][e] = acc[1][e] = 0.f;
@@ -547,6 +554,7 @@ __global__ __launch_bounds__(256, 2) void mbfront8_kernel(MbFront8Args p) {
             if ((k16 & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // (fragment reads at most four k16 steps ahead: registers)
         }
         __builtin_amdgcn_s_barrier();                               // everybody has read the tiles: the next sample's may land
+        prio_vector(p.exp);
         if (smp + Q < p.B) dma_x(smp + Q);
         // ---- E = T16(silu(acc + bias)) -> the wave's padded tile
 #pragma unroll
@@ -584,10 +592,10 @@ __global__ __launch_bounds__(256, 2) void mbfront8_kernel(MbFront8Args p) {
             uint32_t wlo[3][4], whi[3][4];
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                const uint4 tp = *reinterpret_cast<const uint4*>(tbl + 256 + (ky * 3 + kx) * 64 + cl * 16);
-                const uint32_t wp[4] = {tp.x, tp.y, tp.z, tp.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { wlo[kx][e] = wp[e] & 0xffffu; whi[kx][e] = wp[e] & 0xffff0000u; }
+                const uint4 tl = *reinterpret_cast<const uint4*>(tbl + 256 + (ky * 3 + kx) * 128 + cl * 32);
+                const uint4 th = *reinterpret_cast<const uint4*>(tbl + 256 + (ky * 3 + kx) * 128 + cl * 32 + 16);
+                wlo[kx][0] = tl.x; wlo[kx][1] = tl.y; wlo[kx][2] = tl.z; wlo[kx][3] = tl.w;
+                whi[kx][0] = th.x; whi[kx][1] = th.y; whi[kx][2] = th.z; whi[kx][3] = th.w;
             }
             uint4 v[6];
 #pragma unroll
@@ -704,15 +712,17 @@ int launch_mbfront8(const MbFront8Args& a, hipStream_t st) {
         return ISB_ERR_INVALID;
     }
     constexpr int NSL = Mf8<384>::NSL, LDSB = Mf8<384>::LDS;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DevOnce attr_set;
+    if (attr_set.need()) {
         ISB_HIP(hipFuncSetAttribute((const void*)mbfront8_kernel<384, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
         ISB_HIP(hipFuncSetAttribute((const void*)mbfront8_kernel<384, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
-        attr_set = true;
+        attr_set.mark();
     }
     const int Q = std::max(1, std::min(a.B, 512 / NSL));              // sample sequences: two workgroups per CU
-    if (a.f16) hipLaunchKernelGGL((mbfront8_kernel<384, true>), dim3(NSL * Q), dim3(256), LDSB, st, a);
-    else hipLaunchKernelGGL((mbfront8_kernel<384, false>), dim3(NSL * Q), dim3(256), LDSB, st, a);
+    MbFront8Args aa = a;
+    aa.exp = exp_flags();
+    if (a.f16) hipLaunchKernelGGL((mbfront8_kernel<384, true>), dim3(NSL * Q), dim3(256), LDSB, st, aa);
+    else hipLaunchKernelGGL((mbfront8_kernel<384, false>), dim3(NSL * Q), dim3(256), LDSB, st, aa);
     ISB_LAUNCHED("mbfront8", st);
     return ISB_OK;
 }
@@ -725,11 +735,11 @@ int launch_mb8_chain(const Mb8Args& a, hipStream_t st) {
         set_error("mb8_chain: bad arguments (B=%d nblocks=%d cin0=%d)", a.B, a.nblocks, a.cin0);
         return ISB_ERR_INVALID;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DevOnce attr_set;
+    if (attr_set.need()) {
         ISB_HIP(hipFuncSetAttribute((const void*)mb8_chain_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, MB8_LDS));
         ISB_HIP(hipFuncSetAttribute((const void*)mb8_chain_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, MB8_LDS));
-        attr_set = true;
+        attr_set.mark();
     }
     if (a.f16) hipLaunchKernelGGL(mb8_chain_kernel<true>, dim3(a.B), dim3(MB8_NT), MB8_LDS, st, a);
     else hipLaunchKernelGGL(mb8_chain_kernel<false>, dim3(a.B), dim3(MB8_NT), MB8_LDS, st, a);

@@ -585,12 +585,12 @@ int launch_conv_ws(const ConvArgs& a, ConvArgs& aa, int v, hipStream_t st) {
             set_error("conv_igemm: weights-stationary tile of %d bytes does not fit the LDS", bytes);           \
             return ISB_ERR_INVALID;                                                                             \
         }                                                                                                       \
-        static bool attr_set = false;                                                                           \
-        if (!attr_set) {                                                                                        \
+        static DevOnce attr_set;                                                                           \
+        if (attr_set.need()) {                                                                                        \
             ISB_HIP(hipFuncSetAttribute((const void*)gemm1x1_wsreg_kernel<NK, true, false, NW, TMB>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));  \
             ISB_HIP(hipFuncSetAttribute((const void*)gemm1x1_wsreg_kernel<NK, false, false, NW, TMB>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); \
             ISB_HIP(hipFuncSetAttribute((const void*)gemm1x1_wsreg_kernel<NK, true, true, NW, TMB>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));   \
-            attr_set = true;                                                                                    \
+            attr_set.mark();                                                                                    \
         }                                                                                                       \
         if (a.probe & 2) hipLaunchKernelGGL((gemm1x1_wsreg_kernel<NK, true, true, NW, TMB>), g, dim3(64 * NW), bytes, st, aa);           \
         else if (a.act) hipLaunchKernelGGL((gemm1x1_wsreg_kernel<NK, true, false, NW, TMB>), g, dim3(64 * NW), bytes, st, aa);           \
@@ -625,10 +625,10 @@ int launch_conv_ws(const ConvArgs& a, ConvArgs& aa, int v, hipStream_t st) {
 #define ISB_WSP_GO(NK, ACT, STAMPS, TMB, WPC, NWM, M16_, F16_)                                                  \
     do {                                                                                                        \
         const int bytes = std::max(2 * NK * (32 * TMB * NWM) * 64 + 4 * NWM * 2 * WS_STAGE, WPC == 1 ? 84 * 1024 : 0); \
-        static bool attr_set = false;                                                                           \
-        if (!attr_set) {                                                                                        \
+        static DevOnce attr_set;                                                                           \
+        if (attr_set.need()) {                                                                                        \
             ISB_HIP(hipFuncSetAttribute((const void*)gemm1x1_wspipe_kernel<NK, ACT, STAMPS, TMB, WPC, NWM, M16_, F16_>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); \
-            attr_set = true;                                                                                    \
+            attr_set.mark();                                                                                    \
         }                                                                                                       \
         hipLaunchKernelGGL((gemm1x1_wspipe_kernel<NK, ACT, STAMPS, TMB, WPC, NWM, M16_, F16_>), g, dim3(256 * NWM), bytes, st, aa); \
     } while (0)

@@ -480,6 +480,7 @@ extern "C" int isb_hpe_create(const isb_hpe_cfg* cfg, isb_hpe** out) {
     if (const char* e = getenv("ISB_FUSE_SE")) h->fuse_se = atoi(e) != 0;
     if (const char* e = getenv("ISB_MB8")) h->mb8_on = atoi(e) != 0;
     if (const char* e = getenv("ISB_MBF8")) h->mbf8_on = atoi(e) != 0;
+    if (!isb::mbf8_verified()) h->mbf8_on = false;      // fail closed: the build could not confirm the kernel's counted wait (wsreg_guard.cpp)
     if (const char* e = getenv("ISB_MB8_MIN_BATCH")) h->mb8_min_batch = std::max(1, atoi(e));
     h->f16_from = cfg->precision == 1 ? 7 : (cfg->precision == 3 ? 5 : 0);
     if (const char* e = getenv("ISB_HPE_ROI")) h->roi_mode = atoi(e) != 0 ? 1 : 0;

@@ -65,6 +65,11 @@ int blob_get(const std::map<std::string, BlobTensor>& m, const char* name, uint3
     return ISB_OK;
 }
 
+int exp_flags() {
+    static const int v = [] { const char* e = getenv("ISB_EXP"); return e ? (int)strtol(e, nullptr, 0) : 0; }();
+    return v;
+}
+
 int post_launch(const char* what, hipStream_t st) {
     static const bool dbg = getenv("ISB_DEBUG_SYNC") != nullptr;
     hipError_t e = hipGetLastError();
@@ -84,7 +89,7 @@ int post_launch(const char* what, hipStream_t st) {
 }  // namespace isb
 
 extern "C" const char* isb_last_error(void) { return isb::g_err; }
-extern "C" int isb_version(void) { return 1; }
+extern "C" int isb_version(void) { return 2; }      // 2: isb_ar_cfg.precision 0 = default (fp16), bf16 = 3 (include/isbfsar.h)
 extern "C" int isb_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

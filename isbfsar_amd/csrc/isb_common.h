@@ -118,6 +118,34 @@ int guard(F&& f) noexcept {
     }
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is remembered PER DEVICE: a process-wide `static bool` would let an engine on a
+// second device launch a > 64-KiB-LDS kernel without it. One flag per device ordinal; use:
+//     static DevOnce attr; if (attr.need()) { ISB_HIP(hipFuncSetAttribute(...)); attr.mark(); }
+struct DevOnce {
+    bool done[64] = {};
+    int dev = -1;
+    bool need() {
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { dev = -1; return true; }     // unknown device: set it again
+        return !done[dev];
+    }
+    void mark() { if (dev >= 0) done[dev] = true; }
+};
+
+// the same for launchers whose LDS size depends on the shape: the largest size set so far, per device
+struct DevMax {
+    int bytes[64] = {};
+    int dev = -1;
+    bool below(int want) {
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { dev = -1; return true; }
+        return want > bytes[dev];
+    }
+    void set(int v) { if (dev >= 0) bytes[dev] = v; }
+};
+
+// open experiments: a bit mask from the environment (ISB_EXP, read once per process), handed to the kernels in their argument blocks
+// (ConvArgs.exp, ...). Bits: EXPERIMENTS.md round 5. 0 = the product's behaviour.
+int exp_flags();
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t cdivz(size_t a, size_t b) { return (a + b - 1) / b; }
 

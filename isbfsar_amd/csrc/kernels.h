@@ -161,6 +161,7 @@ struct ConvArgs {
     // tuning probes of gemm1x1_wsreg_kernel (isb_debug_conv variant 9181 / ISB_WS_PROBE): bit 0 = no output stores,
     // bit 1 = s_memtime stamps of the first workgroups' wave 0 into `part` (1 KiB per workgroup)
     int probe;
+    int exp;                // open experiments (isb::exp_flags(), set by the launchers): bit 8 = s_setprio around the k loops (EXPERIMENTS.md r5)
     const uint16_t* w2;     // bf16 [Cout2][Cout] (BN scale folded)
     const float* bias2;     // [Cout2]
     int Cout2;
@@ -209,9 +210,11 @@ struct MbFront8Args {
     uint16_t* d;            // out [B][64][cexp] 16-bit: the depthwise output the gated projection reads
     float* pooled;          // out [B][cexp] f32 spatial means
     int B, cin, f16;
+    int exp;                // open experiments (isb::exp_flags(), set by the launcher)
     uint64_t* stamps;       // tuning probe or null: [64 workgroups][4 waves][4] = loop cycles, waiting at the loop top, bodies, iterations
 };
 int launch_mbfront8(const MbFront8Args& a, hipStream_t st);
+int mbf8_verified();        // wsreg_guard.cpp: 1 only if the build confirmed mbfront8_kernel's counted wait in the disassembly
 int launch_mb8_pack_frag(const uint16_t* w, void* dst, int N, int K, int G, hipStream_t st);
 int launch_mb8_pack_se1(const float* w1, float* dst, int cse, int C, hipStream_t st);
 int mb8_proj_group(int cout);

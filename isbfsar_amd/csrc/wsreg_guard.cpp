@@ -5,3 +5,11 @@
 #define ISB_WSREG_VERIFIED 0
 #endif
 extern "C" int isb_wsreg_verified(void) { return ISB_WSREG_VERIFIED; }
+
+// The same for mbfront8_kernel's hand-counted `s_waitcnt vmcnt(5)` (conv_mb8.hip: exactly five vector-memory operations -- four D-row
+// stores and the pooled means -- may follow the next sample's LDS-DMA requests; a spill or a split store would leave input tiles in
+// flight at the barrier). build.py::mbfront8_wait_counted checks the disassembly; 0 = the expand GEMM + depthwise launches run.
+#ifndef ISB_MBF8_VERIFIED
+#define ISB_MBF8_VERIFIED 0
+#endif
+namespace isb { int mbf8_verified() { return ISB_MBF8_VERIFIED; } }

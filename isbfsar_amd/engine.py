@@ -31,22 +31,26 @@ class ArEngine:
     (reference modules/ar/utils/model.py:291-328) for B windows sharing one support set."""
 
     def __init__(self, seq_len: int, n_joints: int, way_max: int, device: int = 0,
-                 precision: Union[int, str] = "f16", max_batch: int = 1024, input_type: str = "skeleton"):
+                 precision: Union[int, str] = "default", max_batch: int = 1024, input_type: str = "skeleton"):
         """input_type (TRXConfig.input_type): "skeleton" (features = MLP(pose), 256 wide) or "hybrid" (features =
         [PostResNet(ResNet-50 trunk) | MLP(pose)], 512 wide; set_support / infer then also take trunk features
         [.., L, 2048], e.g. from RgbEngine)."""
-        prec = {"bf16": _lib.ISB_AR_PREC_BF16, "bf16x3": _lib.ISB_AR_PREC_BF16X3, "f16": _lib.ISB_AR_PREC_F16}.get(precision, precision)
+        # "default" = ISB_AR_PREC_DEFAULT = what a zero-initialised isb_ar_cfg gets: fp16 operands (include/isbfsar.h); the
+        # resolved setting is read back from the handle (isb_ar_precision), so that there is ONE default, the library's
+        prec = {"default": _lib.ISB_AR_PREC_DEFAULT, "bf16": _lib.ISB_AR_PREC_BF16, "bf16x3": _lib.ISB_AR_PREC_BF16X3,
+                "f16": _lib.ISB_AR_PREC_F16}.get(precision, precision)
         if input_type not in ("skeleton", "hybrid"):
             raise ValueError(f"input_type {input_type!r}: 'skeleton' or 'hybrid' (the reference's 'rgb' type is inconsistent with "
                              "its own model: utils/params.py:81 sizes the transformer for 1000-wide features, model.py:274-277 makes 256)")
         self.L, self.J, self.way_max, self.device = seq_len, n_joints, way_max, device
-        self.precision = {_lib.ISB_AR_PREC_BF16X3: "bf16x3", _lib.ISB_AR_PREC_F16: "f16"}.get(prec, "bf16")
         self.input_type = input_type
         self.d_in = 512 if input_type == "hybrid" else 256
         self.n = 0
         self._h = C.c_void_p()
         cfg = _lib.isb_ar_cfg(seq_len, n_joints, way_max, device, prec, max_batch)
         _lib.check(_lib.lib().isb_ar_create(C.byref(cfg), C.byref(self._h)), "isb_ar_create")
+        self.precision = {_lib.ISB_AR_PREC_BF16X3: "bf16x3", _lib.ISB_AR_PREC_F16: "f16",
+                          _lib.ISB_AR_PREC_BF16: "bf16"}[_lib.lib().isb_ar_precision(self._h)]
         if input_type == "hybrid":
             _lib.check(_lib.lib().isb_ar_set_input_type(self._h, 1), "isb_ar_set_input_type")
 

@@ -96,7 +96,7 @@ class ActionRecognizer:
         n_j = args.n_joints
         self.ar = ArEngine(args.seq_len, n_j, args.way,
                            device=getattr(args, "device_index", 0),
-                           precision=getattr(args, "precision", "f16"),
+                           precision=getattr(args, "precision", "default"),
                            max_batch=getattr(args, "max_batch", 1024), input_type=self.input_type)
         self.ar.load_weights(_load_state(args))
         self.rgb = None

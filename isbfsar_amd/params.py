@@ -81,5 +81,5 @@ class TRXConfig(object):
         # --- additions of the HIP build ---
         self.weights = None          # mapping name -> ndarray or ISBW bytes; overrides final_ckpt_path
         self.device_index = 0        # HIP device ordinal
-        self.precision = "bf16"      # "bf16" | "bf16x3" for the tuple-attention contractions
+        self.precision = "default"   # tuple-attention operands: "default" (= the library's: "f16") | "f16" | "bf16" | "bf16x3"
         self.max_batch = 1024

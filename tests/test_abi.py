@@ -35,7 +35,7 @@ def test_ctypes_signatures_cover_header(built_lib):
     h = _lib.lib()
     for name in _lib.SIGNATURES:           # an entry point without argtypes truncates int pointers
         assert getattr(h, name).argtypes is not None, name
-    assert h.isb_version() == 1
+    assert h.isb_version() == 2
     assert isinstance(h.isb_device_count(), int)
 
 
@@ -126,3 +126,35 @@ def test_wspipe_staging_registers_are_private(built_lib):
     assert verdict == (1 if why is None else 0), (verdict, why)
     if os.path.exists(OBJDUMP):
         assert why is None, why                    # this image has the tool: the shipped library must be the verified one
+
+
+def test_mbfront8_counted_wait_is_guarded_by_the_build(built_lib):
+    """mbfront8_kernel's `s_waitcnt vmcnt(5)` assumes exactly five vector-memory operations behind the next sample's
+    input requests (conv_mb8.hip). The build checks that in the disassembly and compiles the verdict in (isb::mbf8_verified,
+    fail closed: unverified = the expand GEMM + depthwise launches run); the shipped library must be the verified one, and the
+    check must reject code it was written to reject (a spill, a sixth store)."""
+    import ctypes
+    from isbfsar_amd import build
+    why = build.mbfront8_wait_counted(built_lib)
+    if os.path.exists(build.OBJDUMP):
+        assert why is None, why
+    lib = ctypes.CDLL(built_lib)
+    sym = next((s for s in ("_ZN3isb13mbf8_verifiedEv",) if hasattr(lib, s)), None)
+    assert sym, "isb::mbf8_verified() not in the library"
+    assert getattr(lib, sym)() == (1 if why is None else 0)
+    # the checker on doctored text: one more store behind the requests, and a scratch instruction
+    good = build._disassemble(built_lib)
+    if good.startswith("\n"):
+        lines = good.splitlines()
+        orig = build._disassemble
+        try:
+            first = next(i for i, ln in enumerate(lines) if "mbfront8_kernel" in ln and ln.rstrip().endswith(">:"))
+            body_store = next(i for i in range(first, len(lines)) if "global_store_dword " in lines[i] or lines[i].split()[:1] == ["global_store_dword"])
+            doctored = lines[:body_store] + [lines[body_store]] + lines[body_store:]
+            build._disassemble = lambda _p: "\n".join(doctored)
+            assert build.mbfront8_wait_counted(built_lib) is not None
+            doctored = lines[:body_store] + ["\tscratch_store_dword off, v0, s0"] + lines[body_store:]
+            build._disassemble = lambda _p: "\n".join(doctored)
+            assert "scratch" in (build.mbfront8_wait_counted(built_lib) or "")
+        finally:
+            build._disassemble = orig

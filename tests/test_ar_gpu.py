@@ -22,7 +22,7 @@ def _softmax(x):
     return e / e.sum(axis=-1, keepdims=True)
 
 
-def _engine(L, J, way, precision="bf16", max_batch=1024, seed=0, state=None):
+def _engine(L, J, way, precision="default", max_batch=1024, seed=0, state=None):
     from isbfsar_amd.engine import ArEngine
     eng = ArEngine(L, J, way, device=0, precision=precision, max_batch=max_batch)
     eng.load_weights(state if state is not None else weights.make_ar_state(L, J, seed=seed))
@@ -279,15 +279,17 @@ def test_support_set_persistence_like_main_py():
     assert outs2[-1][0] and list(outs2[-1][0].keys()) == ["act0", "act1", "act2"]
 
 
-def test_full_size_properties():
-    """BASELINE configs[2]: B=1024 windows of 30x122 joints, 60 classes. Size-independent
-    properties: (i) windows are independent -> a permuted batch gives permuted outputs bit for
+@pytest.mark.parametrize("precision", ["f16", "bf16"])
+def test_full_size_properties(precision):
+    """BASELINE configs[2]: B=1024 windows of 30x122 joints, 60 classes, at the shipped default (fp16 operands) and at bf16.
+    Size-independent properties: (i) windows are independent -> a permuted batch gives permuted outputs bit for
     bit; (ii) a sample agrees with the oracle; (iii) probabilities sum to one."""
     L, J, way, B = 30, 122, 60, 1024
     seed = 1
     ss = synth.skeleton_windows(way, L, J, seed=seed + 100)
     q = synth.skeleton_windows(B, L, J, seed=seed + 400)
-    eng = _engine(L, J, way, "bf16", max_batch=512, seed=seed)
+    eng = _engine(L, J, way, precision, max_batch=512, seed=seed)
+    assert eng.precision == precision
     eng.set_support(poses=ss)
     logits, is_true, _ = eng.infer(q)
     assert np.isfinite(logits).all() and np.isfinite(is_true).all()
@@ -296,7 +298,7 @@ def test_full_size_properties():
     assert np.array_equal(lp, logits[perm]) and np.array_equal(tp, is_true[perm])
     idx = [0, 1, 511, 512, 1023]
     ref = _oracle(L, J, seed=seed).forward(ss, way, q[idx])
-    np.testing.assert_allclose(logits[idx], ref["logits"], rtol=0, atol=ATOL_LOGIT["bf16"])
+    np.testing.assert_allclose(logits[idx], ref["logits"], rtol=0, atol=ATOL_LOGIT[precision])
     np.testing.assert_allclose(is_true[idx], ref["is_true"][:, 0], rtol=0, atol=ATOL_PROB)
     assert np.abs(_softmax(logits).sum(1) - 1).max() < 1e-5
 
@@ -373,3 +375,34 @@ def test_phase_clocks_of_the_all_classes_pass_do_not_change_results():
     assert set(np.unique(tiles)) <= {8 * 14, 5 * 14}
     assert (t[:, :, 0][ok] > 0).all() and (t[:, :, 2][ok] > 0).all() and (t[:, :, 2][ok] < t[:, :, 1][ok]).all()
     assert np.array_equal(eng.infer(q)[0], ref)            # disarmed again
+
+
+def test_one_attention_precision_default_end_to_end():
+    """the C ABI's zero-initialised isb_ar_cfg, ArEngine(), the drop-in ActionRecognizer(TRXConfig()) and
+    bench.py's --precision default all run the SAME attention precision: fp16 operands (include/isbfsar.h, ABI version 2).
+    Matches the reference constructor's role, modules/ar/ar.py:11-28 (one configuration object decides the model)."""
+    import ctypes as C
+    import bench
+    from isbfsar_amd import _lib, params, weights
+    from isbfsar_amd.engine import ArEngine
+    from isbfsar_amd.modules.ar.ar import ActionRecognizer
+    h = C.c_void_p()
+    cfg = _lib.isb_ar_cfg(16, 30, 5, 0, 0, 0)                       # precision field zero-initialised
+    _lib.check(_lib.lib().isb_ar_create(C.byref(cfg), C.byref(h)), "isb_ar_create")
+    try:
+        assert _lib.lib().isb_ar_precision(h) == _lib.ISB_AR_PREC_F16
+    finally:
+        _lib.lib().isb_ar_destroy(h)
+    eng = ArEngine(16, 30, 5, device=0)
+    try:
+        assert eng.precision == "f16"
+    finally:
+        eng.close()
+    args = params.TRXConfig()
+    args.weights = weights.make_ar_state(args.seq_len, args.n_joints, seed=0)
+    rec = ActionRecognizer(args)
+    try:
+        assert rec.ar.precision == "f16"
+    finally:
+        rec.ar.close()
+    assert bench.build_parser().get_default("precision") == "f16"

@@ -267,8 +267,8 @@ def test_backbone_vs_oracle(eng_w, bbone_state, assets):
     err_feat = float(np.abs(feat - f16).max())
     err_log = float(np.abs(logits - l16).max())
     print(f"backbone: max|feat|={scale:.3f} err_feat={err_feat:.2e} err_logits={err_log:.2e}")
-    assert err_feat < 2e-2 * scale                      # bf16 re-rounding noise through 79 blocks
-    assert err_log < 2e-2 * float(np.abs(l16).max())    # the f32 pose head adds nothing of its own
+    assert err_feat < 4e-3 * scale                      # fp16 re-rounding noise through 79 blocks: 5.6e-4 on 0.73 measured, ceiling 5x that
+    assert err_log < 4e-3 * float(np.abs(l16).max())    # the f32 pose head adds nothing of its own
     p2_g, p3_g = ho.decode(logits)
     p2_o, p3_o = ho.decode(l16)
     assert np.abs(p3_g - p3_o).max() < 1e-3             # north star: 3D joints within 1e-3
@@ -396,12 +396,11 @@ def test_absolute_pose_within_1e3_of_fp32_definition(bbone_state, assets):
 
 
 def test_signal_profile_fp16_vs_fp32_definition(assets):
-    """VERDICT r3 item 1(b). On the "signal" weight profile (activations that carry the input, peaked heat-maps: the regime
-    of a trained MetrABS) no 16-bit layout reaches 1e-3 of fp32 -- a random 79-block SiLU network amplifies every rounding
-    -- but the layouts differ by an order of magnitude: the CPU budget (oracle/error_budget.py, profiles/
-    r03_pose_error_budget.txt) puts fp16 everywhere at 3.4e-3 decoded-3D / 2.0e-3 absolute against 2.7e-2 / 5.4e-2 for the
-    bf16 layouts. The HIP fp16 path (the default) has to land within 1.5x of that budget AGAINST THE FP32 ORACLE, and the
-    bf16 layouts -- reported beside it -- must be the worse ones."""
+    """The "signal" weight profile (activations that carry the input, peaked heat-maps: the regime of a trained MetrABS) is the
+    hard one: a random 79-block SiLU network amplifies every rounding. fp16 storage in every stage (the default, the reference's
+    own TensorRT precision, 7_create_engines.py:10) has to stay inside the north star's 1e-3 of the FP32 ORACLE here too --
+    decoded 3D AND the absolute pose estimate() returns (measured 3.4e-4 / 5.6e-4) -- and the bf16-carrying
+    layouts, reported beside it, must be the worse ones (1.6e-3 / 9.1e-3 and 2.1e-3 / 6.7e-3)."""
     from isbfsar_amd import effnetv2
     from isbfsar_amd.hpe_engine import HpeEngine
     from oracle import hpe_oracle as ho
@@ -436,8 +435,8 @@ def test_signal_profile_fp16_vs_fp32_definition(assets):
                 ea = max(ea, float(np.abs(joints[b] - ref).max()))
         res[prec] = (e3, e2, ea)
         print(f"signal profile vs fp32 definition, precision {prec}: decoded 3D {e3:.2e}, 2D {e2:.3f} px, absolute pose {ea:.2e}")
-    assert res["f16"][0] < 1.5 * 3.4e-3, res["f16"]           # decoded 3D (heat-map units): 1.5 x the CPU budget's fp16-everywhere figure
-    assert res["f16"][2] < 1.5 * 3.4e-3, res["f16"]           # absolute pose under the same ceiling
+    assert res["f16"][0] < 1e-3, res["f16"]                   # decoded 3D (heat-map units): the north star's 1e-3
+    assert res["f16"][2] < 1e-3, res["f16"]                   # absolute pose: the same flat 1e-3
     assert res["f16"][0] < 0.5 * res["bf16"][0] and res["f16"][0] < 0.5 * res["bf16_f16tail"][0]
 
 

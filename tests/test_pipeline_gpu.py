@@ -53,8 +53,10 @@ def _oracle_poses(bb_state, expand, frames, boxes):
     return np.stack(out)                                  # [n,122,3] f64
 
 
-def test_config3_full_pipeline_vs_oracle_chain(bb_state, expand):
-    """8 cameras x (29 + 3) frames = 256 frames (one GPU's shard of configs[3]) -> 122-joint poses -> 30-deep windows
+@pytest.mark.parametrize("ar_precision", ["f16", "bf16"])
+def test_config3_full_pipeline_vs_oracle_chain(bb_state, expand, ar_precision):
+    """(At the shipped defaults -- fp16 backbone storage, fp16 attention operands -- and with bf16 attention operands.)
+    8 cameras x (29 + 3) frames = 256 frames (one GPU's shard of configs[3]) -> 122-joint poses -> 30-deep windows
     (3 per camera) -> AR vs 60 classes. The oracle chain runs for two of the cameras (64 frames, 6 windows)."""
     import torch
     from isbfsar_amd.engine import ArEngine
@@ -67,7 +69,8 @@ def test_config3_full_pipeline_vs_oracle_chain(bb_state, expand):
     hpe = HpeEngine(device=0, max_batch=256)
     ar_state = weights.make_ar_state(L, J, seed=1)
     ss = synth.skeleton_windows(way, L, J, seed=101)
-    ar = ArEngine(L, J, way, device=0, precision="bf16", max_batch=64)
+    ar = ArEngine(L, J, way, device=0, precision=ar_precision, max_batch=64)
+    assert ar.precision == ar_precision and hpe.precision == "f16"
     try:
         hpe.load_weights(bb_state)
         hpe.set_joint_map(expand, None)
@@ -123,7 +126,7 @@ class _StreamStep:
         self.hpe.set_joint_map(expand, None)
         self.ar_state = weights.make_ar_state(L, J, seed=1)
         self.ss = synth.skeleton_windows(way, L, J, seed=101)
-        self.ar = ArEngine(L, J, way, device=0, precision="bf16", max_batch=1)
+        self.ar = ArEngine(L, J, way, device=0, max_batch=1)           # the shipped default: fp16 attention operands
         self.ar.load_weights(self.ar_state)
         self.ar.set_support(poses=self.ss)
         self.hist = synth.skeleton_windows(1, L, J, seed=777).reshape(1, L, J, 3)
@@ -235,6 +238,27 @@ def test_bench_launches_its_own_ranks():
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                         env=env2, capture_output=True, text=True, timeout=300)
     assert r2.returncode == 2 and "refusing" in r2.stderr
+
+
+def test_two_rank_pipeline_gather_is_bit_equal_to_unsharded():
+    """`bench.py --gpus 2 --workload pipeline` rehearsed on this one-GPU box (both ranks on cuda:0, gloo as
+    the transport double: RCCL refuses two ranks on one device) must report gather_check.bit_equal_to_unsharded -- rank 0
+    recomputes every rank's shard without a collective and compares the gathered records bit for bit (SURVEY 8e's
+    correctness check). tests/test_multirank_gpu.py is the same assertion over RCCL on >= 2 devices."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(ISB_BENCH_ONE_DEVICE="1", ISB_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--workload", "pipeline", "--batch", "64", "--no-cpu-baseline", "--no-extras", "--min-gpu-seconds", "0"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["world_size"] == 2 and line["value"] > 0
+    chk = line["gather_check"]
+    assert chk and chk["bit_equal_to_unsharded"] is True, chk
+    assert chk["gathered_records"][0] == 2 * line["config"]["per_gpu_batch"]
 
 
 def test_bench_rccl_path_with_one_rank():
