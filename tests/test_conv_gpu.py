@@ -351,6 +351,26 @@ def test_wsreg_expand_gemm(B, H, Cin, Cout, act, variant, f16):
     assert np.array_equal(out2, out)
 
 
+@pytest.mark.parametrize("f16", [False, True])
+@pytest.mark.parametrize("B,H,Cin,Cout", [(8, 32, 96, 384), (40, 16, 192, 768), (130, 8, 384, 768)])
+def test_auto_dispatch_of_a_short_k_gemm_without_activation(B, H, Cin, Cout, f16):
+    """a legal auto-dispatched shape -- 1x1, Cin 96 / 192 / 384, NO activation, no residual or gate, M >= 8192 --
+    must not be sent to the weights-stationary variants, whose product build holds the SiLU forms only (launch_conv_ws refuses the
+    rest): variant 0 has to run it on the tile kernels (131 / 132), with the tile kernels' bits."""
+    from isbfsar_amd.hpe_engine import f16_to_f32, f32_to_f16
+    rng = np.random.default_rng(B + Cin)
+    x = rng.normal(0, 1, (B, H, H, Cin)).astype(np.float32)
+    w = (rng.normal(0, 1, (Cout, 1, 1, Cin)) / np.sqrt(Cin)).astype(np.float32)
+    scale = rng.uniform(0.8, 1.2, Cout).astype(np.float32)
+    shift = rng.uniform(-0.1, 0.1, Cout).astype(np.float32)
+    cvt, back = (f32_to_f16, f16_to_f32) if f16 else (f32_to_bf16, bf16_to_f32)
+    out, _ = conv_debug(cvt(x), w, scale, shift, 1, 1, 0, None, None, variant=0, f16=f16)
+    tile, _ = conv_debug(cvt(x), w, scale, shift, 1, 1, 0, None, None, variant=131 if Cout % 192 == 0 else 132, f16=f16)
+    assert np.array_equal(out, tile)
+    ref = _ref16(x, w, scale, shift, 1, 1, 0, None, "f16" if f16 else "bf16")
+    assert np.abs(back(out) - ref).max() <= (2.0 ** -10 if f16 else 2.0 ** -7) * max(1.0, np.abs(ref).max()) + 1e-4
+
+
 def _gemm_ref(A, W, bias, a_bias, a_add, act, a_act):
     """float64 restatement of gemm_f32.hip's contract."""
     actf = {0: lambda v: v, 1: lambda v: np.maximum(v, 0), 2: lambda v: v / (1 + np.exp(-v)), 3: lambda v: 1 / (1 + np.exp(-v))}
