@@ -6,6 +6,7 @@
 // The backbone is what the reference runs as `bbone1.engine` (utils/params.py:29, hpe.py:103);
 // layer semantics follow the public efficientnetv2-l definition (isbfsar_amd/effnetv2.py).
 #include "conv_common.h"
+#include "dw_mm.h"
 
 namespace isb {
 
@@ -361,6 +362,143 @@ __global__ __launch_bounds__(256) void dwconv3x3_map_kernel(DwArgs p) {
     }
 }
 
+
+// Stride-1 depthwise 3x3 on whole 8 x 8 / 16 x 16 maps with the TAPS ON THE MATRIX PIPE (dw_mm.h; round 5): the batch path of the 54
+// stride-1 depthwise launches. Staging as in dwconv3x3_map_kernel (the slab goes to LDS once, inside a ring of zero pixels), but a
+// wave owns CPW channels of the slab for ALL pixels: per 8-channel group and 32-pixel tile, three 16-byte fragment reads + three
+// v_mfma_f32_16x16x32 replace 288 v_dot2 (per lane: 4 outputs instead of 32 per pass, 7 vector instructions per output instead of
+// 17). The 16-bit results are staged in LDS and leave as full pixel rows; pooled means: per lane over its tiles in order, then the
+// 32 (pixel pair, pixel) slots in order.
+// LDS images: in  [TW x TW pixels][RB bytes], 16-byte chunk slot = chunk ^ f(y, x) with f chosen so that the sixteen lanes a
+//                 ds_read_b128 serves together (pixels 2n + j of two rows) fall into sixteen different slots;
+//             out [HW x HW pixels][RB bytes], chunk slot = chunk ^ (pixel >> 1).
+// (launch bounds: at least two waves per SIMD = at most 256 registers, with which the compiler keeps the MFMA results in ordinary
+// vector registers -- with 512 allowed it accumulates in AGPRs and reads every result back with a v_accvgpr_read)
+template <bool F16, int HW>
+__global__ __launch_bounds__(256, 2) void dwconv3x3_mm_kernel(DwArgs p) {
+    T16<F16>::enter();
+    constexpr int TW = HW + 2;
+    constexpr int CPW = HW == 16 ? 16 : 32;                // channels per wave
+    constexpr int GPW = CPW / 8;                           // 8-channel groups per wave
+    constexpr int CWG = 4 * CPW;                           // channels per workgroup: 64 / 128 (dwconv3x3_map_kernel's slabs)
+    constexpr int RB = CWG * 2;                            // bytes per pixel in LDS
+    constexpr int NCH = RB / 16;                           // 16-byte chunks per pixel: 8 / 16
+    constexpr int NT = HW * HW / 32;                       // 32-pixel tiles per map: 8 / 2
+    constexpr int PPR = HW / 2, RPT = 32 / HW;             // pixel pairs per row, rows per tile
+    constexpr int NLD = HW * HW * NCH / 256;               // 16-byte loads per thread: 8 / 4
+    constexpr int IN_BYTES = TW * TW * RB;                 // 41 472 / 25 600 (+ the output image: dwmm_lds_bytes, dynamic LDS)
+    unsigned char* const tin = conv_lds_dyn;
+    unsigned char* const tout = conv_lds_dyn + IN_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y, c0 = blockIdx.x * CWG;
+    auto fsw = [](int y, int x) { return HW == 16 ? ((x >> 1) & 7) : (((x >> 1) & 3) | ((y & 3) << 2)); };
+
+    uint4 ld[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int idx = tid + 256 * k, px = idx / NCH, ch = idx % NCH;
+        ld[k] = *reinterpret_cast<const uint4*>(p.in + ((size_t)b * (HW * HW) + px) * p.C + c0 + ch * 8);
+    }
+    for (int i = tid; i < (4 * HW + 4) * NCH; i += 256) {  // the ring of zero pixels
+        const int q = i / NCH, ch = i % NCH;
+        const int y = q < TW ? 0 : (q < 2 * TW ? TW - 1 : 1 + ((q - 2 * TW) >> 1)), x = q < TW ? q : (q < 2 * TW ? q - TW : ((q - 2 * TW) & 1) * (TW - 1));
+        *reinterpret_cast<uint4*>(tin + (y * TW + x) * RB + ch * 16) = make_uint4(0, 0, 0, 0);
+    }
+    // the wave's weight fragments (block-diagonal Toeplitz rows, dw_mm.h) and its lanes' biases
+    const DwmmLane wl(lane);
+    const int n = lane & 15, j = lane >> 4, s = j >> 1;
+    uint4 afr[GPW][3];
+    f32x4 bias[GPW];
+#pragma unroll
+    for (int g = 0; g < GPW; ++g) {
+        const int cg = c0 + wave * CPW + g * 8;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int tap = ky * 3 + min(max(wl.d, 0), 2);
+            afr[g][ky] = wl.place((uint32_t)p.w[(size_t)tap * p.C + cg + wl.c]);
+        }
+        const float4 bs = *reinterpret_cast<const float4*>(p.bias + cg + 4 * (j & 1));
+        bias[g] = f32x4{bs.x, bs.y, bs.z, bs.w};
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int idx = tid + 256 * k, px = idx / NCH, ch = idx % NCH;
+        const int y = px / HW + 1, x = px % HW + 1;
+        *reinterpret_cast<uint4*>(tin + (y * TW + x) * RB + ((ch ^ fsw(y, x)) << 4)) = ld[k];
+    }
+    __syncthreads();
+
+    // lane (n, j): pixel pair n of a tile = row ry, first pixel xp; B fragment = padded pixel (row + ky, xp + j)
+    const int ry = n / PPR, xp = 2 * (n % PPR);
+    int boff[GPW][3];
+#pragma unroll
+    for (int g = 0; g < GPW; ++g)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+            boff[g][ky] = ((ry + ky) * TW + xp + j) * RB + (((wave * GPW + g) ^ fsw(ry + ky, xp + j)) << 4);     // (rows of later tiles: + t RPT TW RB; f is periodic in them)
+    static_assert(HW == 16 || RPT % 4 == 0, "f(y, x) must not change from tile to tile");
+    int ooff[GPW];
+    {
+        const int px0 = ry * HW + xp + s;                   // the lane's output pixel in tile 0; tile t: + 32 t (h(pixel) is periodic in 32)
+#pragma unroll
+        for (int g = 0; g < GPW; ++g) ooff[g] = px0 * RB + ((((wave * GPW + g) ^ (px0 >> 1)) & (NCH - 1)) << 4) + (j & 1) * 8;
+    }
+    uint32_t one_lo, one_hi;
+    if constexpr (F16) asm volatile("v_mov_b32 %0, 0x3c00\n\tv_lshlrev_b32 %1, 16, %0" : "=v"(one_lo), "=v"(one_hi));
+    else asm volatile("v_mov_b32 %0, 0x3f80\n\tv_lshlrev_b32 %1, 16, %0" : "=v"(one_lo), "=v"(one_hi));
+    float psum[GPW][4];
+#pragma unroll
+    for (int g = 0; g < GPW; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) psum[g][i] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int g = 0; g < GPW; ++g) {
+            f32x4 acc = bias[g];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const uint4 bf = *reinterpret_cast<const uint4*>(tin + boff[g][ky] + t * (RPT * TW * RB));
+                acc = mfma16<F16>(afr[g][ky], bf, acc);
+            }
+            const uint32_t pk0 = T16<F16>::pack2(silu_fast(acc[0]), silu_fast(acc[1]));
+            const uint32_t pk1 = T16<F16>::pack2(silu_fast(acc[2]), silu_fast(acc[3]));
+            psum[g][0] = T16<F16>::dot2(pk0, one_lo, psum[g][0]);      // the pool sees the stored (rounded) activations
+            psum[g][1] = T16<F16>::dot2(pk0, one_hi, psum[g][1]);
+            psum[g][2] = T16<F16>::dot2(pk1, one_lo, psum[g][2]);
+            psum[g][3] = T16<F16>::dot2(pk1, one_hi, psum[g][3]);
+            *reinterpret_cast<uint2*>(tout + ooff[g] + t * (32 * RB)) = make_uint2(pk0, pk1);
+        }
+    }
+    __syncthreads();                                        // every fragment read is done: the input image is free
+    if (p.pooled) {
+        // pooled means, one fixed order (the fused front of the 8 x 8 blocks, conv_mb8.hip, walks the same one): a lane's sums over
+        // its tiles, then the 32 (pixel pair, pixel) slots in order -- through a per-wave scratch in the freed input image
+        float* const red = reinterpret_cast<float*>(tin + wave * (32 * CPW * 4));       // [slot = 2 n + s][CPW channels]
+#pragma unroll
+        for (int g = 0; g < GPW; ++g)
+            *reinterpret_cast<float4*>(red + (2 * n + s) * CPW + g * 8 + 4 * (j & 1)) = make_float4(psum[g][0], psum[g][1], psum[g][2], psum[g][3]);
+        if (lane < CPW) {
+            float rv[32];
+#pragma unroll
+            for (int q = 0; q < 32; ++q) rv[q] = red[q * CPW + lane];
+            float tsum = 0.f;
+#pragma unroll
+            for (int q = 0; q < 32; ++q) tsum += rv[q];
+            p.pooled[(size_t)b * p.C + c0 + wave * CPW + lane] = tsum / (float)(HW * HW);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int idx = tid + 256 * k, px = idx / NCH, ch = idx % NCH;
+        *reinterpret_cast<uint4*>(p.out + ((size_t)b * (HW * HW) + px) * p.C + c0 + ch * 8) =
+            *reinterpret_cast<const uint4*>(tout + px * RB + (((ch ^ (px >> 1)) & (NCH - 1)) << 4));
+    }
+}
+
+static constexpr int dwmm_lds_bytes(int hw) { return (hw + 2) * (hw + 2) * (hw == 16 ? 128 : 256) + hw * hw * (hw == 16 ? 128 : 256); }
+
 int dw_slabs(const DwArgs& a) {
     const int nq = (a.OH * a.OW) >> 2;
     return cdiv(a.C / 8, 256 / std::min(32, std::max(nq, 1)));
@@ -386,7 +524,24 @@ int launch_dwconv3x3(const DwArgs& a, hipStream_t st) {
         return ISB_ERR_INVALID;
     }
     if (a.stride == 1 && a.H == a.W && (a.H == 8 || a.H == 16) && a.OH == a.H && a.OW == a.W && a.pad == 1 && (form == 0 || form == 3) &&
-        !a.general) {
+        a.general == 0 && !a.se_w1 && a.C % (a.H == 8 ? 128 : 64) == 0) {
+        // batches: the taps on the matrix pipe (same slabs, so grid.x = dw_slabs(a))
+        static DevOnce attr_set;
+        if (attr_set.need()) {
+            ISB_HIP(hipFuncSetAttribute((const void*)dwconv3x3_mm_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, dwmm_lds_bytes(8)));
+            ISB_HIP(hipFuncSetAttribute((const void*)dwconv3x3_mm_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, dwmm_lds_bytes(8)));
+            ISB_HIP(hipFuncSetAttribute((const void*)dwconv3x3_mm_kernel<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, dwmm_lds_bytes(16)));
+            ISB_HIP(hipFuncSetAttribute((const void*)dwconv3x3_mm_kernel<false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, dwmm_lds_bytes(16)));
+            attr_set.mark();
+        }
+        const int ldsb = dwmm_lds_bytes(a.H);
+        if (a.H == 8) { if (form == 3) hipLaunchKernelGGL((dwconv3x3_mm_kernel<true, 8>), grid, dim3(256), ldsb, st, a); else hipLaunchKernelGGL((dwconv3x3_mm_kernel<false, 8>), grid, dim3(256), ldsb, st, a); }
+        else { if (form == 3) hipLaunchKernelGGL((dwconv3x3_mm_kernel<true, 16>), grid, dim3(256), ldsb, st, a); else hipLaunchKernelGGL((dwconv3x3_mm_kernel<false, 16>), grid, dim3(256), ldsb, st, a); }
+        ISB_LAUNCHED("dwconv3x3_mm", st);
+        return ISB_OK;
+    }
+    if (a.stride == 1 && a.H == a.W && (a.H == 8 || a.H == 16) && a.OH == a.H && a.OW == a.W && a.pad == 1 && (form == 0 || form == 3) &&
+        a.general != 1) {
         // grid.x = dw_slabs(a): slabs of 128 (8 x 8 maps) / 64 (16 x 16 maps) channels, as in the general kernel
 #define ISB_DW_MAP(F16_, HW_)                                                                                            \
     do {                                                                                                                 \

@@ -24,7 +24,16 @@ namespace isb {
 // 16 consecutive pixels of one chunk then sit in 16 different 16-byte slots (round 4; with `pixel & 7` pixels p and p + 8 shared a
 // slot: SQ_LDS_BANK_CONFLICT 19 % of the LDS-active cycles of this kernel, every A read two passes). The k loop
 // then streams only the weights: 16 instead of 24 KiB per k-step. Same (tap, channel) order: bit-identical.
-template <int WGM, int TN, int WPR, bool HALO = false, bool F16 = false>
+// REGE (round 5; projections to <= 64 channels): the E tile never exists. After the k loop a lane holds, for its pixel, sixteen
+// channels of every 32-channel tile in its accumulators -- bias, SiLU and ONE rounding (what the two-launch path stores) leave them
+// as eight 16-bit values per k16 step, and those ARE the B fragment of the projection's transposed MFMA once the contraction
+// index is ordered as the accumulator rows are (k slot (h, t) <-> channel 32 j + 16 s + 8 (t / 4) + 4 h + t % 4; the projection
+// weights are packed in that order at load time, launch_fmb_pack_w2). So a wave multiplies ITS 128 channels straight from
+// registers -- no 64-KiB E image in LDS, no A-fragment reads, and the eight publish() round trips of the streamed projection
+// weights become ONE: the packed weights (32 KiB) land in the k loop's buffers by LDS-DMA while the SiLUs run. The two waves
+// that share a pixel block then exchange one partial tile through LDS. Sums: a wave's 128 channels in k order, then
+// (channels 0 - 127) + (128 - 255): the two-launch path's bits up to f32 association (tested against it with that tolerance).
+template <int WGM, int TN, int WPR, bool HALO = false, bool F16 = false, bool REGE = false>
 __global__ __launch_bounds__(128 * WGM) void fused_mb_kernel(ConvArgs p) {
     T16<F16>::enter();
     constexpr int WGN = 2, NW = WGM * WGN;
@@ -35,13 +44,18 @@ __global__ __launch_bounds__(128 * WGM) void fused_mb_kernel(ConvArgs p) {
     constexpr int BUF = (BM + BN) * ROWB;
     constexpr int NKB = BN / 32;                             // k-blocks of the second GEMM
     constexpr int E_BYTES = NKB * BM * ROWB;                 // E tile: NKB blocks of [128 rows][64 B], swizzled like A tiles
-    constexpr int WP_ROWS = WPR, WP_BUF = WP_ROWS * ROWB;    // projection weights of one k-block (rows past Cout2 unused)
+    constexpr int WP_ROWS = WPR, WP_BUF = REGE ? 0 : WP_ROWS * ROWB;    // projection weights of one k-block (rows past Cout2 unused)
     constexpr int W2_PW = (WP_ROWS / 16 + NW - 1) / NW;
     constexpr int STAGE2 = BM * (64 * TN2 * 2 + 16);         // epilogue staging of the output tile
     constexpr int HW_ = 64, HWD = HW_ + 2, HALO_BYTES = 4 * HWD * 128;     // HALO: 264 pixel rows of 128 B = 33 pieces
     constexpr int BBUF = BN * ROWB;                                         // HALO: one k-step of weights
     constexpr int KREG = HALO ? HALO_BYTES + 2 * BBUF : 2 * BUF;
-    constexpr int REG_A0 = KREG > E_BYTES ? KREG : E_BYTES;
+    static_assert(!REGE || (TN2 == 1 && WGM == 4), "REGE: projections to <= 64 channels, 8 waves");
+    constexpr int C2T = (WPR + 31) / 32;                     // REGE: 32-channel tiles of the projection (each wave multiplies all of them)
+    constexpr int W2P_BYTES = C2T * NKB * 2 * 1024;          // REGE: the packed projection weights, one 1-KiB fragment per (tile, k16 step)
+    constexpr int XCH_OFF = W2P_BYTES > STAGE2 ? W2P_BYTES : STAGE2;      // REGE: partial tiles of the channel halves, 4 KiB per wave
+    constexpr int REGE_BYTES = XCH_OFF + 2 * WGM * 4096;
+    constexpr int REG_A0 = REGE ? (KREG > REGE_BYTES ? KREG : REGE_BYTES) : (KREG > E_BYTES ? KREG : E_BYTES);
     constexpr int REG_A = REG_A0 > STAGE2 ? REG_A0 : STAGE2;
     constexpr int WP_OFF = REG_A, BIAS1_OFF = WP_OFF + 2 * WP_BUF, BIAS2_OFF = BIAS1_OFF + BN * 4;
     __shared__ __attribute__((aligned(16))) unsigned char lds[BIAS2_OFF + 128 * 4];
@@ -51,6 +65,11 @@ __global__ __launch_bounds__(128 * WGM) void fused_mb_kernel(ConvArgs p) {
     const int wm = wave / WGN, wn = wave % WGN;
     const int r = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.x * BM;
+    // tuning probe (ConvArgs.probe & 2, isb_debug_fused_mb): s_memtime at the phase boundaries, wave 0 of workgroups 256 .. 319 (steady
+    // state: the first round of workgroups starts on an empty chip) -> p.part[64][8]
+    const bool stamped = (p.probe & 2) && p.part && blockIdx.x >= 256 && blockIdx.x < 320;
+    uint64_t st[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (stamped) st[0] = __builtin_amdgcn_s_memtime();
 
     const int ohw = p.OH * p.OW;
     const uint32_t pix = (uint32_t)p.Cin * 2u;
@@ -155,6 +174,9 @@ __global__ __launch_bounds__(128 * WGM) void fused_mb_kernel(ConvArgs p) {
     const int hq = wm * 32 + r;
     const int hp0 = (hq / HW_) * HWD + (hq % HW_);
     int h_tap = 0, h_off = 0;                                 // tap index and its pixel offset ky * 66 + kx
+    // (round 5: issuing all ten fragment reads of a k-step ahead of its eight MFMAs -- a second register set, sched_group_barrier --
+    // changes nothing, 201.9 vs 199.8 us per 128 frames: the k-step is set by the 16 KiB of weights a workgroup pulls in, 24 B/clk per CU
+    // with two workgroups, not by the wave's exposed LDS round trips; EXPERIMENTS.md)
     auto compute = [&](auto bufc) {
         constexpr int buf = decltype(bufc)::value;
 #pragma unroll
@@ -186,7 +208,7 @@ __global__ __launch_bounds__(128 * WGM) void fused_mb_kernel(ConvArgs p) {
     const int nkt = p.K / CK;
     dma(std::integral_constant<int, 0>{});
     publish();
-    prio_matrix(p.exp);
+    if (stamped) st[1] = __builtin_amdgcn_s_memtime();
     int kt = 0;
     for (; kt + 2 <= nkt; kt += 2) {
         dma(std::integral_constant<int, 1>{});
@@ -201,6 +223,96 @@ __global__ __launch_bounds__(128 * WGM) void fused_mb_kernel(ConvArgs p) {
         __syncthreads();
     }
 
+    if constexpr (REGE) {
+        // the packed projection weights -> the (free) k-loop region, in flight while the SiLUs run
+        {
+            constexpr int NPIECE = W2P_BYTES / 1024;
+#pragma unroll
+            for (int i = 0; i < (NPIECE + NW - 1) / NW; ++i)
+                if (wave + NW * i < NPIECE) dma16_s(p.w2p, (uint32_t)((wave + NW * i) * 1024 + lane * 16), ldsA + (wave + NW * i) * 1024);
+        }
+        if (stamped) st[2] = __builtin_amdgcn_s_memtime();
+        // E = T16(silu(acc + bias)): the lane's sixteen channels of tile j as two B fragments (k16 steps s = 0, 1)
+        uint4 ef[TN][2];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nl = (wn * TN + j) * 32 + 8 * q + 4 * h;
+                const float4 bs = *reinterpret_cast<const float4*>(lds + BIAS1_OFF + nl * 4);
+                float v0 = acc[j][4 * q] + bs.x, v1 = acc[j][4 * q + 1] + bs.y, v2 = acc[j][4 * q + 2] + bs.z, v3 = acc[j][4 * q + 3] + bs.w;
+                if (p.act) { v0 = silu_fast(v0); v1 = silu_fast(v1); v2 = silu_fast(v2); v3 = silu_fast(v3); }
+                const uint32_t lo = T16<F16>::pack2(v0, v1), hi = T16<F16>::pack2(v2, v3);
+                if (q == 0) { ef[j][0].x = lo; ef[j][0].y = hi; }
+                else if (q == 1) { ef[j][0].z = lo; ef[j][0].w = hi; }
+                else if (q == 2) { ef[j][1].x = lo; ef[j][1].y = hi; }
+                else { ef[j][1].z = lo; ef[j][1].w = hi; }
+            }
+        if (stamped) st[3] = __builtin_amdgcn_s_memtime();
+        publish();                                           // the packed weights have landed (and every wave has left the k loop's buffers)
+        if (stamped) st[4] = __builtin_amdgcn_s_memtime();
+        // partial projection over the wave's channels: acc2[c] (channels 32 c ..) += W2frag(c, tile, s) . Efrag(tile, s)
+        f32x16 pacc[C2T];
+#pragma unroll
+        for (int c = 0; c < C2T; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) pacc[c][e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int sI = 0; sI < 2; ++sI) {
+                uint4 wf[C2T];
+#pragma unroll
+                for (int c = 0; c < C2T; ++c)
+                    wf[c] = *reinterpret_cast<const uint4*>(lds + ((c * NKB + wn * TN + j) * 2 + sI) * 1024 + lane * 16);
+#pragma unroll
+                for (int c = 0; c < C2T; ++c) pacc[c] = T16<F16>::mfma32(wf[c], ef[j][sI], pacc[c]);
+            }
+        // the wave that shares this pixel block holds the other half of the channels: it gets the partial tile it finishes,
+        // this wave gets the one IT finishes (tile wn; C2T == 2)
+        static_assert(C2T <= 2, "REGE: one partial tile per wave");
+        __syncthreads();                                     // every wave is done with the packed weights (the exchange area is behind them, the staging area over them)
+        {
+            float4* xo = reinterpret_cast<float4*>(lds + XCH_OFF + wave * 4096) + lane;
+            const f32x16& give = pacc[C2T == 1 ? 0 : 1 - wn];
+            if (C2T == 2 || wn == 1) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xo[q * 64] = make_float4(give[4 * q], give[4 * q + 1], give[4 * q + 2], give[4 * q + 3]);
+            }
+        }
+        __syncthreads();
+        f32x16 acc2r[1][1];
+        {
+            const float4* xi = reinterpret_cast<const float4*>(lds + XCH_OFF + (wave ^ 1) * 4096) + lane;      // waves (wm, 0) and (wm, 1) are neighbours
+            const f32x16& own = pacc[C2T == 1 ? 0 : wn];
+            if (C2T == 2 || wn == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 o = xi[q * 64];
+                    // (channels 0 - 127) + (128 - 255): the same two operands in both waves' sums
+                    acc2r[0][0][4 * q] = own[4 * q] + o.x; acc2r[0][0][4 * q + 1] = own[4 * q + 1] + o.y;
+                    acc2r[0][0][4 * q + 2] = own[4 * q + 2] + o.z; acc2r[0][0][4 * q + 3] = own[4 * q + 3] + o.w;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc2r[0][0][e] = 0.f;      // (C2T == 1: wave (wm, 1) has no tile to finish; its rows lie past Cout2)
+            }
+        }
+        if (stamped) st[5] = __builtin_amdgcn_s_memtime();
+        ConvArgs p2 = p;
+        p2.Cout = p.Cout2;
+        p2.act = 0;
+        conv_epilogue<1, 1, WGM, 2, true, F16>(p2, acc2r, lds, m0, 0, wm, wn, r, h, tid, BIAS2_OFF);
+        if (stamped && tid == 0) {
+            st[6] = __builtin_amdgcn_s_memtime();
+            uint64_t* o = reinterpret_cast<uint64_t*>(p.part) + (size_t)(blockIdx.x - 256) * 8;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) o[i] = st[i + 1] - st[i];
+            o[6] = st[6] - st[0];
+            o[7] = 1;
+        }
+        return;
+    }
     // ---- E tile: bias + SiLU, one bf16 rounding (what the two-launch path stores), into the A layout of GEMM 2
     const unsigned char* w2_base = reinterpret_cast<const unsigned char*>(p.w2);
     auto dma_w2 = [&](auto bufc) {                           // next 32 expanded channels of the projection weights
@@ -210,8 +322,8 @@ __global__ __launch_bounds__(128 * WGM) void fused_mb_kernel(ConvArgs p) {
             if (wave + NW * s < WP_ROWS / 16) dma16_s(w2_base, w2_voff[s], lds0 + WP_OFF + buf * WP_BUF + NW * s * 1024);
         w2_base += CK * 2;
     };
+    if (stamped) st[2] = __builtin_amdgcn_s_memtime();
     dma_w2(std::integral_constant<int, 0>{});
-    prio_vector(p.exp);
     {
         const int ml = wm * 32 + r;
 #pragma unroll
@@ -228,8 +340,9 @@ __global__ __launch_bounds__(128 * WGM) void fused_mb_kernel(ConvArgs p) {
                 *reinterpret_cast<uint2*>(lds + (wn * TN + j) * (BM * ROWB) + swz(ml, q) + 8 * h) = pk;
             }
     }
+    if (stamped) st[3] = __builtin_amdgcn_s_memtime();
     publish();
-    prio_matrix(p.exp);
+    if (stamped) st[4] = __builtin_amdgcn_s_memtime();
 
     // ---- GEMM 2: out[128, Cout2] = E[128, Cexp] . w2[Cout2, Cexp]^T ; wave = 32 pixels x 32 * TN2 channels
     f32x16 acc2[1][TN2];
@@ -276,11 +389,49 @@ __global__ __launch_bounds__(128 * WGM) void fused_mb_kernel(ConvArgs p) {
     }
     static_assert(NKB == 4 || NKB == 8 || NKB == 12, "Cexp = 128, 256 or 384");
 
-    prio_vector(p.exp);
+    if (stamped) st[5] = __builtin_amdgcn_s_memtime();
     ConvArgs p2 = p;                                         // epilogue of the projection: bias2, no activation, residual
     p2.Cout = p.Cout2;
     p2.act = 0;
     conv_epilogue<1, TN2, WGM, 2, true, F16>(p2, acc2, lds, m0, 0, wm, wn, r, h, tid, BIAS2_OFF);
+    if (stamped && tid == 0) {
+        st[6] = __builtin_amdgcn_s_memtime();
+        uint64_t* o = reinterpret_cast<uint64_t*>(p.part) + (size_t)(blockIdx.x - 256) * 8;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) o[i] = st[i + 1] - st[i];
+        o[6] = st[6] - st[0];
+        o[7] = 1;
+    }
+}
+
+__global__ void fmb_pack_w2_kernel(const uint16_t* w2, uint4* dst, int Cout2, int Cexp, int total) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int lane = i & 63, sI = (i >> 6) & 1, nkb = Cexp / 32;
+    const int j = (i >> 7) % nkb, c = (i >> 7) / nkb;
+    const int row = 32 * c + (lane & 31), hh = lane >> 5;
+    uint32_t v[4] = {0, 0, 0, 0};
+    if (row < Cout2) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const uint32_t wv = w2[(size_t)row * Cexp + 32 * j + 16 * sI + 8 * (t >> 2) + 4 * hh + (t & 3)];
+            v[t >> 1] |= wv << (16 * (t & 1));
+        }
+    }
+    dst[i] = make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+size_t fmb_w2p_bytes(int Cout2, int Cexp) { return (size_t)cdiv(Cout2, 32) * (Cexp / 32) * 2 * 1024; }
+
+int launch_fmb_pack_w2(const uint16_t* w2, void* dst, int Cout2, int Cexp, hipStream_t st) {
+    if (Cexp % 32 != 0 || Cout2 < 1) {
+        set_error("fmb_pack_w2: Cout2=%d Cexp=%d", Cout2, Cexp);
+        return ISB_ERR_INVALID;
+    }
+    const int total = (int)(fmb_w2p_bytes(Cout2, Cexp) / 16);
+    hipLaunchKernelGGL(fmb_pack_w2_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w2, reinterpret_cast<uint4*>(dst), Cout2, Cexp, total);
+    ISB_LAUNCHED("fmb_pack_w2", st);
+    return ISB_OK;
 }
 
 int launch_fused_mb(const ConvArgs& a, hipStream_t st) {
@@ -300,11 +451,18 @@ int launch_fused_mb(const ConvArgs& a, hipStream_t st) {
         if (a.f16) hipLaunchKernelGGL((fused_mb_kernel<WGM, TN, WPR, HALO_, true>), dim3(cdiv(a.M, 32 * WGM)), dim3(128 * WGM), 0, st, aa); \
         else hipLaunchKernelGGL((fused_mb_kernel<WGM, TN, WPR, HALO_, false>), dim3(cdiv(a.M, 32 * WGM)), dim3(128 * WGM), 0, st, aa);     \
     } while (0)
+    // the projection from the accumulators (packed weights given; <= 64 projected channels)
+#define ISB_FMB_R(WGM, TN, HALO_)                                                                                            \
+    do {                                                                                                                     \
+        if (a.f16) hipLaunchKernelGGL((fused_mb_kernel<WGM, TN, 64, HALO_, true, true>), dim3(cdiv(a.M, 32 * WGM)), dim3(128 * WGM), 0, st, aa); \
+        else hipLaunchKernelGGL((fused_mb_kernel<WGM, TN, 64, HALO_, false, true>), dim3(cdiv(a.M, 32 * WGM)), dim3(128 * WGM), 0, st, aa);     \
+    } while (0)
+    const bool rege = a.w2p != nullptr && wpr == 64 && a.Cout2 > 32;
     // the shapes EfficientNetV2-L has: 32 -> 128 -> 64 (stride 2), 64 -> 256 -> 64 (body of stage 1: halo-tile A operand on its
     // 64-wide maps), 64 -> 256 -> 96 (stride 2). (384 expanded channels measured slower than two launches: EXPERIMENTS.md.)
-    if (a.Cout == 128 && wpr == 64) ISB_FMB(4, 2, 64, false);
-    else if (a.Cout == 256 && wpr == 64 && same1 && a.Cin == 64 && a.W == 64 && a.H % 2 == 0) ISB_FMB(4, 4, 64, true);
-    else if (a.Cout == 256 && wpr == 64) ISB_FMB(4, 4, 64, false);
+    if (a.Cout == 128 && wpr == 64) { if (rege) ISB_FMB_R(4, 2, false); else ISB_FMB(4, 2, 64, false); }
+    else if (a.Cout == 256 && wpr == 64 && same1 && a.Cin == 64 && a.W == 64 && a.H % 2 == 0) { if (rege) ISB_FMB_R(4, 4, true); else ISB_FMB(4, 4, 64, true); }
+    else if (a.Cout == 256 && wpr == 64) { if (rege) ISB_FMB_R(4, 4, false); else ISB_FMB(4, 4, 64, false); }
     else if (a.Cout == 256 && wpr == 96) ISB_FMB(4, 4, 96, false);
 #ifdef ISB_BUILD_PROBES
     else if (a.f16) { set_error("fused_mb: the probe shapes are bf16 only"); return ISB_ERR_INVALID; }
@@ -320,6 +478,7 @@ int launch_fused_mb(const ConvArgs& a, hipStream_t st) {
         return ISB_ERR_INVALID;
     }
 #undef ISB_FMB
+#undef ISB_FMB_R
     ISB_LAUNCHED("fused_mb", st);
     return ISB_OK;
 }

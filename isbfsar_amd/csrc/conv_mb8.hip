@@ -27,13 +27,14 @@
 // squeeze-excite for 384 channels) for 64 rows -- 128 FLOP per 16-bit weight byte against the 127 a CU's matrix pipe needs per
 // byte delivered at 32 B/clk; DESIGN.md section 3 has the arithmetic and the measured stamps.
 #include "conv_tiles.h"
+#include "dw_mm.h"
 
 namespace isb {
 
 namespace {
 
 constexpr int MB8_NW = 8;                       // waves per workgroup (two per SIMD)
-constexpr int MB8_NT = 64 * MB8_NW;
+[[maybe_unused]] constexpr int MB8_NT = 64 * MB8_NW;
 constexpr int MB8_XBYTES = 20 * 4096;           // residual stream: up to 640 channels = 20 tiles of [64 rows][64 B]
 constexpr int MB8_ET_PIX = 100;                 // 10 x 10 padded pixels
 constexpr int MB8_ET_BYTES = MB8_ET_PIX * 64;   // per wave: [pixel][32 ch x 2 B]
@@ -42,10 +43,11 @@ constexpr int MB8_POOL_OFF = MB8_ET_OFF + MB8_NW * MB8_ET_BYTES;      // f32 [Ce
 constexpr int MB8_MID_OFF = MB8_POOL_OFF + 3840 * 4;                  // f32 [160] squeeze-excite hidden units
 constexpr int MB8_PART_OFF = MB8_MID_OFF + 160 * 4;                   // f32 [15][160] FC1 partial sums per 256-channel chunk
 constexpr int MB8_LDS = MB8_PART_OFF + 15 * 160 * 4;                  // 158 720 B
-constexpr int MB8_RING_OFF = MB8_ET_OFF;        // phase 5: 8 D tiles of 4 KiB (two halves of four k-steps) overlay the E tiles
+[[maybe_unused]] constexpr int MB8_RING_OFF = MB8_ET_OFF;        // phase 5: 8 D tiles of 4 KiB (two halves of four k-steps) overlay the E tiles
 static_assert(8 * 4096 <= MB8_NW * MB8_ET_BYTES, "the D ring fits the E tiles' region");
 static_assert(MB8_LDS <= 160 * 1024, "LDS");
 
+#ifdef ISB_BUILD_PROBES      // (shapes of mb8_chain_kernel)
 template <int CIN, int COUT, bool F16>
 struct Mb8Shape {
     static constexpr int CEXP = 6 * CIN, CSE = CIN / 4;
@@ -66,8 +68,10 @@ __device__ __forceinline__ void mb8_static_for(F&& f) {
     }
 }
 
+#endif
 __device__ __forceinline__ int et_pix(int m) { return ((m >> 3) + 1) * 10 + (m & 7) + 1; }      // pixel m of the 8 x 8 map in the padded tile
 
+#ifdef ISB_BUILD_PROBES      // the per-sample chain: measured 2x slower than the five launches (EXPERIMENTS.md round 4), kept as a probe
 // One MBConv block for the workgroup's sample. X (LDS) in: the block's input, out: its output.
 template <int CIN, int COUT, bool F16>
 __device__ __forceinline__ void mb8_block(const Mb8Block& bk, unsigned char* lds, unsigned char* dscr, uint16_t* out_g, int tid, uint64_t* stamps) {
@@ -446,6 +450,7 @@ __global__ __launch_bounds__(MB8_NT) void mb8_chain_kernel(Mb8Args p) {
     }
 }
 
+#endif  // ISB_BUILD_PROBES
 // -------------------------------------------------------------------------------------------------------------------
 // The FRONT HALF of a stride-1 MBConv block on 8 x 8 maps in one launch: 1x1 expand + BN + SiLU -> depthwise 3x3 + BN + SiLU -> D
 // (NHWC, what the gated projection reads) + the squeeze-excite pool. The expanded tensor never leaves the chip.
@@ -464,9 +469,8 @@ struct Mf8 {
     static constexpr int NK16 = CIN / 16, NKT = CIN / 32, CEXP = 6 * CIN, NSL = CEXP / 128;
     static constexpr int XBUF = NKT * 4096;
     static constexpr int ET_OFF = XBUF;
-    // per wave 1.5 KiB: bias [32] f32 | depthwise bias [32] f32 | taps [9][4 chunks][(w, 0) x 4 pairs | (0, w) x 4 pairs]: the split
-    // copies v_dot2 needs, made ONCE (round 5: masking them per sample was 72 of the ~840 vector instructions of a sample)
-    static constexpr int TBL_BYTES = 1536;
+    // per wave 1 KiB: bias [32] f32 | depthwise bias [32] f32 | taps [9][32] 16-bit (tap-major)
+    static constexpr int TBL_BYTES = 1024;
     static constexpr int TBL_OFF = ET_OFF + 4 * MB8_ET_BYTES;
     static constexpr int LDS = TBL_OFF + 4 * TBL_BYTES;
     static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
@@ -513,10 +517,7 @@ __global__ __launch_bounds__(256, 2) void mbfront8_kernel(MbFront8Args p) {
     else if (lane < 16) *reinterpret_cast<float4*>(tbl + lane * 16) = *reinterpret_cast<const float4*>(p.dwb + c0 + (lane - 8) * 4);
     else if (lane < 16 + 36) {
         const int t = (lane - 16) >> 2, c4 = (lane - 16) & 3;
-        const uint4 tp = *reinterpret_cast<const uint4*>(p.dww + (size_t)t * CEXP + c0 + c4 * 8);
-        *reinterpret_cast<uint4*>(tbl + 256 + t * 128 + c4 * 32) = make_uint4(tp.x & 0xffffu, tp.y & 0xffffu, tp.z & 0xffffu, tp.w & 0xffffu);
-        *reinterpret_cast<uint4*>(tbl + 256 + t * 128 + c4 * 32 + 16) =
-            make_uint4(tp.x & 0xffff0000u, tp.y & 0xffff0000u, tp.z & 0xffff0000u, tp.w & 0xffff0000u);
+        *reinterpret_cast<uint4*>(tbl + 256 + t * 64 + c4 * 16) = *reinterpret_cast<const uint4*>(p.dww + (size_t)t * CEXP + c0 + c4 * 8);
     }
     for (int i = lane; i < 36 * 4; i += 64) {                       // the zero ring of the wave's padded tile, once
         const int qi = i >> 2, ch = i & 3;
@@ -528,7 +529,29 @@ __global__ __launch_bounds__(256, 2) void mbfront8_kernel(MbFront8Args p) {
     if constexpr (F16) asm volatile("v_mov_b32 %0, 0x3c00\n\tv_lshlrev_b32 %1, 16, %0" : "=v"(one_lo), "=v"(one_hi));
     else asm volatile("v_mov_b32 %0, 0x3f80\n\tv_lshlrev_b32 %1, 16, %0" : "=v"(one_lo), "=v"(one_hi));
 
+    // lane constants of the matrix-pipe depthwise (dw_mm.h). The padded tile's 16-byte chunk slots are turned by
+    // f(y, x) = ((x >> 2) & 1) | ((y & 1) << 1): the sixteen lanes a ds_read_b128 serves together (pixels 2 n + j of four rows) then
+    // fall into sixteen different slots of the 256-byte bank row (four pixels of 64 bytes)
+    const DwmmLane wl(lane);
+    const int w_d = min(max(wl.d, 0), 2);
+    const int mn = lane & 15, mj = lane >> 4, ms = mj >> 1;        // pixel pair, input column / output rows, pixel of the pair
+    const int e_f = ((((r & 7) + 1) >> 2) & 1) | ((((r >> 3) + 1) & 1) << 1);      // E write: padded pixel ((r >> 3) + 1 + 4 rb, (r & 7) + 1)
+    int b_pix[3], b_f[2];
+    {
+        const int ry = mn >> 2, xx = 2 * (mn & 3) + mj;             // B fragment: padded pixel (4 t + ry + ky, xx)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) b_pix[ky] = ((ry + ky) * 10 + xx) * 64;
+        b_f[0] = ((xx >> 2) & 1) | ((ry & 1) << 1);                 // ky even
+        b_f[1] = ((xx >> 2) & 1) | (((ry + 1) & 1) << 1);           // ky odd
+    }
+    int d_pix, d_f;
+    {
+        const int yy = (mn >> 2) + 1, xx = 2 * (mn & 3) + ms + 1;   // the lane's output pixel (tile 0), padded coordinates
+        d_pix = (yy * 10 + xx) * 64 + (mj & 1) * 8;
+        d_f = ((xx >> 2) & 1) | ((yy & 1) << 1);
+    }
     uint64_t st_wait = 0, st_body = 0, st_t0 = 0;                  // tuning probe (MbFront8Args.stamps)
+    uint64_t st_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};                               // ... phases of the body: expand MFMAs, second barrier, E epilogue, depthwise + stores
     if (p.stamps) st_t0 = __builtin_amdgcn_s_memtime();
     int it = 0;
     for (int smp = q; smp < p.B; smp += Q, ++it) {
@@ -545,18 +568,36 @@ __global__ __launch_bounds__(256, 2) void mbfront8_kernel(MbFront8Args p) {
         f32x16 acc[2];
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[0][e] = acc[1][e] = 0.f;
+        // fragment reads run one pair of k16 steps (four MFMAs) ahead of the MFMAs that use them, in a second register set: left to
+        // itself the compiler emits read -> wait -> MFMA per fragment, and with two waves per SIMD nothing hides the LDS latency
+        // (round 5 stamps: 2 930 cycles for these 48 MFMAs)
+        {
+            uint4 fa[2][4];                                          // [set][k16 of the pair x row block]
+            auto rd = [&](int pair, uint4 (&f)[4]) {
+                const unsigned char* xt = lds + pair * 4096;
+                f[0] = *reinterpret_cast<const uint4*>(xt + a_sw0); f[1] = *reinterpret_cast<const uint4*>(xt + a_sw0 + 2048);
+                f[2] = *reinterpret_cast<const uint4*>(xt + a_sw1); f[3] = *reinterpret_cast<const uint4*>(xt + a_sw1 + 2048);
+            };
+            rd(0, fa[0]);
 #pragma unroll
-        for (int k16 = 0; k16 < NK16; ++k16) {
-            const unsigned char* xt = lds + (k16 >> 1) * 4096 + ((k16 & 1) ? a_sw1 : a_sw0);
-            const uint4 a0 = *reinterpret_cast<const uint4*>(xt), a1 = *reinterpret_cast<const uint4*>(xt + 2048);
-            acc[0] = T16<F16>::mfma32(wreg[k16], a0, acc[0]);
-            acc[1] = T16<F16>::mfma32(wreg[k16], a1, acc[1]);
-            if ((k16 & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // (fragment reads at most four k16 steps ahead: registers)
+            for (int pr = 0; pr < NK16 / 2; ++pr) {
+                if (pr + 1 < NK16 / 2) rd(pr + 1, fa[(pr + 1) & 1]);
+                acc[0] = T16<F16>::mfma32(wreg[2 * pr], fa[pr & 1][0], acc[0]);
+                acc[1] = T16<F16>::mfma32(wreg[2 * pr], fa[pr & 1][1], acc[1]);
+                acc[0] = T16<F16>::mfma32(wreg[2 * pr + 1], fa[pr & 1][2], acc[0]);
+                acc[1] = T16<F16>::mfma32(wreg[2 * pr + 1], fa[pr & 1][3], acc[1]);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  // the next pair's four fragment reads first ...
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // ... then this pair's four MFMAs
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
+        uint64_t tc = 0, td = 0, te = 0;
+        if (p.stamps) tc = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_barrier();                               // everybody has read the tiles: the next sample's may land
+        if (p.stamps) { td = __builtin_amdgcn_s_memtime(); st_ph[0] += tc - tb; st_ph[1] += td - tc; }
         prio_vector(p.exp);
         if (smp + Q < p.B) dma_x(smp + Q);
-        // ---- E = T16(silu(acc + bias)) -> the wave's padded tile
+        // ---- E = T16(silu(acc + bias)) -> the wave's padded tile (16-byte chunk slot = chunk ^ f(y, x): see the lane constants)
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
             unsigned char* cell = et + et_pix(rb * 32 + r) * 64 + h * 8;
@@ -568,89 +609,108 @@ __global__ __launch_bounds__(256, 2) void mbfront8_kernel(MbFront8Args p) {
                 uint2 pk;
                 pk.x = T16<F16>::pack2(v0, v1);
                 pk.y = T16<F16>::pack2(v2, v3);
-                *reinterpret_cast<uint2*>(cell + qq * 16) = pk;
+                *reinterpret_cast<uint2*>(cell + ((qq ^ e_f) << 4)) = pk;
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        // ---- depthwise 3x3 + bias + SiLU (taps and order of dwconv3x3_map_kernel), D rows, pooled means
-        float dacc[4][8], psum[8];
+        if (p.stamps) { te = __builtin_amdgcn_s_memtime(); st_ph[2] += te - td; }
+        // ---- depthwise 3x3 + bias on the MATRIX pipe (dw_mm.h: per 8-channel group and 32-pixel tile three 16-byte fragment reads
+        // and three v_mfma_f32_16x16x32 instead of 288 v_dot2), SiLU, pooled sums; arithmetic and orders of dwconv3x3_mm_kernel<8>
+        // (all 24 MFMAs first -- the fragments of a group are read while the previous group multiplies -- then the 32 SiLUs as
+        // independent streams: one item after the other is a chain of dependent instructions, 5 700 cycles per sample)
+        f32x4 a4[4][2];
         {
-            const float4 d0 = *reinterpret_cast<const float4*>(tbl + 128 + cl * 32), d1 = *reinterpret_cast<const float4*>(tbl + 128 + cl * 32 + 16);
-            const float dbias[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+            uint4 bf[2][6];
+            auto rdb = [&](int g, uint4 (&f)[6]) {
 #pragma unroll
-            for (int o = 0; o < 4; ++o)
+                for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) dacc[o][e] = dbias[e];
-        }
+                    for (int ky = 0; ky < 3; ++ky)
+                        f[t * 3 + ky] = *reinterpret_cast<const uint4*>(et + b_pix[ky] + ((g ^ b_f[ky & 1]) << 4) + t * (4 * 10 * 64));
+            };
+            rdb(0, bf[0]);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) psum[e] = 0.f;
+            for (int g = 0; g < 4; ++g) {
+                uint4 af[3];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            // the row's three taps of the lane's eight channels, split into (w, 0) / (0, w) pairs: v_dot2 with a zeroed partner is the
-            // exact f32 FMA of ONE channel -- and, like dwconv3x3_map_kernel's, it flushes 16-bit denormal operands (a v_fma_mix_f32
-            // form, which needs no split copies, keeps them: not the same bits; measured)
-            uint32_t wlo[3][4], whi[3][4];
+                for (int ky = 0; ky < 3; ++ky)
+                    af[ky] = wl.place((uint32_t)*reinterpret_cast<const uint16_t*>(tbl + 256 + (ky * 3 + w_d) * 64 + (g * 8 + wl.c) * 2));
+                const float4 db = *reinterpret_cast<const float4*>(tbl + 128 + (g * 8 + 4 * (mj & 1)) * 4);
+                if (g + 1 < 4) rdb(g + 1, bf[(g + 1) & 1]);
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const uint4 tl = *reinterpret_cast<const uint4*>(tbl + 256 + (ky * 3 + kx) * 128 + cl * 32);
-                const uint4 th = *reinterpret_cast<const uint4*>(tbl + 256 + (ky * 3 + kx) * 128 + cl * 32 + 16);
-                wlo[kx][0] = tl.x; wlo[kx][1] = tl.y; wlo[kx][2] = tl.z; wlo[kx][3] = tl.w;
-                whi[kx][0] = th.x; whi[kx][1] = th.y; whi[kx][2] = th.z; whi[kx][3] = th.w;
-            }
-            uint4 v[6];
+                for (int t = 0; t < 2; ++t) {
+                    f32x4 c4 = f32x4{db.x, db.y, db.z, db.w};
 #pragma unroll
-            for (int col = 0; col < 6; ++col) v[col] = *reinterpret_cast<const uint4*>(et + ((oy + ky) * 10 + ox0 + col) * 64 + cl * 16);
-#pragma unroll
-            for (int col = 0; col < 6; ++col) {
-                const uint32_t x[4] = {v[col].x, v[col].y, v[col].z, v[col].w};
-#pragma unroll
-                for (int o = 0; o < 4; ++o) {
-                    const int kx = col - o;
-                    if (kx >= 0 && kx < 3) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            dacc[o][2 * e] = T16<F16>::dot2(x[e], wlo[kx][e], dacc[o][2 * e]);
-                            dacc[o][2 * e + 1] = T16<F16>::dot2(x[e], whi[kx][e], dacc[o][2 * e + 1]);
-                        }
-                    }
+                    for (int ky = 0; ky < 3; ++ky) c4 = mfma16<F16>(af[ky], bf[g & 1][t * 3 + ky], c4);
+                    a4[g][t] = c4;
                 }
+                __builtin_amdgcn_sched_group_barrier(0x100, 10, 0); // the group's taps and bias and the next group's six fragments: reads first
+                __builtin_amdgcn_sched_group_barrier(0x002, 16, 0); // the weight fragments take their places (vector ALU)
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);  // six MFMAs (two chains of three)
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
+        uint64_t tg = 0, th = 0, ti = 0;
+        if (p.stamps) { tg = __builtin_amdgcn_s_memtime(); st_ph[4] += tg - te; }
+        uint32_t dpk[4][2][2];                                      // [group][tile]: the lane's 4 channels of pixel 2 n + s
+        float psum[4][4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) psum[g][i] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const uint32_t pk0 = T16<F16>::pack2(silu_fast(a4[g][t][0]), silu_fast(a4[g][t][1]));
+                const uint32_t pk1 = T16<F16>::pack2(silu_fast(a4[g][t][2]), silu_fast(a4[g][t][3]));
+                psum[g][0] = T16<F16>::dot2(pk0, one_lo, psum[g][0]);      // the pool sees the stored (rounded) activations
+                psum[g][1] = T16<F16>::dot2(pk0, one_hi, psum[g][1]);
+                psum[g][2] = T16<F16>::dot2(pk1, one_lo, psum[g][2]);
+                psum[g][3] = T16<F16>::dot2(pk1, one_hi, psum[g][3]);
+                dpk[g][t][0] = pk0;
+                dpk[g][t][1] = pk1;
+            }
+        }
+        if (p.stamps) { th = __builtin_amdgcn_s_memtime(); st_ph[5] += th - tg; }
+        // D: every fragment read of the sample is done -- the results go into the tile's interior in place (own chunks, wave-private
+        // tile) and leave as whole 16-byte pieces: lane = (pixel quad, 8-channel chunk), four stores of 64 bytes per pixel and wave
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                *reinterpret_cast<uint2*>(et + d_pix + ((g ^ d_f) << 4) + t * (4 * 10 * 64)) = make_uint2(dpk[g][t][0], dpk[g][t][1]);
         uint16_t* const drow = p.d + ((size_t)smp * 64) * CEXP + c0 + cl * 8;
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
-            uint32_t pk[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                pk[e] = T16<F16>::pack2(silu_fast(dacc[o][2 * e]), silu_fast(dacc[o][2 * e + 1]));
-                psum[2 * e] = T16<F16>::dot2(pk[e], one_lo, psum[2 * e]);      // the pool sees the stored (rounded) activations
-                psum[2 * e + 1] = T16<F16>::dot2(pk[e], one_hi, psum[2 * e + 1]);
-            }
-            *reinterpret_cast<uint4*>(drow + (size_t)(oy * 8 + ox0 + o) * CEXP) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            const int yy = oy + 1, xx = ox0 + o + 1;
+            const uint4 v = *reinterpret_cast<const uint4*>(et + (yy * 10 + xx) * 64 + ((cl ^ (((xx >> 2) & 1) | ((yy & 1) << 1))) << 4));
+            *reinterpret_cast<uint4*>(drow + (size_t)(oy * 8 + ox0 + o) * CEXP) = v;
         }
-        // pool: quad sums -> 16-term sums in quad order -> / 64 (dwconv3x3_map_kernel's walk); the sums sit in the tile's interior
-        float* const red = reinterpret_cast<float*>(et + 11 * 64);
+        if (p.stamps) { ti = __builtin_amdgcn_s_memtime(); st_ph[6] += ti - th; }
+        // pool: the lanes' sums over their two tiles -> the 32 (pixel pair, pixel) slots in order (dwconv3x3_mm_kernel's walk), / 64
+        float* const red = reinterpret_cast<float*>(et + 11 * 64);       // 4 KiB over the tile's interior (and ring pixels, re-zeroed below)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) red[pq * 32 + cl * 8 + e] = psum[e];
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(red + (2 * mn + ms) * 32 + g * 8 + 4 * (mj & 1)) = make_float4(psum[g][0], psum[g][1], psum[g][2], psum[g][3]);
         if (lane < 32) {
-            float rv[16];                                           // all sixteen reads in flight, then the sum in quad order
+            float rv[32];
 #pragma unroll
-            for (int s2 = 0; s2 < 16; ++s2) rv[s2] = red[s2 * 32 + lane];
+            for (int s2 = 0; s2 < 32; ++s2) rv[s2] = red[s2 * 32 + lane];
             float t = 0.f;
 #pragma unroll
-            for (int s2 = 0; s2 < 16; ++s2) t += rv[s2];
+            for (int s2 = 0; s2 < 32; ++s2) t += rv[s2];
             p.pooled[(size_t)smp * CEXP + c0 + lane] = t / 64.0f;
         }
-        if (lane < 24) {                                            // the ring pixels the sums overlapped (19, 20, 29, 30, 39, 40)
+        if (lane < 48) {                                            // the ring pixels the sums overlapped: 19, 20, 29, 30, ..., 69, 70
             const int qi = lane >> 2, ch = lane & 3;
             *reinterpret_cast<uint4*>(et + (19 + 10 * (qi >> 1) + (qi & 1)) * 64 + ch * 16) = make_uint4(0, 0, 0, 0);
         }
-        if (p.stamps) st_body += __builtin_amdgcn_s_memtime() - tb;
+        if (p.stamps) { const uint64_t tf = __builtin_amdgcn_s_memtime(); st_body += tf - tb; st_ph[3] += tf - te; st_ph[7] += tf - ti; }
     }
-    if (p.stamps && blockIdx.x < 64 && lane == 0) {
-        uint64_t* o = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 4;
+    if (p.stamps && blockIdx.x < 32 && lane == 0) {
+        uint64_t* o = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 16;
         o[0] = __builtin_amdgcn_s_memtime() - st_t0; o[1] = st_wait; o[2] = st_body; o[3] = (uint64_t)it;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[4 + i] = st_ph[i];
     }
 }
 
@@ -730,6 +790,7 @@ int launch_mbfront8(const MbFront8Args& a, hipStream_t st) {
 int mb8_proj_group(int cout) { return cout == 384 ? 2 : 4; }           // Mb8Shape::CBW (the packing of Mb8Block.w2p)
 
 int launch_mb8_chain(const Mb8Args& a, hipStream_t st) {
+#ifdef ISB_BUILD_PROBES
     if (a.B < 1 || a.nblocks < 1 || !a.blocks || !a.x || !a.out || !a.dscratch || (a.cin0 != 384 && a.cin0 != 640) ||
         a.dscratch_stride < (size_t)64 * 6 * 640 * 2) {
         set_error("mb8_chain: bad arguments (B=%d nblocks=%d cin0=%d)", a.B, a.nblocks, a.cin0);
@@ -745,6 +806,11 @@ int launch_mb8_chain(const Mb8Args& a, hipStream_t st) {
     else hipLaunchKernelGGL(mb8_chain_kernel<false>, dim3(a.B), dim3(MB8_NT), MB8_LDS, st, a);
     ISB_LAUNCHED("mb8_chain", st);
     return ISB_OK;
+#else
+    (void)a; (void)st;
+    set_error("mb8_chain: the per-sample chain of the 8 x 8 stages is a probe (2x slower than the five launches); build with ISB_BUILD_PROBES=1");
+    return ISB_ERR_INVALID;
+#endif
 }
 
 }  // namespace isb

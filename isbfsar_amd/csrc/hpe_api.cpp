@@ -30,6 +30,7 @@ struct BlockW {
     int cin = 0, cout = 0, cexp = 0, stride = 1, cse = 0, in_hw = 0, out_hw = 0;
     ConvW expand, project;
     DevBuf dw_w16, dw_b, se_w1, se_b1, se_w2, se_b2;   // dw_w16: the depthwise taps in the stage's 16-bit type
+    DevBuf fmb_w2p;                   // Fused-MBConv blocks: the projection weights in the register-E kernel's fragment order (launch_fmb_pack_w2)
     DevBuf mbf_w1p;                   // stride-1 MBConv blocks with 384 inputs on 8 x 8 maps: the expand weights in fragment order (mbfront8_kernel)
     DevBuf mb_w1p, mb_w2p, mb_se1p;   // stride-1 blocks of the 8 x 8 stages: the weights in mb8_chain_kernel's streaming layouts (conv_mb8.hip)
 };
@@ -77,6 +78,8 @@ struct isb_hpe {
     bool mb8_on = false;
     // the FRONT half (expand + SiLU + depthwise + SiLU + pool) of the stride-1 MBConv blocks with 384 input channels on 8 x 8 maps in one
     // launch on stationary weights (conv_mb8.hip mbfront8_kernel; bit-identical to the two launches): batches >= mbf8_min_batch
+    bool fmb_rege = true;         // ISB_FMB_REGE=0: Fused-MBConv blocks with the E tile in LDS (the round-2 form; A/B switch)
+    bool dwmm_on = true;          // ISB_DWMM=0: stride-1 depthwise launches of a batch on the v_dot2 kernel instead of the matrix-pipe one (A/B switch)
     bool mbf8_on = true;          // ISB_MBF8=0: expand GEMM + depthwise kernel (the bit-identity test's reference)
     int mbf8_min_batch = 32;
     int mb8_min_batch = 48;
@@ -334,6 +337,7 @@ int backbone_blocks(isb_hpe* h, Lane& L, hipStream_t st, int B, size_t i0, size_
                 a.OH = b.out_hw; a.OW = b.out_hw; a.pad = b.stride == 1 ? 1 : 0; a.M = B * b.out_hw * b.out_hw; a.K = 9 * b.cin;
                 a.act = 1; a.f16 = b.f16 ? 1 : 0;
                 a.w2 = b.project.w16.as<uint16_t>(); a.bias2 = b.project.bias.as<float>(); a.Cout2 = b.cout;
+                a.w2p = h->fmb_rege ? b.fmb_w2p.p : nullptr;
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (h->prof) {
                     ISB_HIP(hipEventCreate(&e0));
@@ -378,6 +382,7 @@ int backbone_blocks(isb_hpe* h, Lane& L, hipStream_t st, int B, size_t i0, size_
                 d.pad = b.stride == 1 ? 1 : 0;
                 d.in_f16 = b.f16_in ? 1 : 0; d.out_f16 = b.f16 ? 1 : 0;
                 d.pooled = L.pooled.as<float>();
+                d.general = h->dwmm_on ? 0 : 2;
                 if (B == 1) {   // one frame: FC1 of the squeeze-excite rides in the depthwise launch (batches: measured slower)
                     d.se_w1 = b.se_w1.as<float>(); d.se_part = L.semid.as<float>(); d.cse = b.cse;
                     se_parts = dw_slabs(d);
@@ -478,7 +483,11 @@ extern "C" int isb_hpe_create(const isb_hpe_cfg* cfg, isb_hpe** out) {
     ISB_TRY(h->zeros.alloc(256));
     ISB_HIP(hipMemset(h->zeros.p, 0, 256));
     if (const char* e = getenv("ISB_FUSE_SE")) h->fuse_se = atoi(e) != 0;
-    if (const char* e = getenv("ISB_MB8")) h->mb8_on = atoi(e) != 0;
+#ifdef ISB_BUILD_PROBES
+    if (const char* e = getenv("ISB_MB8")) h->mb8_on = atoi(e) != 0;       // (the per-sample chain kernel exists in probe builds only)
+#endif
+    if (const char* e = getenv("ISB_DWMM")) h->dwmm_on = atoi(e) != 0;
+    if (const char* e = getenv("ISB_FMB_REGE")) h->fmb_rege = atoi(e) != 0;
     if (const char* e = getenv("ISB_MBF8")) h->mbf8_on = atoi(e) != 0;
     if (!isb::mbf8_verified()) h->mbf8_on = false;      // fail closed: the build could not confirm the kernel's counted wait (wsreg_guard.cpp)
     if (const char* e = getenv("ISB_MB8_MIN_BATCH")) h->mb8_min_batch = std::max(1, atoi(e));
@@ -577,6 +586,10 @@ extern "C" int isb_hpe_load_weights(isb_hpe* h, const void* blob, size_t nbytes)
                 } else {
                     ISB_TRY(upload_conv(m, p + ".expand", b->cexp, 3, b->cin, b->expand, st, b->f16));
                     ISB_TRY(upload_conv(m, p + ".project", b->cout, 1, b->cexp, b->project, st, b->f16));
+                    if (b->cexp <= 256 && b->cout <= 64) {
+                        ISB_TRY(b->fmb_w2p.alloc(fmb_w2p_bytes(b->cout, b->cexp)));
+                        ISB_TRY(launch_fmb_pack_w2(b->project.w16.as<uint16_t>(), b->fmb_w2p.p, b->cout, b->cexp, st));
+                    }
                 }
             } else {
                 ISB_TRY(upload_conv(m, p + ".expand", b->cexp, 1, b->cin, b->expand, st, b->f16_in));
@@ -1333,6 +1346,8 @@ extern "C" int isb_debug_fused_mb(int32_t device, const uint16_t* x, const float
     return isb::guard([&]() -> int {
         ISB_REQUIRE(x && w1 && scale1 && shift1 && w2 && scale2 && shift2 && out && ms_per_iter, ISB_ERR_INVALID, "null argument");
         const int f16 = (stride & 0x100) ? 1 : 0;      // x / res / out hold fp16 bits and the weights are rounded to fp16
+        const int stamps = (stride & 0x200) ? 1 : 0;   // tuning probe: phase clocks of workgroups 256 .. 319 to stderr
+        const int lds_e = (stride & 0x400) ? 1 : 0;    // the E tile through LDS (round 2's form) instead of the projection from the accumulators
         stride &= 0xff;
         ISB_REQUIRE((stride == 1 || stride == 2) && iters >= 1 && B >= 1, ISB_ERR_INVALID, "bad parameters");
         ISB_HIP(hipSetDevice(device));
@@ -1360,6 +1375,19 @@ extern "C" int isb_debug_fused_mb(int32_t device, const uint16_t* x, const float
         a.B = B; a.H = H; a.W = H; a.Cin = Cin; a.Cout = Cexp; a.KH = 3; a.KW = 3; a.stride = stride; a.OH = OH; a.OW = OH;
         a.pad = stride == 1 ? 1 : 0; a.M = B * OH * OH; a.K = 9 * Cin; a.act = 1;
         a.w2 = dw2.as<uint16_t>(); a.bias2 = db2.as<float>(); a.Cout2 = Cout2;
+        DevBuf dw2p;
+        if (!lds_e && Cout2 <= 64 && Cexp <= 256) {
+            ISB_TRY(dw2p.alloc(fmb_w2p_bytes(Cout2, Cexp)));
+            ISB_TRY(launch_fmb_pack_w2(dw2.as<uint16_t>(), dw2p.p, Cout2, Cexp, nullptr));
+            a.w2p = dw2p.p;
+        }
+        DevBuf dstamps;
+        if (stamps) {
+            ISB_TRY(dstamps.alloc(64 * 64));
+            ISB_HIP(hipMemset(dstamps.p, 0, 64 * 64));
+            a.part = dstamps.as<float>();
+            a.probe = 2;
+        }
         ISB_TRY(launch_fused_mb(a, nullptr));
         ISB_HIP(hipDeviceSynchronize());
         hipEvent_t e0, e1;
@@ -1375,6 +1403,21 @@ extern "C" int isb_debug_fused_mb(int32_t device, const uint16_t* x, const float
         (void)hipEventDestroy(e1);
         *ms_per_iter = ms / iters;
         ISB_HIP(hipMemcpy(out, dout.p, nout * 2, hipMemcpyDeviceToHost));
+        if (stamps) {
+            std::vector<uint64_t> st(64 * 8);
+            ISB_HIP(hipMemcpy(st.data(), dstamps.p, 64 * 64, hipMemcpyDeviceToHost));
+            double sum[7] = {0, 0, 0, 0, 0, 0, 0};
+            int n = 0;
+            for (int g = 0; g < 64; ++g) {
+                if (!st[(size_t)g * 8 + 7]) continue;
+                for (int i = 0; i < 7; ++i) sum[i] += (double)st[(size_t)g * 8 + i];
+                ++n;
+            }
+            if (n)
+                fprintf(stderr, "fused_mb, mean of %d workgroups (cycles, wave 0): prologue %.0f | k loop %.0f | E epilogue %.0f | its publish %.0f | "
+                                "GEMM 2 %.0f | out epilogue %.0f | workgroup %.0f\n",
+                        n, sum[0] / n, sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n, sum[5] / n, sum[6] / n);
+        }
         return ISB_OK;
     });
 }
@@ -1442,7 +1485,7 @@ static int debug_dwconv_impl(int32_t device, const uint16_t* x, const float* w, 
     return isb::guard([&]() -> int {
         ISB_REQUIRE(x && w && scale && shift && out && pooled && ms_per_iter, ISB_ERR_INVALID, "null argument");
         const int in_f16 = (stride & 0x100) ? 1 : 0, out_f16 = (stride & 0x200) ? 1 : 0;   // fp16 input + taps / fp16 output
-        const int general = (stride & 0x400) ? 1 : 0;                                       // never the 8 x 8-map kernel
+        const int general = (stride & 0x400) ? 1 : ((stride & 0x800) ? 2 : 0);              // DwArgs.general: 1 = the general kernel, 2 = the LDS-map kernel with v_dot2 taps
         stride &= 0xff;
         ISB_REQUIRE((stride == 1 || stride == 2) && iters >= 1 && B >= 1, ISB_ERR_INVALID, "bad depthwise parameters");
         ISB_HIP(hipSetDevice(device));

@@ -88,6 +88,14 @@ int post_launch(const char* what, hipStream_t st) {
 
 }  // namespace isb
 
+// 1 in builds with -DISB_BUILD_PROBES (tools/, probe-only tests); not part of the C ABI of include/isbfsar.h
+extern "C" int isbfsar_probe_build(void) {
+#ifdef ISB_BUILD_PROBES
+    return 1;
+#else
+    return 0;
+#endif
+}
 extern "C" const char* isb_last_error(void) { return isb::g_err; }
 extern "C" int isb_version(void) { return 2; }      // 2: isb_ar_cfg.precision 0 = default (fp16), bf16 = 3 (include/isbfsar.h)
 extern "C" int isb_device_count(void) {

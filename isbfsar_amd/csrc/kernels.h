@@ -163,6 +163,8 @@ struct ConvArgs {
     int probe;
     int exp;                // open experiments (isb::exp_flags(), set by the launchers): bit 8 = s_setprio around the k loops (EXPERIMENTS.md r5)
     const uint16_t* w2;     // bf16 [Cout2][Cout] (BN scale folded)
+    const void* w2p;        // the same weights in the register-E kernel's fragment order (launch_fmb_pack_w2; fmb_w2p_bytes) or null:
+                            // projections to <= 64 channels then run from the accumulators (fused_mb_kernel<.., REGE>)
     const float* bias2;     // [Cout2]
     int Cout2;
 };
@@ -170,6 +172,10 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t st);
 // conv_ws.hip: the weights-stationary expand GEMMs (tile variants 181 - 188); aa = a with the grid fields the launcher fills
 int launch_conv_ws(const ConvArgs& a, ConvArgs& aa, int v, hipStream_t st);
 int launch_fused_mb(const ConvArgs& a, hipStream_t st);
+// projection weights [Cout2][Cexp] (16-bit) -> [tile c][Cexp / 32 tiles j][2 k16 steps s][64 lanes][8]: lane (m = lane & 31, h = lane >> 5) holds
+// W[32 c + m][32 j + 16 s + 8 (t / 4) + 4 h + t % 4], t = 0..7 (rows past Cout2 are zero)
+size_t fmb_w2p_bytes(int Cout2, int Cexp);
+int launch_fmb_pack_w2(const uint16_t* w2, void* dst, int Cout2, int Cexp, hipStream_t st);
 int launch_splitk_reduce(const ConvArgs& a, hipStream_t st);
 
 // ---------------------------------------------------------------- conv_mb8.hip: the stride-1 MBConv blocks of the 8 x 8 stages as one launch
@@ -211,7 +217,9 @@ struct MbFront8Args {
     float* pooled;          // out [B][cexp] f32 spatial means
     int B, cin, f16;
     int exp;                // open experiments (isb::exp_flags(), set by the launcher)
-    uint64_t* stamps;       // tuning probe or null: [64 workgroups][4 waves][4] = loop cycles, waiting at the loop top, bodies, iterations
+    uint64_t* stamps;       // tuning probe or null: [32 workgroups][4 waves][16] = loop cycles, waiting at the loop top, bodies, iterations,
+                            // then the bodies' phases: expand MFMAs, second barrier, E epilogue, depthwise + stores + pool, and the last
+                            // one's parts: its MFMAs, SiLU + pack + sums, D through LDS + stores, pooled means
 };
 int launch_mbfront8(const MbFront8Args& a, hipStream_t st);
 int mbf8_verified();        // wsreg_guard.cpp: 1 only if the build confirmed mbfront8_kernel's counted wait in the disassembly
@@ -231,7 +239,8 @@ struct DwArgs {
     const float* se_w1;     // [cse,C] or null
     float* se_part;         // [dw_slabs(a)][B][cse]
     int cse;
-    int general;            // 1: never the 8 x 8-map kernel (tests compare the two forms bit for bit)
+    int general;            // kernel choice on stride-1 8 x 8 / 16 x 16 maps: 0 = taps on the matrix pipe (dwconv3x3_mm_kernel; batches), 2 = the
+                            // LDS-map kernel with v_dot2 taps, 1 = the general kernel (tests compare 1 and 2 bit for bit, 0 within f32 rounding)
     int in_f16, out_f16;    // `in` + `w` / `out` hold fp16 instead of bf16 (ConvArgs.f16); in bf16 -> out fp16 is the block that
                             // enters the fp16 stages
 };

@@ -253,7 +253,7 @@ def conv_debug(x_bf16, w, scale, shift, k, stride, act, res_bf16=None, gate=None
     return out, ms.value
 
 
-def fused_mb_debug(x_bf16, w1, scale1, shift1, w2, scale2, shift2, res_bf16=None, stride=1, iters=1, device=0, f16=False):
+def fused_mb_debug(x_bf16, w1, scale1, shift1, w2, scale2, shift2, res_bf16=None, stride=1, iters=1, device=0, f16=False, stamps=False, lds_e=False):
     """A whole Fused-MBConv block through isb_debug_fused_mb. x_bf16 uint16 [B,H,H,Cin], w1 f32 [Cexp,3,3,Cin],
     w2 f32 [Cout2,Cexp]. Returns (out uint16 [B,H/stride,H/stride,Cout2], ms_per_launch). f16: x / res / out hold fp16 bits."""
     x = np.ascontiguousarray(x_bf16, dtype=np.uint16)
@@ -265,7 +265,7 @@ def fused_mb_debug(x_bf16, w1, scale1, shift1, w2, scale2, shift2, res_bf16=None
     r = None if res_bf16 is None else np.ascontiguousarray(res_bf16, dtype=np.uint16)
     ms = C.c_float()
     _lib.check(_lib.lib().isb_debug_fused_mb(device, _ptr(x), _ptr(w1), _ptr(f(scale1)), _ptr(f(shift1)), _ptr(w2),
-                                             _ptr(f(scale2)), _ptr(f(shift2)), _ptr(r), B, H, Cin, Cexp, Cout2, stride | (0x100 if f16 else 0), iters,
+                                             _ptr(f(scale2)), _ptr(f(shift2)), _ptr(r), B, H, Cin, Cexp, Cout2, stride | (0x100 if f16 else 0) | (0x200 if stamps else 0) | (0x400 if lds_e else 0), iters,
                                              _ptr(out), C.byref(ms)), "isb_debug_fused_mb")
     return out, ms.value
 
@@ -291,7 +291,8 @@ def gemm_f32_debug(A, W, bias=None, a_bias=None, a_add=None, act=0, a_act=0, spl
 def dwconv_debug(x_bf16, w, scale, shift, stride=1, iters=1, device=0, in_f16=False, out_f16=False, general=False):
     """Depthwise 3x3 + SiLU + SE mean through isb_debug_dwconv. x_bf16 uint16 [B,H,H,C], w f32 [C,3,3].
     Returns (out uint16 [B,H/stride,H/stride,C], pooled f32 [B,C], ms_per_launch). in_f16: x and the taps are fp16;
-    out_f16: out is fp16 (DwArgs.in_f16 / out_f16); general: the general kernel also on 8 x 8 maps."""
+    out_f16: out is fp16 (DwArgs.in_f16 / out_f16); general (DwArgs.general, stride-1 8 x 8 / 16 x 16 maps): 0 = the taps on the
+    matrix pipe (what batches run), 1 / True = the general kernel, 2 = the LDS-map kernel with v_dot2 taps."""
     x = np.ascontiguousarray(x_bf16, dtype=np.uint16)
     B, H, _, Cc = x.shape
     f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
@@ -299,7 +300,7 @@ def dwconv_debug(x_bf16, w, scale, shift, stride=1, iters=1, device=0, in_f16=Fa
     pooled = np.empty((B, Cc), np.float32)
     ms = C.c_float()
     _lib.check(_lib.lib().isb_debug_dwconv(device, _ptr(x), _ptr(f(w)), _ptr(f(scale)), _ptr(f(shift)), B, H, Cc,
-                                           stride | (0x100 if in_f16 else 0) | (0x200 if out_f16 else 0) | (0x400 if general else 0),
+                                           stride | (0x100 if in_f16 else 0) | (0x200 if out_f16 else 0) | {0: 0, 1: 0x400, 2: 0x800}[int(general)],
                                            iters, _ptr(out), _ptr(pooled), C.byref(ms)), "isb_debug_dwconv")
     return out, pooled, ms.value
 

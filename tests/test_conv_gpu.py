@@ -237,8 +237,12 @@ def test_depthwise_pool(B, H, C, stride):
     (1, 32, 64, 256, 96, 2, False),     # stage 3 first block
 ])
 def test_fused_mbconv_block(B, H, Cin, Cexp, Cout2, stride, use_res, f16):
-    """One-launch Fused-MBConv block: bit-identical to the two-launch path (lean 3x3 kernel -> 1x1 GEMM kernel), and
-    within one ulp of the 16-bit type of torch-CPU on the same rounded operands -- in bf16 and in fp16 (ConvArgs.f16)."""
+    """One-launch Fused-MBConv block, in bf16 and in fp16 (ConvArgs.f16). With the E tile through LDS (round 2's form, still what
+    projections to 96 channels run) it is bit-identical to the two-launch path (lean 3x3 kernel -> 1x1 GEMM kernel). With the
+    projection straight from the accumulators (round 5, projections to 64 channels: fused_mb_kernel<.., REGE>) the expanded values
+    are the same bits and the projection's sum is associated differently -- (channels 0 - 127) + (128 - 255), the k slots of an MFMA in
+    accumulator-row order -- so it agrees with the two-launch path to f32 rounding: the same 16-bit outputs except at rounding
+    boundaries. Both within one ulp of the 16-bit type of torch-CPU on the same rounded operands."""
     from isbfsar_amd.hpe_engine import f16_to_f32, f32_to_f16, fused_mb_debug
     rng = np.random.default_rng(Cexp * 10 + Cout2 + stride)
     x = rng.normal(0, 1, (B, H, H, Cin)).astype(np.float32)
@@ -251,10 +255,20 @@ def test_fused_mbconv_block(B, H, Cin, Cexp, Cout2, stride, use_res, f16):
     cvt, back = (f32_to_f16, f16_to_f32) if f16 else (f32_to_bf16, bf16_to_f32)
     xb, rb = cvt(x), (None if res is None else cvt(res))
     out, _ = fused_mb_debug(xb, w1, s1, b1, w2, s2, b2, rb, stride, f16=f16)
+    lds_e, _ = fused_mb_debug(xb, w1, s1, b1, w2, s2, b2, rb, stride, f16=f16, lds_e=True)
     # two-launch path through the same library
     e, _ = conv_debug(xb, w1, s1, b1, 3, stride, 1, None, None, variant=0, f16=f16)
     two, _ = conv_debug(e, w2.reshape(Cout2, 1, 1, Cexp), s2, b2, 1, 1, 0, rb, None, variant=0, f16=f16)
-    assert np.array_equal(out, two)
+    assert np.array_equal(lds_e, two)
+    if Cout2 > 64:
+        assert np.array_equal(out, two)                      # (96 projected channels: the LDS form is the only one)
+    else:
+        fo, ft = back(out), back(two)
+        step = (2.0 ** -10 if f16 else 2.0 ** -7) * np.abs(ft) + 2e-6
+        assert np.all(np.abs(fo - ft) <= step), float(np.abs(fo - ft).max())
+        assert np.mean(out != two) < 5e-3, float(np.mean(out != two))
+        again, _ = fused_mb_debug(xb, w1, s1, b1, w2, s2, b2, rb, stride, f16=f16, iters=2)
+        assert np.array_equal(out, again)
     # torch-CPU
     got = back(out)
     if f16:
@@ -541,10 +555,47 @@ def test_dwconv_map8_is_bit_identical(HW, Cc, f16):
     scale = rng.uniform(0.8, 1.2, Cc).astype(np.float32)
     shift = rng.uniform(-0.1, 0.1, Cc).astype(np.float32)
     xin = f32_to_f16(x) if f16 else f32_to_bf16(x)
-    a, pa, _ = dwconv_debug(xin, w, scale, shift, stride=1, in_f16=f16, out_f16=f16)
-    g, pg, _ = dwconv_debug(xin, w, scale, shift, stride=1, in_f16=f16, out_f16=f16, general=True)
+    a, pa, _ = dwconv_debug(xin, w, scale, shift, stride=1, in_f16=f16, out_f16=f16, general=2)
+    g, pg, _ = dwconv_debug(xin, w, scale, shift, stride=1, in_f16=f16, out_f16=f16, general=1)
     assert np.array_equal(a, g) and np.array_equal(pa, pg)
     assert np.abs(pa).max() > 0
+
+
+@pytest.mark.parametrize("f16", [False, True])
+@pytest.mark.parametrize("B,HW,Cc", [(5, 8, 2304), (3, 8, 3840), (2, 8, 128), (5, 16, 768), (3, 16, 1344), (2, 16, 1152), (1, 16, 64)])
+def test_dwconv_taps_on_the_matrix_pipe(B, HW, Cc, f16):
+    """dwconv3x3_mm_kernel (round 5; what a batch's stride-1 depthwise launches run): the nine taps as three Toeplitz-band
+    v_mfma_f32_16x16x32 per 8 channels x 32 pixels instead of 288 v_dot2 (dw_mm.h). Products of 16-bit values are exact in f32
+    and the sums are f32 in both forms, so against the v_dot2 kernel the results may differ by the summation ORDER only: the
+    16-bit outputs agree except at rounding boundaries (one ulp of the storage type there), pooled means to f32 rounding; and
+    against torch on the same rounded operands like every depthwise kernel."""
+    from isbfsar_amd.hpe_engine import dwconv_debug, f16_to_f32, f32_to_f16
+    rng = np.random.default_rng(Cc + int(f16) + HW + B)
+    x = rng.normal(0, 1, (B, HW, HW, Cc)).astype(np.float32)
+    w = (rng.normal(0, 1, (Cc, 3, 3)) / 3.0).astype(np.float32)
+    scale = rng.uniform(0.8, 1.2, Cc).astype(np.float32)
+    shift = rng.uniform(-0.1, 0.1, Cc).astype(np.float32)
+    cvt, back = (f32_to_f16, f16_to_f32) if f16 else (f32_to_bf16, bf16_to_f32)
+    xin = cvt(x)
+    a, pa, _ = dwconv_debug(xin, w, scale, shift, stride=1, in_f16=f16, out_f16=f16)               # general = 0: the matrix-pipe kernel
+    g, pg, _ = dwconv_debug(xin, w, scale, shift, stride=1, in_f16=f16, out_f16=f16, general=2)    # v_dot2 taps
+    fa, fg = back(a), back(g)
+    ulp = (2.0 ** -10 if f16 else 2.0 ** -7) * np.abs(fg) + 2e-6            # one step of the storage type, or f32 rounding of a nine-term sum near zero
+    assert np.all(np.abs(fa - fg) <= ulp), float(np.abs(fa - fg).max())
+    assert np.mean(a != g) < 5e-3, float(np.mean(a != g))
+    np.testing.assert_allclose(pa, pg, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(pa, fa.reshape(B, -1, Cc).mean(axis=1), rtol=0, atol=2e-5)          # the pool sees the stored values
+    xr = torch.from_numpy(back(xin)).permute(0, 3, 1, 2)
+    wf = torch.from_numpy(w) * torch.from_numpy(scale).view(-1, 1, 1)
+    wf = (wf.half() if f16 else wf.bfloat16()).float().unsqueeze(1)
+    y = F.conv2d(xr, wf, padding=1, groups=Cc) + torch.from_numpy(shift).view(1, -1, 1, 1)
+    y = (y * torch.sigmoid(y)).permute(0, 2, 3, 1)
+    ref = (y.half() if f16 else y.bfloat16()).float().numpy()
+    tol = (2.0 ** -10 if f16 else 2.0 ** -7) * np.maximum(0.25 if f16 else 1.0, np.abs(ref))
+    assert np.all(np.abs(fa - ref) <= tol), float(np.abs(fa - ref).max())
+    # a repeated launch gives the same bits (fixed summation orders, no atomics)
+    a2, pa2, _ = dwconv_debug(xin, w, scale, shift, stride=1, in_f16=f16, out_f16=f16, iters=2)
+    assert np.array_equal(a, a2) and np.array_equal(pa, pa2)
 
 
 @pytest.mark.parametrize("f16", [False, True])

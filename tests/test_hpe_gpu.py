@@ -835,8 +835,16 @@ def test_fused_8x8_chain_is_bit_identical_to_the_five_launch_path(bbone_state, a
     chain: expand from register-streamed weights, depthwise from LDS, squeeze-excite in the workgroup, gated projection, residual
     in LDS). Every sum keeps the order of the five-launch path, so features and poses are the same BITS. The chain measured 2x
     SLOWER than the five launches (EXPERIMENTS.md round 4: per-sample weight streams are bound by L2 -> CU delivery), so it is off by
-    default and ISB_MB8=1 (read when the engine is created) selects it."""
+    default and ISB_MB8=1 (read when the engine is created) selects it. Round 5: the kernel is compiled in PROBE builds only
+    (ISB_BUILD_PROBES=1), and its depthwise taps are v_dot2 sums, so the path it is compared with runs the
+    v_dot2 depthwise kernel too (ISB_DWMM=0, ISB_MBF8=0: the product's batch path now puts the taps on the matrix pipe)."""
+    import ctypes
+    from isbfsar_amd import _lib
     from isbfsar_amd.hpe_engine import HpeEngine
+    if not ctypes.CDLL(_lib.LIB_PATH).isbfsar_probe_build():
+        pytest.skip("mb8_chain_kernel is compiled in probe builds only (ISB_BUILD_PROBES=1 python -m isbfsar_amd.build --force)")
+    monkeypatch.setenv("ISB_DWMM", "0")
+    monkeypatch.setenv("ISB_MBF8", "0")
     from oracle import hpe_oracle as ho
     W, st = assets
     idx = st["smpl+head_30"]["indices"]

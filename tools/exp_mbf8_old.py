@@ -24,12 +24,8 @@ e.forward(fr, bb)
 torch.cuda.synchronize()
 out = np.zeros((32 * 2 * 32,), np.uint64)
 _lib.check(_lib.lib().isb_debug_hpe_mb8_stamps(e._h, 0, out.ctypes.data_as(C.c_void_p)), "stamps off")
-t = out[:32 * 4 * 16].reshape(32, 4, 16).astype(np.int64)        # the last launch's stamps
+t = out[:64 * 4 * 4].reshape(64, 4, 4).astype(np.int64)          # the last launch's stamps
 ok = t[:, :, 3] > 0
-tot, wait, body, its, p0, p1, p2, p3, p4, p5, p6, p7 = (t[:, :, i][ok] for i in range(12))
+tot, wait, body, its = (t[:, :, i][ok] for i in range(4))
 print(f"iterations per workgroup {its.min()}-{its.max()}; per iteration (median over waves): loop {np.median(tot / its):.0f} cycles, "
       f"waiting at the top {np.median(wait / its):.0f}, body {np.median(body / its):.0f}; whole loop {np.median(tot)} cycles")
-print(f"body phases per iteration: expand MFMAs {np.median(p0 / its):.0f}, second barrier {np.median(p1 / its):.0f}, "
-      f"E epilogue {np.median(p2 / its):.0f}, depthwise + stores + pool {np.median(p3 / its):.0f}")
-print(f"depthwise phase: MFMAs {np.median(p4 / its):.0f}, SiLU + pack + sums {np.median(p5 / its):.0f}, D through LDS + stores {np.median(p6 / its):.0f}, "
-      f"pooled means {np.median(p7 / its):.0f}")
