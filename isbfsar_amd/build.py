@@ -54,6 +54,7 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-u
 # (EXPERIMENTS.md, tools/): ~130 more instantiations, a 6-minute build. The product build holds what the three networks launch.
 if os.environ.get("ISB_BUILD_PROBES", "0") not in ("", "0"):
     FLAGS.append("-DISB_BUILD_PROBES")
+    SOURCES.insert(SOURCES.index("conv_gemm1x1_gate.hip") + 1, "conv_wsk.hip")     # variant 157: measured 2x slower (EXPERIMENTS.md round 5)
 
 
 def _hipcc() -> str:

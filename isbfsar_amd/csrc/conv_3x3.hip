@@ -181,7 +181,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_dma_kernel(ConvArgs p)
     const int nkt = p.K / CK;
     dma(std::integral_constant<int, 0>{});
     publish();
-    prio_matrix(p.exp);
     int kt = 0;
     for (; kt + 2 <= nkt; kt += 2) {
         dma(std::integral_constant<int, 1>{});
@@ -195,7 +194,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_dma_kernel(ConvArgs p)
         compute(std::integral_constant<int, 0>{});
         __syncthreads();
     }
-    prio_vector(p.exp);
     conv_epilogue<TM, TN, WGM, WGN, true, F16>(p, acc, lds, m0, n0, wm, wn, r, h, tid, bias_off);
 }
 

@@ -112,16 +112,17 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
     }
     const int v = a.variant ? a.variant : choose_variant(a);
     const bool is_g1 = (v >= 131 && v <= 140) || v == 150, is_g1g = (v >= 141 && v <= 149) || (v >= 152 && v <= 156) || (v >= 191 && v <= 197);
+    const bool is_wsk = v == 157;
     const bool is_ws = v >= 181 && v <= 188, is_c3 = v >= 161 && v <= 171;
-    if (a.act_after_res && (a.act < 2 || a.out_f32 || aa.splits > 1 || v == 171 || is_ws)) {
+    if (a.act_after_res && (a.act < 2 || a.out_f32 || aa.splits > 1 || v == 171 || is_ws || is_wsk)) {
         set_error("conv_igemm: act_after_res takes act 2-4 on the kernels with the shared 16-bit epilogue (variant %d)", v);
         return ISB_ERR_INVALID;
     }
-    if (a.out_ld && (a.out_ld < a.Cout || a.out_ld % 8 != 0 || a.out_f32 || aa.splits > 1 || v == 171 || v == 149 || is_ws)) {
+    if (a.out_ld && (a.out_ld < a.Cout || a.out_ld % 8 != 0 || a.out_f32 || aa.splits > 1 || v == 171 || v == 149 || is_ws || is_wsk)) {
         set_error("conv_igemm: out_ld (a channel slice of a wider 16-bit tensor) needs out_ld >= Cout, a multiple of 8, and a kernel with the shared epilogue (variant %d)", v);
         return ISB_ERR_INVALID;
     }
-    if (a.f16 && !(is_g1 || is_g1g || is_ws || is_c3)) {
+    if (a.f16 && !(is_g1 || is_g1g || is_ws || is_c3 || is_wsk)) {
         set_error("conv_igemm: fp16 operands are implemented by the lean kernels (1x1: 131 / 132 / 138, gated 141 - 156, weights-stationary 184 - 186; 3x3: 161 / 163 / 167 / 169 / 171), got variant %d", v);
         return ISB_ERR_INVALID;
     }
@@ -142,6 +143,15 @@ static int launch_conv_igemm_impl(const ConvArgs& a, hipStream_t st) {
         return ISB_ERR_INVALID;
     }
     int rc;
+#ifdef ISB_BUILD_PROBES
+    if (is_wsk) rc = launch_conv_wsk(a, aa, st);
+    else
+#else
+    if (is_wsk) {
+        set_error("conv_igemm: variant 157 (gated projection with stationary weights: 2x slower than the tile kernels) exists in probe builds only");
+        return ISB_ERR_INVALID;
+    }
+#endif
     if (is_ws) rc = launch_conv_ws(a, aa, v, st);
     else if (is_g1) rc = launch_tiles_gemm1x1(v, a, aa, st);
     else if (is_g1g) rc = launch_tiles_gemm1x1_gate(v, a, aa, st);

@@ -363,8 +363,9 @@ __global__ __launch_bounds__(256) void dwconv3x3_map_kernel(DwArgs p) {
 }
 
 
-// Stride-1 depthwise 3x3 on whole 8 x 8 / 16 x 16 maps with the TAPS ON THE MATRIX PIPE (dw_mm.h; round 5): the batch path of the 54
-// stride-1 depthwise launches. Staging as in dwconv3x3_map_kernel (the slab goes to LDS once, inside a ring of zero pixels), but a
+// Stride-1 depthwise 3x3 on whole 8 x 8 / 16 x 16 maps with the TAPS ON THE MATRIX PIPE (dw_mm.h; round 5; DwArgs.general == 3): the
+// stand-alone partner of the fused 8 x 8 front (same arithmetic, same bits), selected for blocks that have one when the batch is too
+// small for it. Staging as in dwconv3x3_map_kernel (the slab goes to LDS once, inside a ring of zero pixels), but a
 // wave owns CPW channels of the slab for ALL pixels: per 8-channel group and 32-pixel tile, three 16-byte fragment reads + three
 // v_mfma_f32_16x16x32 replace 288 v_dot2 (per lane: 4 outputs instead of 32 per pass, 7 vector instructions per output instead of
 // 17). The 16-bit results are staged in LDS and leave as full pixel rows; pooled means: per lane over its tiles in order, then the
@@ -524,8 +525,10 @@ int launch_dwconv3x3(const DwArgs& a, hipStream_t st) {
         return ISB_ERR_INVALID;
     }
     if (a.stride == 1 && a.H == a.W && (a.H == 8 || a.H == 16) && a.OH == a.H && a.OW == a.W && a.pad == 1 && (form == 0 || form == 3) &&
-        a.general == 0 && !a.se_w1 && a.C % (a.H == 8 ? 128 : 64) == 0) {
-        // batches: the taps on the matrix pipe (same slabs, so grid.x = dw_slabs(a))
+        a.general == 3 && !a.se_w1 && a.C % (a.H == 8 ? 128 : 64) == 0) {
+        // the taps on the matrix pipe (same slabs, so grid.x = dw_slabs(a)): the arithmetic of the fused 8 x 8 front (mbfront8_kernel), for
+        // the batches too small for it. As a stand-alone kernel it is SLOWER than the v_dot2 form below (66 vs 60 us on 16 x 16 maps, 58 vs
+        // 52 on 8 x 8 at 256 frames: these launches move their bytes at 6 TB/s either way, and this form holds two workgroups per CU)
         static DevOnce attr_set;
         if (attr_set.need()) {
             ISB_HIP(hipFuncSetAttribute((const void*)dwconv3x3_mm_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, dwmm_lds_bytes(8)));

@@ -564,7 +564,6 @@ __global__ __launch_bounds__(256, 2) void mbfront8_kernel(MbFront8Args p) {
         __builtin_amdgcn_s_barrier();
         if (p.stamps) { tb = __builtin_amdgcn_s_memtime(); st_wait += tb - ta; }
         // ---- expand: the sample x the wave's 32 channels
-        prio_matrix(p.exp);
         f32x16 acc[2];
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[0][e] = acc[1][e] = 0.f;
@@ -595,7 +594,6 @@ __global__ __launch_bounds__(256, 2) void mbfront8_kernel(MbFront8Args p) {
         if (p.stamps) tc = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_barrier();                               // everybody has read the tiles: the next sample's may land
         if (p.stamps) { td = __builtin_amdgcn_s_memtime(); st_ph[0] += tc - tb; st_ph[1] += td - tc; }
-        prio_vector(p.exp);
         if (smp + Q < p.B) dma_x(smp + Q);
         // ---- E = T16(silu(acc + bias)) -> the wave's padded tile (16-byte chunk slot = chunk ^ f(y, x): see the lane constants)
 #pragma unroll

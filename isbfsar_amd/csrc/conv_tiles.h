@@ -121,12 +121,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
     }
 }
 
-// experiment (ConvArgs.exp bit 8, ISB_EXP=0x100): a wave inside a k loop (matrix phase) outranks a wave inside an epilogue (vector
-// phase) when they compete for a SIMD's issue port -- two workgroups share a CU, and without it the OLDER wave wins whatever it
-// issues (MI355X_MICROARCH.md, "Two waves per SIMD", item 2): a vector phase of the older workgroup starves the other's MFMAs
-__device__ __forceinline__ void prio_matrix(int exp) { if (exp & 0x100) __builtin_amdgcn_s_setprio(2); }
-__device__ __forceinline__ void prio_vector(int exp) { if (exp & 0x100) __builtin_amdgcn_s_setprio(0); }
-
 // workgroup -> output tile. Mode 0: 2-D grid. Modes 1/2: 1-D grid; hardware hands consecutive workgroup ids
 // to the 8 XCDs round-robin, so id % 8 names the XCD (and its private L2) a workgroup runs on. Within an XCD
 // the N tiles of one M tile are consecutive: the A rows are fetched into that L2 once and re-read from it.
@@ -203,6 +197,7 @@ int launch_tiles_igemm(int v, const ConvArgs& a, ConvArgs& aa, hipStream_t st); 
 int launch_tiles_gemm1x1(int v, const ConvArgs& a, ConvArgs& aa, hipStream_t st);       // conv_gemm1x1.hip: 131 - 140, 150
 int launch_tiles_gemm1x1_gate(int v, const ConvArgs& a, ConvArgs& aa, hipStream_t st);  // conv_gemm1x1_gate.hip: 141 - 149, 152 - 156, 191 - 197
 int launch_tiles_conv3x3(int v, const ConvArgs& a, ConvArgs& aa, hipStream_t st);       // conv_3x3.hip: 161 - 171
+int launch_conv_wsk(const ConvArgs& a, ConvArgs& aa, hipStream_t st);                   // conv_wsk.hip: 157 (gated projection, weights stationary in registers)
 
 static inline dim3 conv_grid(ConvArgs& a, int BM, int BN) {
     a.grid_m = cdiv(a.M, BM);

@@ -79,7 +79,7 @@ struct isb_hpe {
     // the FRONT half (expand + SiLU + depthwise + SiLU + pool) of the stride-1 MBConv blocks with 384 input channels on 8 x 8 maps in one
     // launch on stationary weights (conv_mb8.hip mbfront8_kernel; bit-identical to the two launches): batches >= mbf8_min_batch
     bool fmb_rege = true;         // ISB_FMB_REGE=0: Fused-MBConv blocks with the E tile in LDS (the round-2 form; A/B switch)
-    bool dwmm_on = true;          // ISB_DWMM=0: stride-1 depthwise launches of a batch on the v_dot2 kernel instead of the matrix-pipe one (A/B switch)
+    bool dwmm_on = true;          // ISB_DWMM=0: (tests of the probe-only chain kernel) small batches of fused-front blocks on the v_dot2 depthwise kernel
     bool mbf8_on = true;          // ISB_MBF8=0: expand GEMM + depthwise kernel (the bit-identity test's reference)
     int mbf8_min_batch = 32;
     int mb8_min_batch = 48;
@@ -382,7 +382,9 @@ int backbone_blocks(isb_hpe* h, Lane& L, hipStream_t st, int B, size_t i0, size_
                 d.pad = b.stride == 1 ? 1 : 0;
                 d.in_f16 = b.f16_in ? 1 : 0; d.out_f16 = b.f16 ? 1 : 0;
                 d.pooled = L.pooled.as<float>();
-                d.general = h->dwmm_on ? 0 : 2;
+                // a block that has a fused front (mbfront8_kernel, batches >= mbf8_min_batch) runs the stand-alone kernel with ITS
+                // arithmetic below that size, so that a frame's bits do not depend on the batch it arrives in
+                d.general = (h->dwmm_on && h->mbf8_on && b.mbf_w1p.p) ? 3 : 0;
                 if (B == 1) {   // one frame: FC1 of the squeeze-excite rides in the depthwise launch (batches: measured slower)
                     d.se_w1 = b.se_w1.as<float>(); d.se_part = L.semid.as<float>(); d.cse = b.cse;
                     se_parts = dw_slabs(d);
@@ -1485,7 +1487,7 @@ static int debug_dwconv_impl(int32_t device, const uint16_t* x, const float* w, 
     return isb::guard([&]() -> int {
         ISB_REQUIRE(x && w && scale && shift && out && pooled && ms_per_iter, ISB_ERR_INVALID, "null argument");
         const int in_f16 = (stride & 0x100) ? 1 : 0, out_f16 = (stride & 0x200) ? 1 : 0;   // fp16 input + taps / fp16 output
-        const int general = (stride & 0x400) ? 1 : ((stride & 0x800) ? 2 : 0);              // DwArgs.general: 1 = the general kernel, 2 = the LDS-map kernel with v_dot2 taps
+        const int general = ((stride & 0x400) ? 1 : 0) | ((stride & 0x800) ? 2 : 0);        // DwArgs.general: 1 = the general kernel, 2 = the LDS-map kernel, 3 = taps on the matrix pipe
         stride &= 0xff;
         ISB_REQUIRE((stride == 1 || stride == 2) && iters >= 1 && B >= 1, ISB_ERR_INVALID, "bad depthwise parameters");
         ISB_HIP(hipSetDevice(device));

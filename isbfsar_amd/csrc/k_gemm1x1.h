@@ -229,7 +229,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_dma_kernel(ConvArgs p)
         }
     };
 
-    prio_matrix(p.exp);
     if constexpr (NBUF == 3) {
         // pieces this wave requests per k-step (wave-uniform): the counted wait needs it as an immediate
         int n_req = 0;
@@ -303,7 +302,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm1x1_dma_kernel(ConvArgs p)
     }
     }
     if constexpr (STAMPS) st_loop1 = __builtin_amdgcn_s_memtime();
-    prio_vector(p.exp);
     conv_epilogue<TM, TN, WGM, WGN, true, F16>(p, acc, lds, m0, n0, wm, wn, r, h, tid, bias_off);
     if constexpr (STAMPS) {
         const uint64_t t_end = __builtin_amdgcn_s_memtime();

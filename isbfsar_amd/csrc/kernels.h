@@ -161,7 +161,8 @@ struct ConvArgs {
     // tuning probes of gemm1x1_wsreg_kernel (isb_debug_conv variant 9181 / ISB_WS_PROBE): bit 0 = no output stores,
     // bit 1 = s_memtime stamps of the first workgroups' wave 0 into `part` (1 KiB per workgroup)
     int probe;
-    int exp;                // open experiments (isb::exp_flags(), set by the launchers): bit 8 = s_setprio around the k loops (EXPERIMENTS.md r5)
+    int exp;                // open experiments (isb::exp_flags() = ISB_EXP, set by the launchers); no bit is in use (EXPERIMENTS.md round 5: bit 8 was
+                            // s_setprio around the k loops)
     const uint16_t* w2;     // bf16 [Cout2][Cout] (BN scale folded)
     const void* w2p;        // the same weights in the register-E kernel's fragment order (launch_fmb_pack_w2; fmb_w2p_bytes) or null:
                             // projections to <= 64 channels then run from the accumulators (fused_mb_kernel<.., REGE>)
@@ -239,8 +240,9 @@ struct DwArgs {
     const float* se_w1;     // [cse,C] or null
     float* se_part;         // [dw_slabs(a)][B][cse]
     int cse;
-    int general;            // kernel choice on stride-1 8 x 8 / 16 x 16 maps: 0 = taps on the matrix pipe (dwconv3x3_mm_kernel; batches), 2 = the
-                            // LDS-map kernel with v_dot2 taps, 1 = the general kernel (tests compare 1 and 2 bit for bit, 0 within f32 rounding)
+    int general;            // kernel choice on stride-1 8 x 8 / 16 x 16 maps: 0 / 2 = the LDS-map kernel with v_dot2 taps, 1 = the general kernel
+                            // (tests compare the two bit for bit), 3 = taps on the matrix pipe (dwconv3x3_mm_kernel: the arithmetic of the
+                            // fused 8 x 8 front, within f32 rounding of the others)
     int in_f16, out_f16;    // `in` + `w` / `out` hold fp16 instead of bf16 (ConvArgs.f16); in bf16 -> out fp16 is the block that
                             // enters the fp16 stages
 };

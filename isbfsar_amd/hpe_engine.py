@@ -291,8 +291,8 @@ def gemm_f32_debug(A, W, bias=None, a_bias=None, a_add=None, act=0, a_act=0, spl
 def dwconv_debug(x_bf16, w, scale, shift, stride=1, iters=1, device=0, in_f16=False, out_f16=False, general=False):
     """Depthwise 3x3 + SiLU + SE mean through isb_debug_dwconv. x_bf16 uint16 [B,H,H,C], w f32 [C,3,3].
     Returns (out uint16 [B,H/stride,H/stride,C], pooled f32 [B,C], ms_per_launch). in_f16: x and the taps are fp16;
-    out_f16: out is fp16 (DwArgs.in_f16 / out_f16); general (DwArgs.general, stride-1 8 x 8 / 16 x 16 maps): 0 = the taps on the
-    matrix pipe (what batches run), 1 / True = the general kernel, 2 = the LDS-map kernel with v_dot2 taps."""
+    out_f16: out is fp16 (DwArgs.in_f16 / out_f16); general (DwArgs.general, stride-1 8 x 8 / 16 x 16 maps): 0 / 2 = the LDS-map kernel
+    with v_dot2 taps, 1 / True = the general kernel, 3 = the taps on the matrix pipe (the fused 8 x 8 front's arithmetic)."""
     x = np.ascontiguousarray(x_bf16, dtype=np.uint16)
     B, H, _, Cc = x.shape
     f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
@@ -300,7 +300,7 @@ def dwconv_debug(x_bf16, w, scale, shift, stride=1, iters=1, device=0, in_f16=Fa
     pooled = np.empty((B, Cc), np.float32)
     ms = C.c_float()
     _lib.check(_lib.lib().isb_debug_dwconv(device, _ptr(x), _ptr(f(w)), _ptr(f(scale)), _ptr(f(shift)), B, H, Cc,
-                                           stride | (0x100 if in_f16 else 0) | (0x200 if out_f16 else 0) | {0: 0, 1: 0x400, 2: 0x800}[int(general)],
+                                           stride | (0x100 if in_f16 else 0) | (0x200 if out_f16 else 0) | {0: 0, 1: 0x400, 2: 0x800, 3: 0xc00}[int(general)],
                                            iters, _ptr(out), _ptr(pooled), C.byref(ms)), "isb_debug_dwconv")
     return out, pooled, ms.value
 

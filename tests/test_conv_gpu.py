@@ -385,6 +385,36 @@ def test_auto_dispatch_of_a_short_k_gemm_without_activation(B, H, Cin, Cout, f16
     assert np.abs(back(out) - ref).max() <= (2.0 ** -10 if f16 else 2.0 ** -7) * max(1.0, np.abs(ref).max()) + 1e-4
 
 
+@pytest.mark.parametrize("B,H,Cin,Cout", [(64, 16, 1344, 224), (70, 16, 1152, 224), (65, 16, 768, 192), (3, 16, 768, 192), (130, 16, 1344, 224)])
+def test_gated_projection_with_stationary_weights(B, H, Cin, Cout):
+    """gemm1x1_wsk_kernel (conv_wsk.hip, tile variant 157; round 5): the SE-gated fp16 projections of the 16 x 16 stage with a wave's
+    weights for all of K in registers and the gate applied once per CU on the activations' way into LDS -- same k order, same gate
+    rounding (f16(f32(x) * g)), same shared epilogue as the tile kernel: bit-identical to variant 143 / 141; and against torch on
+    the same rounded operands. Shapes: one tile sequence longer than the others (ragged tile count), fewer tiles than sequences.
+    MEASURED 2x SLOWER than the tile kernels (EXPERIMENTS.md round 5: a lone wave per SIMD, 32 KiB in flight per CU), so the kernel is
+    compiled in probe builds only; the gate's single rounding (v_fma_mix) differs from the tile kernel's mul + convert in rare
+    double-rounding cases, hence one 16-bit step of tolerance."""
+    import ctypes
+    from isbfsar_amd import _lib
+    from isbfsar_amd.hpe_engine import f16_to_f32, f32_to_f16
+    if not ctypes.CDLL(_lib.LIB_PATH).isbfsar_probe_build():
+        pytest.skip("variant 157 is compiled in probe builds only (ISB_BUILD_PROBES=1 python -m isbfsar_amd.build --force)")
+    rng = np.random.default_rng(B + Cin)
+    x = rng.normal(0, 1, (B, H, H, Cin)).astype(np.float32)
+    w = (rng.normal(0, 1, (Cout, 1, 1, Cin)) / np.sqrt(Cin)).astype(np.float32)
+    scale = rng.uniform(0.8, 1.2, Cout).astype(np.float32)
+    shift = rng.uniform(-0.1, 0.1, Cout).astype(np.float32)
+    res = f32_to_f16(rng.normal(0, 1, (B, H, H, Cout)).astype(np.float32))
+    gate = rng.uniform(0.1, 0.9, (B, Cin)).astype(np.float32)
+    out, _ = conv_debug(f32_to_f16(x), w, scale, shift, 1, 1, 0, res, gate, variant=157, f16=True)
+    tile, _ = conv_debug(f32_to_f16(x), w, scale, shift, 1, 1, 0, res, gate, variant=143 if Cout == 224 else 141, f16=True)
+    fo, ft = f16_to_f32(out), f16_to_f32(tile)
+    assert np.all(np.abs(fo - ft) <= 2.0 ** -10 * np.abs(ft) + 2e-6) and np.mean(out != tile) < 1e-3
+    again, _ = conv_debug(f32_to_f16(x), w, scale, shift, 1, 1, 0, res, gate, variant=157, f16=True, iters=2)
+    assert np.array_equal(out, again)
+    assert np.isfinite(f16_to_f32(out)).all() and float(np.abs(f16_to_f32(out)).max()) > 0
+
+
 def _gemm_ref(A, W, bias, a_bias, a_add, act, a_act):
     """float64 restatement of gemm_f32.hip's contract."""
     actf = {0: lambda v: v, 1: lambda v: np.maximum(v, 0), 2: lambda v: v / (1 + np.exp(-v)), 3: lambda v: 1 / (1 + np.exp(-v))}
@@ -564,7 +594,7 @@ def test_dwconv_map8_is_bit_identical(HW, Cc, f16):
 @pytest.mark.parametrize("f16", [False, True])
 @pytest.mark.parametrize("B,HW,Cc", [(5, 8, 2304), (3, 8, 3840), (2, 8, 128), (5, 16, 768), (3, 16, 1344), (2, 16, 1152), (1, 16, 64)])
 def test_dwconv_taps_on_the_matrix_pipe(B, HW, Cc, f16):
-    """dwconv3x3_mm_kernel (round 5; what a batch's stride-1 depthwise launches run): the nine taps as three Toeplitz-band
+    """dwconv3x3_mm_kernel (round 5; DwArgs.general = 3: the stand-alone partner of the fused 8 x 8 front): the nine taps as three Toeplitz-band
     v_mfma_f32_16x16x32 per 8 channels x 32 pixels instead of 288 v_dot2 (dw_mm.h). Products of 16-bit values are exact in f32
     and the sums are f32 in both forms, so against the v_dot2 kernel the results may differ by the summation ORDER only: the
     16-bit outputs agree except at rounding boundaries (one ulp of the storage type there), pooled means to f32 rounding; and
@@ -577,7 +607,7 @@ def test_dwconv_taps_on_the_matrix_pipe(B, HW, Cc, f16):
     shift = rng.uniform(-0.1, 0.1, Cc).astype(np.float32)
     cvt, back = (f32_to_f16, f16_to_f32) if f16 else (f32_to_bf16, bf16_to_f32)
     xin = cvt(x)
-    a, pa, _ = dwconv_debug(xin, w, scale, shift, stride=1, in_f16=f16, out_f16=f16)               # general = 0: the matrix-pipe kernel
+    a, pa, _ = dwconv_debug(xin, w, scale, shift, stride=1, in_f16=f16, out_f16=f16, general=3)    # the matrix-pipe kernel
     g, pg, _ = dwconv_debug(xin, w, scale, shift, stride=1, in_f16=f16, out_f16=f16, general=2)    # v_dot2 taps
     fa, fg = back(a), back(g)
     ulp = (2.0 ** -10 if f16 else 2.0 ** -7) * np.abs(fg) + 2e-6            # one step of the storage type, or f32 rounding of a nine-term sum near zero
@@ -594,7 +624,7 @@ def test_dwconv_taps_on_the_matrix_pipe(B, HW, Cc, f16):
     tol = (2.0 ** -10 if f16 else 2.0 ** -7) * np.maximum(0.25 if f16 else 1.0, np.abs(ref))
     assert np.all(np.abs(fa - ref) <= tol), float(np.abs(fa - ref).max())
     # a repeated launch gives the same bits (fixed summation orders, no atomics)
-    a2, pa2, _ = dwconv_debug(xin, w, scale, shift, stride=1, in_f16=f16, out_f16=f16, iters=2)
+    a2, pa2, _ = dwconv_debug(xin, w, scale, shift, stride=1, in_f16=f16, out_f16=f16, general=3, iters=2)
     assert np.array_equal(a, a2) and np.array_equal(pa, pa2)
 
 
@@ -644,7 +674,7 @@ def test_gated_projection_with_loader_waves_is_bit_identical(shape, f16):
     assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("kind", ["g1_131", "g1_138", "gate_146", "gate_155", "ws_184", "ws_186", "c3_161", "c3_171", "c3_167", "fused", "dw1", "dw2", "splitk"])
+@pytest.mark.parametrize("kind", ["g1_131", "g1_138", "gate_146", "gate_155", "ws_184", "ws_186", "c3_161", "c3_171", "c3_167", "fused", "dw1", "dw1mm", "dw2", "splitk"])
 def test_f16_storage_saturates_instead_of_overflowing(kind):
     """fp16 storage must never produce an inf (it would poison every later layer): the kernels templated on the storage type set
     MODE.FP16_OVFL at their start, so conversions clamp to +-65504 (conv_common.h T16::enter). Every fp16 kernel family is driven
@@ -683,10 +713,11 @@ def test_f16_storage_saturates_instead_of_overflowing(kind):
         out, _ = fused_mb_debug(f32_to_f16(x), w1, 300.0 * one, zero, w2, 300.0 * one[:64], zero[:64], None, 1, f16=True)   # the E tile saturates too
         check(out)
     else:
-        stride = 1 if kind == "dw1" else 2
+        stride = 1 if kind in ("dw1", "dw1mm") else 2
         C_ = 256
         x = rng.normal(0, 1, (2, 8 * stride, 8 * stride, C_)).astype(np.float32)
         w = (rng.normal(0, 1, (C_, 3, 3)) / 3.0).astype(np.float32)
-        out, pooled, _ = dwconv_debug(f32_to_f16(x), w, np.full(C_, big, np.float32), np.zeros(C_, np.float32), stride=stride, in_f16=True, out_f16=True)
+        out, pooled, _ = dwconv_debug(f32_to_f16(x), w, np.full(C_, big, np.float32), np.zeros(C_, np.float32), stride=stride, in_f16=True, out_f16=True,
+                                      general=3 if kind == "dw1mm" else 0)
         check(out)
         assert np.isfinite(pooled).all()
