@@ -144,9 +144,16 @@ class ArWorkload:
         if tj and chunk == 1024 and self.way == 60 and self.precision in ("bf16", "f16"):
             with open(tj) as f:       # HBM bytes of one ar_proto launch (PMC passes, profiles/README.md)
                 traffic = json.load(f).get("ar_b1024", {}).get("ar_proto", {}).get("hbm_bytes_per_launch")
+        from bench_workloads import ar_proto_algorithmic_bytes
+        alg = ar_proto_algorithmic_bytes(chunk, self.way, self.L)
         return {"bound": "mfma", "kernel": "ar_proto_all_kernel", "achieved": round(achieved, 2), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+                "algorithmic_bytes": alg, "traffic_over_algorithmic": round(traffic / alg, 2) if traffic else None,
                 "avg_launch_ms": round(ms / max(launches, 1), 4), "launches": int(launches)}
+
+    def step_flops(self):
+        from bench_workloads import ar_flops_per_window
+        return ar_flops_per_window(self.way, self.L, self.J) * self.B
 
     def cpu_baseline(self, sample, iters=10):
         from oracle.ar_oracle import TRXOSOracle
@@ -287,6 +294,11 @@ def main():
         dist.all_gather_object(gathered, f"rank{rank}=cuda:{torch.cuda.current_device()}")
         devices = gathered
 
+    if rank == 0 and roof is not None and hasattr(W, "step_flops"):
+        # the WHOLE step against the dense 16-bit matrix peak: sum of the algorithmic FLOPs of every stage / the timed step
+        sf = W.step_flops() / (dt / args.steps) / 1e12
+        roof["step_achieved"] = round(sf, 2)
+        roof["step_frac"] = round(sf / MFMA_PEAK_TFLOPS["bf16"], 4)
     if rank == 0:
         units = W.units_per_step() * world * args.steps
         line = {

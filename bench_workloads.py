@@ -101,6 +101,47 @@ def igemm_macs_per_crop() -> int:
     return m + 64 * 640 * effnetv2.HEAD_OUT
 
 
+def igemm_algorithmic_bytes(batch: int) -> float:
+    """Algorithmic HBM bytes of the convolution launches of one forward pass over `batch` crops (what `roofline.traffic` is compared
+    with): per launch its input + output (+ residual) activations at 2 bytes per element and its weights once, with the expanded tensor
+    of the one-launch Fused-MBConv blocks and of the fused 8 x 8 fronts counted as what those launches really move (tools/layer_breakdown.py
+    walks the same table per layer; SE gates: 4 bytes per gated channel and sample)."""
+    B, t = float(batch), 0.0
+    for b in effnetv2.blocks():
+        o, i2 = b.out_hw * b.out_hw, b.in_hw * b.in_hw
+        r = 2 if b.residual else 1
+        if b.kind == "fused":
+            if b.cexp == b.cin:
+                t += 2.0 * (B * i2 * b.cin + B * o * b.cout * r + 9 * b.cin * b.cout)
+            elif b.cexp <= 256 and b.cout <= 128:
+                t += 2.0 * (B * i2 * b.cin + B * o * b.cout * r + 9 * b.cin * b.cexp + b.cexp * b.cout)
+            else:
+                t += 2.0 * (B * i2 * b.cin + B * o * b.cexp + 9 * b.cin * b.cexp)
+                t += 2.0 * (B * o * b.cexp + B * o * b.cout * r + b.cexp * b.cout)
+        else:
+            t += 2.0 * (B * i2 * (b.cin + b.cexp) + b.cin * b.cexp)
+            t += 2.0 * (B * o * b.cexp + B * o * b.cout * r + b.cexp * b.cout) + 4.0 * B * b.cexp
+    return t + 2.0 * (B * 64 * 640 + 640 * 1280) + 4.0 * B * 64 * 1280
+
+
+# algorithmic FLOPs per unit (SURVEY.md 8d): one frame through the pose stage (backbone 15.966 + head 0.024 GMAC), one window through the
+# match stage (MLP + tuple projections + attention + discriminator, support K / V amortised; per class 2 T^2 128 MACs of attention)
+POSE_FLOPS_PER_FRAME = 2.0 * 15.99e9
+
+
+def ar_flops_per_window(way: int, L: int = 30, J: int = 122) -> float:
+    T = L * (L - 1) // 2
+    return 2.0 * (L * (3 * J * 6 * J + 6 * J * 256) + 2 * T * 512 * 128 + way * 2 * T * T * 128 + T * 128 * L + T * L * 256 + 256 * 64 + 64)      # (query K / V projections as the reference writes them, SURVEY 8a)
+
+
+def ar_proto_algorithmic_bytes(windows: int, way: int, L: int = 30) -> float:
+    """Algorithmic HBM bytes of one all-classes attention launch: per window its K fragment image (16-bit), the column statistics of every
+    class (f32) and its V image (f32); the support set's K / V^T images once."""
+    T = L * (L - 1) // 2
+    Tp = (T + 31) // 32 * 32
+    return windows * (Tp * 128 * 2 + way * Tp * 4 + Tp * 128 * 4) + 2.0 * way * Tp * 128 * 2
+
+
 class _HpeBase:
     L, J = 30, 122
     precision = "f16"          # 16-bit storage type of the pose backbone (isb_hpe_cfg.precision 0 / 2) and of the AR attention operands
@@ -136,12 +177,18 @@ class _HpeBase:
             with open(tj) as f:     # (FETCH_SIZE / WRITE_SIZE, collected separately; see profiles/README.md)
                 t = json.load(f)["hpe_b256"]["conv_igemm"]["hbm_bytes_per_forward"]
             traffic = t * self.B / 256.0
+        alg = igemm_algorithmic_bytes(self.B)
         return {"bound": "mfma", "kernel": "conv_igemm / gemm1x1 family (all convolution launches of a forward pass)",
                 "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS_BF16, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_PEAK_TFLOPS_BF16, 4), "traffic": traffic,
                 "traffic_unit": "HBM bytes per forward pass over all convolution launches (PMC, measured at B=256)",
+                "algorithmic_bytes": alg, "traffic_over_algorithmic": round(traffic / alg, 3) if traffic else None,
                 "avg_launch_ms": round(ms / max(launches, 1), 5), "launches": int(launches),
                 "flops_per_step": flops / steps}
+
+    def step_flops(self):
+        """algorithmic FLOPs of one step of this workload (for roofline.step_frac)"""
+        return POSE_FLOPS_PER_FRAME * self.B
 
     def _cpu_hpe(self, n, iters):
         """The fp32 pose oracle on the first n frames of this rank's batch: (median seconds per frame, total seconds,
@@ -298,7 +345,32 @@ class PipelineWorkload(_HpeBase):
             self.out = (logits, is_true)
 
     def roofline(self, steps):
-        return self._hpe_roofline(steps)
+        r = self._hpe_roofline(steps)
+        # the match stage's dominant kernel in the same line: ar_proto_all over this step's windows (HIP events on its launch stream)
+        self.ar.profile(True)
+        for _ in range(steps):
+            self.step()
+        self.torch.cuda.synchronize()
+        ms, launches = self.ar.profile_read()
+        self.ar.profile(False)
+        T = self.L * (self.L - 1) // 2
+        fl = self.B * self.way * 2 * (2 * T * T * 128)
+        ach = fl / (ms / max(launches, 1) / 1e3) / 1e12 if ms > 0 else None
+        traffic = None
+        tj = latest_traffic_json()
+        if tj:
+            with open(tj) as f:
+                traffic = json.load(f).get("ar_b1024", {}).get("ar_proto", {}).get("hbm_bytes_per_launch")
+        r["ar_proto_all"] = {"achieved": round(ach, 2) if ach else None, "peak": MFMA_PEAK_TFLOPS_BF16, "unit": "TFLOP/s",
+                             "frac": round(ach / MFMA_PEAK_TFLOPS_BF16, 4) if ach else None,
+                             "avg_launch_ms": round(ms / max(launches, 1), 4), "launches": int(launches), "windows_per_launch": self.B,
+                             "traffic": traffic, "traffic_unit": "HBM bytes of ONE 1024-window launch, way 60 (PMC, `--workload ar`)",
+                             "algorithmic_bytes": ar_proto_algorithmic_bytes(1024, 60, self.L),
+                             "traffic_over_algorithmic": round(traffic / ar_proto_algorithmic_bytes(1024, 60, self.L), 2) if traffic else None}
+        return r
+
+    def step_flops(self):
+        return (POSE_FLOPS_PER_FRAME + ar_flops_per_window(self.way, self.L, self.J)) * self.B
 
     def _initial_ring(self, rank):
         hist = synth.skeleton_windows(self.N_CAM, self.L - 1, self.J, seed=555 + rank).reshape(self.N_CAM, self.L - 1, self.J, 3)

@@ -219,7 +219,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     guard_o = os.path.join(OBJ, "wsreg_guard.o")
     if jobs or force or not os.path.exists(LIB) or not os.path.exists(guard_o):
         # fail closed: link once without the guard's verdict, check the code the compiler actually produced,
-        # then compile the verdict in. isb_wsreg_verified() == 0 makes conv_kernels.hip fall back to the tile kernels.
+        # then compile the verdict in. isb_wsreg_verified() == 0 makes conv_dispatch.hip fall back to the tile kernels.
         def guard(ok: int, ok8: int):
             run([hipcc, "-O2", "-std=c++17", "-fPIC", f"-DISB_WSREG_VERIFIED={ok}", f"-DISB_MBF8_VERIFIED={ok8}", "-c",
                  os.path.join(CSRC, GUARD_SRC), "-o", guard_o])

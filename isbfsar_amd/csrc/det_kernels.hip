@@ -4,7 +4,7 @@
 //   concat         : channel concatenation of two NHWC tensors, the second optionally 2x nearest-upsampled (PANet routes)
 //   spp            : cat[maxpool13, maxpool9, maxpool5, x] (stride 1, same padding)
 //   yolo_decode    : the YOLO layer of the public implementation in inference mode (boxes + class confidences)
-// The 109 other convolutions run on the conv_igemm kernel family (conv_kernels.hip) with Mish / LeakyReLU epilogues.
+// The 109 other convolutions run on the conv_igemm kernel family (conv_dispatch.hip and the conv_*.hip families) with Mish / LeakyReLU epilogues.
 #include "isb_common.h"
 #include "kernels.h"
 

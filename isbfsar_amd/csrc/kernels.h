@@ -118,7 +118,7 @@ struct ArDiscTailArgs {
 };
 int launch_ar_disc_tail(const ArDiscTailArgs& a, hipStream_t st);
 
-// ---------------------------------------------------------------- conv_kernels.hip
+// ---------------------------------------------------------------- conv_dispatch.hip + conv_*.hip (the convolution family)
 struct ConvArgs {
     const uint16_t* in;     // bf16 [B,H,W,Cin]
     const uint16_t* w;      // bf16 [Cout, KH*KW*Cin] (BN scale folded)
@@ -138,7 +138,7 @@ struct ConvArgs {
     // the pose backbone under isb_hpe_cfg.precision 0. Implemented by the gemm1x1 variants the 8x8 stages
     // select (131, 132, 138; gated 141, 144, 146, 147, 149; weights-stationary 185 / 186) and the split-K reduction.
     int f16;
-    int variant;            // tile variant, 0 = choose by Cout (conv_kernels.hip)
+    int variant;            // tile variant, 0 = chosen per layer shape (conv_dispatch.hip)
     const uint16_t* zeros;  // >= 16 bytes of zeros (source of padding taps for the LDS-DMA kernels)
     // workgroup -> tile mapping (set by launch_conv_igemm): 0 = (blockIdx.x, blockIdx.y) = (M tile, N tile);
     // 1/2 = 1-D grid decoded per XCD (workgroup id % 8 = XCD): all N tiles of an M tile run back to back on
