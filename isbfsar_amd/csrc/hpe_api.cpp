@@ -384,7 +384,7 @@ int backbone_blocks(isb_hpe* h, Lane& L, hipStream_t st, int B, size_t i0, size_
                 d.pooled = L.pooled.as<float>();
                 // a block that has a fused front (mbfront8_kernel, batches >= mbf8_min_batch) runs the stand-alone kernel with ITS
                 // arithmetic below that size, so that a frame's bits do not depend on the batch it arrives in
-                d.general = (h->dwmm_on && h->mbf8_on && b.mbf_w1p.p) ? 3 : 0;
+                d.general = (h->dwmm_on && b.stride == 1 && b.in_hw == 8 && b.cin == 384 && b.f16_in == b.f16) ? 3 : 0;
                 if (B == 1) {   // one frame: FC1 of the squeeze-excite rides in the depthwise launch (batches: measured slower)
                     d.se_w1 = b.se_w1.as<float>(); d.se_part = L.semid.as<float>(); d.cse = b.cse;
                     se_parts = dw_slabs(d);
