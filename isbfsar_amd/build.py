@@ -44,7 +44,7 @@ SOURCES = [
     "rgb_api.cpp",
 ]
 # optional units appear as they are written
-for _extra in ("conv_mb8.hip",):
+for _extra in ("conv_mb8.hip", "conv_mb16.hip"):
     if os.path.exists(os.path.join(CSRC, _extra)):
         SOURCES.append(_extra)
 

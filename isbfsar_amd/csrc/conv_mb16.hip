@@ -1,0 +1,316 @@
+// The FRONT HALF of a stride-1 MBConv block on 16 x 16 maps in one launch (round 5): 1x1 expand + BN + SiLU -> depthwise 3x3 + BN +
+// SiLU -> D (NHWC, what the gated projection reads) + the squeeze-excite pool. The expanded tensor (176 MB per 224 -> 1344 block
+// at 256 frames, written once and read once by the two-launch path) never leaves the chip.
+//
+// mbfront8_kernel (conv_mb8.hip) did this for 8 x 8 maps, where a sample is one 64-row tile; it runs two waves per SIMD (96
+// stationary weight registers per wave at K = 384) and is bound by latency, not by its instruction count (EXPERIMENTS.md round 5).
+// Here K is 192 / 224 (48 / 56 weight registers), the depthwise taps run on the matrix pipe (dw_mm.h: no 80-register tap stage), and
+// a sample is walked in BANDS of two image rows so that a wave's expanded tile is a ring of six padded rows (6.9 KB) instead of a
+// whole padded map (20.7 KB): a workgroup of FOUR waves (one per SIMD) owns a 128-channel slice, THREE workgroups share a CU --
+// three waves per SIMD. (Six-wave workgroups of 192 channels, which divide 768 / 1152 / 1344 evenly, were the first form: the
+// hardware then places ONE workgroup per CU -- a second one would need four waves on some SIMD -- and the launch ran in two rounds.)
+//   step s = 0..7 of a sample: the band's 32 x Cin input tile (LDS-DMA, one buffer, requested behind the previous band's MFMAs)
+//                x the wave's 32 channels (weights stationary: K / 4 registers) -> bias, SiLU, one rounding -> ring rows 2s, 2s + 1;
+//   step s = 1..8: depthwise outputs of rows 2s - 2, 2s - 1 from ring rows 2s - 3 .. 2s (row -1 / 16: zeros; columns -1 / 16: the
+//                ring's zero columns): per 8-channel group three 16-byte fragment reads + three v_mfma_f32_16x16x32 (dw_mm.h),
+//                bias as the C operand, SiLU, one rounding, pooled sums, the two D rows through the two ring rows that just died.
+// Arithmetic and summation orders are those of the expand GEMM (k ascending in one accumulator) and of dwconv3x3_mm_kernel<16>
+// (tap MFMAs, lane sums over the bands in order, then the 32 (pixel pair, pixel) slots in order): bit-identical to that two-launch
+// path (tested), which is what batches below the threshold run.
+#include "conv_tiles.h"
+#include "dw_mm.h"
+
+namespace isb {
+
+namespace {
+
+template <int CIN>
+struct Mf16 {
+    static constexpr int NK16 = CIN / 16, NKT = CIN / 32;
+    static constexpr int NW = 4;                            // waves per workgroup (one per SIMD): a 128-channel slice
+    static constexpr int XBUF = NKT * 2048;                 // a band's input tile: [NKT][32 rows][64 B], swizzled (gemm1x1's A image)
+    static constexpr int ET_ROW = 18 * 64;                  // one padded row of a wave's ring: [18 pixels][32 ch x 2 B]
+    static constexpr int ET_BYTES = 6 * ET_ROW;             // six rows
+    static constexpr int ET_OFF = XBUF;
+    static constexpr int TBL_OFF = ET_OFF + NW * ET_BYTES;
+    static constexpr int TBL_BYTES = 1024;                  // per wave: bias [32] f32 | depthwise bias [32] f32 | taps [9][32] 16-bit
+    static constexpr int LDS = TBL_OFF + NW * TBL_BYTES;
+    static_assert(3 * LDS <= 160 * 1024, "three workgroups per CU");
+};
+
+}  // namespace
+
+template <int CIN, bool F16>
+__global__ __launch_bounds__(256, 3) void mbfront16_kernel(MbFront16Args p) {
+    using S = Mf16<CIN>;
+    constexpr int NK16 = S::NK16, NW = S::NW, ET_ROW = S::ET_ROW;
+    T16<F16>::enter();
+    unsigned char* const lds = conv_lds_dyn;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int CEXP = p.cexp, NSL = (CEXP + 127) / 128;
+    const int slice = blockIdx.x % NSL, q = blockIdx.x / NSL, Q = gridDim.x / NSL;
+    if (q >= p.B) return;
+    const int cb = min(slice * NW + wave, CEXP / 32 - 1), c0 = cb * 32;
+    const bool live = (slice * NW + wave) * 32 < CEXP;     // 1344 channels = 10 slices + 64: the last slice's upper waves only stage tiles and meet the barriers
+    unsigned char* const et = lds + S::ET_OFF + wave * S::ET_BYTES;
+    unsigned char* const tbl = lds + S::TBL_OFF + wave * S::TBL_BYTES;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)lds;
+
+    // band s of sample smp -> the X tile: piece pc = (k-tile pc >> 1, rows 16 (pc & 1) ..), 1 KiB each
+    auto dma_x = [&](int smp, int s) {
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(p.x) + ((size_t)smp * 256 + s * 32) * (CIN * 2);
+        for (int pc = wave; pc < S::NKT * 2; pc += NW) {
+            const int kt = pc >> 1, row = 16 * (pc & 1) + (lane >> 2);
+            const int logical = (lane & 3) ^ ((row >> 2) & 3);
+            dma16_s(src, (uint32_t)(row * CIN * 2 + kt * 64 + logical * 16), lds0 + (uint32_t)(pc * 1024));
+        }
+    };
+    dma_x(q, 0);
+    // the wave's weights, for the whole kernel (fragment-packed: one coalesced 1-KiB load per k16 step)
+    uint4 wreg[NK16];
+    {
+        const uint4* src = p.w1p + (size_t)cb * NK16 * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < NK16; ++s) wreg[s] = src[s * 64];
+    }
+    if (lane < 8) *reinterpret_cast<float4*>(tbl + lane * 16) = *reinterpret_cast<const float4*>(p.b1 + c0 + lane * 4);
+    else if (lane < 16) *reinterpret_cast<float4*>(tbl + lane * 16) = *reinterpret_cast<const float4*>(p.dwb + c0 + (lane - 8) * 4);
+    else if (lane < 16 + 36) {
+        const int t = (lane - 16) >> 2, c4 = (lane - 16) & 3;
+        *reinterpret_cast<uint4*>(tbl + 256 + t * 64 + c4 * 16) = *reinterpret_cast<const uint4*>(p.dww + (size_t)t * CEXP + c0 + c4 * 8);
+    }
+    for (int i = lane; i < S::ET_BYTES / 16; i += 64) *reinterpret_cast<uint4*>(et + i * 16) = make_uint4(0, 0, 0, 0);     // the ring, zero columns included
+    const int a_sw0 = swz(r, h), a_sw1 = swz(r, 2 + h);
+    uint32_t one_lo, one_hi;                                        // (1, 0) / (0, 1) pairs in the storage type (see dwconv3x3_pool_kernel)
+    if constexpr (F16) asm volatile("v_mov_b32 %0, 0x3c00\n\tv_lshlrev_b32 %1, 16, %0" : "=v"(one_lo), "=v"(one_hi));
+    else asm volatile("v_mov_b32 %0, 0x3f80\n\tv_lshlrev_b32 %1, 16, %0" : "=v"(one_lo), "=v"(one_hi));
+
+    // lane constants. The ring's 16-byte chunk slots are turned by f(y, x) = ((x >> 2) & 1) | ((y & 1) << 1) (y the image row, x the
+    // padded column): the sixteen lanes a ds_read_b128 serves together (pixels 2 n + j of two consecutive rows) then fall into
+    // sixteen different slots of the 256-byte bank row (four pixels of 64 bytes)
+    const DwmmLane wl(lane);
+    const int w_d = min(max(wl.d, 0), 2);
+    const int mn = lane & 15, mj = lane >> 4, ms = mj >> 1;        // pixel pair, input column / output rows, pixel of the pair
+    // E write: lane = pixel r of the band (row r >> 4, column r & 15), 16 channels 4 h + 8 qq + i
+    const int e_x = (r & 15) + 1;
+    const int e_lane = (r >> 4) * ET_ROW + e_x * 64 + h * 8;
+    const int e_f = ((e_x >> 2) & 1) | ((r >> 4) << 1);            // (the band's first row 2 s is even)
+    // B fragment: output row ry of the step's two, pixel pair pr; input row index k = ry + ky of the four rows 2s - 3 .. 2s
+    const int t_ry = mn >> 3, t_x = 2 * (mn & 7) + mj;             // padded column of the fragment's pixel
+    const int t_lane = t_x * 64;
+    int t_f[2];
+    t_f[0] = ((t_x >> 2) & 1) | (((t_ry + 1) & 1) << 1);           // ky even: image row 2s - 3 + ry + ky is odd iff ry + ky is even
+    t_f[1] = ((t_x >> 2) & 1) | ((t_ry & 1) << 1);                 // ky odd
+    // D staging: the step's two output rows leave through the interiors of the two ring rows its taps read LAST (rows 2s - 3 and
+    // 2s - 2 are dead once the step's MFMAs are done): the lane's output pixel (ry, 2 pr + ms), its 4 channels of group g
+    const int d_x = 2 * (mn & 7) + ms;
+    const int d_lane = (d_x + 1) * 64 + (mj & 1) * 8;
+    const int d_f = (d_x >> 1) & 3;
+
+    uint64_t stp[7] = {0, 0, 0, 0, 0, 0, 0}, st_t0 = 0, st_n = 0;       // tuning probe (MbFront16Args.stamps)
+    uint64_t st_r0 = 0;
+    if (p.stamps) { st_t0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
+    bool first = true;
+    for (int smp = q; smp < p.B; smp += Q) {
+        // Three workgroups share a CU and a SIMD's issue port goes to the OLDEST wave first: left alone, a CU's first workgroup runs at
+        // full speed (4 samples in 71 us), the third crawls (3 samples in 96 us) and the launch ends with CUs a third full (census of
+        // the workgroups' clocks, EXPERIMENTS.md round 5). Priority outranks age, so a workgroup steps down as it gets ahead: the one
+        // with the most samples still to do is served first and the three arrive together (first form, by samples done: 122.0 -> 114.7 us).
+        {
+            const int left = (p.B - 1 - smp) / Q;                  // samples this workgroup still has to do after this one
+            if (left >= 3) __builtin_amdgcn_s_setprio(3);
+            else if (left == 2) __builtin_amdgcn_s_setprio(2);
+            else if (left == 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+        float psum[4][4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) psum[g][i] = 0.f;
+        // image row -1: zeros (slot 5), its interior was the previous sample's
+        *reinterpret_cast<uint4*>(et + 5 * ET_ROW + 64 + lane * 16) = make_uint4(0, 0, 0, 0);
+#pragma unroll 1
+        for (int s = 0; s <= 8; ++s) {
+            uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
+            if (p.stamps) { t0 = __builtin_amdgcn_s_memtime(); ++st_n; }
+            t1 = t2 = t3 = t4 = t0;
+            if (s < 8) {
+                // ---- the band's tile landed (requested behind the previous band's MFMAs). Younger vector-memory operations of this
+                // wave may keep flying (vmcnt retires in order): the two D-row stores of the previous band's depthwise step, and at a
+                // sample's first band the previous sample's last four D-row stores and its pooled means
+                if (s >= 2 && live) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");        // (a wave without channels has no stores: its tile pieces are its youngest operations)
+                else if (s == 0 && !first && live) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (p.stamps) t1 = __builtin_amdgcn_s_memtime();
+                // ---- expand: 32 pixels x the wave's 32 channels; fragment reads two k16 steps ahead (second register set)
+                f32x16 acc;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+                if (live) {
+                    uint4 fa[2][2];
+                    auto rd = [&](int pr2, uint4 (&f)[2]) __attribute__((always_inline)) {
+                        f[0] = *reinterpret_cast<const uint4*>(lds + pr2 * 2048 + a_sw0);
+                        f[1] = *reinterpret_cast<const uint4*>(lds + pr2 * 2048 + a_sw1);
+                    };
+                    rd(0, fa[0]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int pr2 = 0; pr2 < NK16 / 2; ++pr2) {
+                        if (pr2 + 1 < NK16 / 2) rd(pr2 + 1, fa[(pr2 + 1) & 1]);
+                        acc = T16<F16>::mfma32(wreg[2 * pr2], fa[pr2 & 1][0], acc);
+                        acc = T16<F16>::mfma32(wreg[2 * pr2 + 1], fa[pr2 & 1][1], acc);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if (p.stamps) t2 = __builtin_amdgcn_s_memtime();
+                __builtin_amdgcn_s_barrier();                       // everybody has read the tile: the next one may land
+                if (p.stamps) t3 = __builtin_amdgcn_s_memtime();
+                if (s + 1 < 8) dma_x(smp, s + 1);
+                else if (smp + Q < p.B) dma_x(smp + Q, 0);
+                // ---- E = T16(silu(acc + bias)) -> ring rows 2s, 2s + 1 (slots (2s) % 6, + 1)
+                unsigned char* const cell = et + ((2 * s) % 6) * ET_ROW + e_lane;
+                if (live)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const float4 bs = *reinterpret_cast<const float4*>(tbl + (8 * qq + 4 * h) * 4);
+                    const float v0 = silu_fast(acc[4 * qq] + bs.x), v1 = silu_fast(acc[4 * qq + 1] + bs.y);
+                    const float v2 = silu_fast(acc[4 * qq + 2] + bs.z), v3 = silu_fast(acc[4 * qq + 3] + bs.w);
+                    uint2 pk;
+                    pk.x = T16<F16>::pack2(v0, v1);
+                    pk.y = T16<F16>::pack2(v2, v3);
+                    *reinterpret_cast<uint2*>(cell + ((qq ^ e_f) << 4)) = pk;
+                }
+            } else {
+                // image row 16: zeros (slot 4)
+                *reinterpret_cast<uint4*>(et + 4 * ET_ROW + 64 + lane * 16) = make_uint4(0, 0, 0, 0);
+            }
+            if (p.stamps) { t4 = __builtin_amdgcn_s_memtime(); stp[0] += t1 - t0; stp[1] += t2 - t1; stp[2] += t3 - t2; stp[3] += t4 - t3; }
+            if (s == 0 || !live) continue;
+            // ---- depthwise 3x3 + bias on the matrix pipe: output rows 2s - 2, 2s - 1 from ring rows 2s - 3 .. 2s
+            int rowoff[3];                                          // the lane's three input rows: slot (2s + 3 + ry + ky) % 6
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int s_a = ((2 * s + 3 + ky) % 6) * ET_ROW, s_b = ((2 * s + 4 + ky) % 6) * ET_ROW;       // (wave-uniform)
+                rowoff[ky] = (t_ry ? s_b : s_a) + t_lane;
+            }
+            f32x4 a4[4];
+            {
+                uint4 bf[2][3];
+                auto rdb = [&](int g, uint4 (&f)[3]) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) f[ky] = *reinterpret_cast<const uint4*>(et + rowoff[ky] + ((g ^ t_f[ky & 1]) << 4));
+                };
+                rdb(0, bf[0]);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint4 af[3];
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+                        af[ky] = wl.place((uint32_t)*reinterpret_cast<const uint16_t*>(tbl + 256 + (ky * 3 + w_d) * 64 + (g * 8 + wl.c) * 2));
+                    const float4 db = *reinterpret_cast<const float4*>(tbl + 128 + (g * 8 + 4 * (mj & 1)) * 4);
+                    if (g + 1 < 4) rdb(g + 1, bf[(g + 1) & 1]);
+                    f32x4 c4 = f32x4{db.x, db.y, db.z, db.w};
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) c4 = mfma16<F16>(af[ky], bf[g & 1][ky], c4);
+                    a4[g] = c4;
+                }
+            }
+            if (p.stamps) { t5 = __builtin_amdgcn_s_memtime(); stp[4] += t5 - t4; }
+            // SiLU, one rounding, pooled sums (the pool sees the stored activations), the two D rows through the dead ring rows
+            const int d_r0 = ((2 * s + 3) % 6) * ET_ROW, d_r1 = ((2 * s + 4) % 6) * ET_ROW;       // slots of image rows 2s - 3, 2s - 2
+            const int d_row = t_ry ? d_r1 : d_r0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const uint32_t pk0 = T16<F16>::pack2(silu_fast(a4[g][0]), silu_fast(a4[g][1]));
+                const uint32_t pk1 = T16<F16>::pack2(silu_fast(a4[g][2]), silu_fast(a4[g][3]));
+                psum[g][0] = T16<F16>::dot2(pk0, one_lo, psum[g][0]);
+                psum[g][1] = T16<F16>::dot2(pk0, one_hi, psum[g][1]);
+                psum[g][2] = T16<F16>::dot2(pk1, one_lo, psum[g][2]);
+                psum[g][3] = T16<F16>::dot2(pk1, one_hi, psum[g][3]);
+                *reinterpret_cast<uint2*>(et + d_row + d_lane + ((g ^ d_f) << 4)) = make_uint2(pk0, pk1);
+            }
+            {
+                uint16_t* const drow = p.d + ((size_t)smp * 256 + (2 * s - 2) * 16) * CEXP + c0 + (lane & 3) * 8;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int px = (lane >> 2) + 16 * i, xx = lane >> 2;
+                    const uint4 v = *reinterpret_cast<const uint4*>(et + (i ? d_r1 : d_r0) + (xx + 1) * 64 + (((lane & 3) ^ ((xx >> 1) & 3)) << 4));
+                    *reinterpret_cast<uint4*>(drow + (size_t)px * CEXP) = v;
+                }
+            }
+            if (p.stamps) stp[5] += __builtin_amdgcn_s_memtime() - t5;
+        }
+        uint64_t tp = 0;
+        if (p.stamps) tp = __builtin_amdgcn_s_memtime();
+        // ---- pooled means: the lanes' sums over the eight bands -> the 32 (pixel pair, pixel) slots in order (dwconv3x3_mm_kernel's
+        // walk), / 256. Scratch: 4 KiB over the interiors of ring rows 0 .. 3 (every interior pixel is rewritten or zeroed before the
+        // next sample reads it; the zero columns are not touched)
+        auto red_at = [&](int fl) __attribute__((always_inline)) {        // float index -> address
+            const int o = fl * 4;
+            return reinterpret_cast<float*>(et + (o >> 10) * ET_ROW + 64 + (o & 1023));
+        };
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(red_at((2 * mn + ms) * 32 + g * 8 + 4 * (mj & 1))) = make_float4(psum[g][0], psum[g][1], psum[g][2], psum[g][3]);
+        if (lane < 32 && live) {
+            float rv[32];
+#pragma unroll
+            for (int s2 = 0; s2 < 32; ++s2) rv[s2] = *red_at(s2 * 32 + lane);
+            float t = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < 32; ++s2) t += rv[s2];
+            p.pooled[(size_t)smp * CEXP + c0 + lane] = t / 256.0f;
+        }
+        first = false;
+        if (p.stamps) stp[6] += __builtin_amdgcn_s_memtime() - tp;
+    }
+    if (p.stamps && (p.exp & 0x10000) && tid == 0 && blockIdx.x < 1000) {       // census: every workgroup's loop start / end on the 100-MHz clock
+        p.stamps[(size_t)blockIdx.x * 2] = st_r0;
+        p.stamps[(size_t)blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime();
+    } else if (p.stamps && blockIdx.x < 32 && lane == 0) {
+        uint64_t* o = p.stamps + ((size_t)blockIdx.x * 6 + wave) * 10;       // (slots for six waves: four in use)
+        o[0] = __builtin_amdgcn_s_memtime() - st_t0; o[1] = st_n;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) o[2 + i] = stp[i];
+        o[9] = __builtin_amdgcn_s_memrealtime() - st_r0;          // 100 MHz ticks of the same interval as o[0]: the clock the chip held
+    }
+}
+
+int launch_mbfront16(const MbFront16Args& a, hipStream_t st) {
+    if (a.B < 1 || !a.x || !a.w1p || !a.b1 || !a.dww || !a.dwb || !a.d || !a.pooled || (a.cin != 192 && a.cin != 224) || a.cexp % 32 != 0 ||
+        a.cexp < 128) {
+        set_error("mbfront16: bad arguments (B=%d cin=%d cexp=%d; built for 192 / 224 inputs)", a.B, a.cin, a.cexp);
+        return ISB_ERR_INVALID;
+    }
+    const int nsl = cdiv(a.cexp, 128);
+    const int Q = std::max(1, std::min(a.B, 768 / nsl));             // sample sequences: three workgroups per CU
+    MbFront16Args aa = a;
+    aa.exp = exp_flags();
+#define ISB_MBF16(CIN_, F16_)                                                                                                \
+    do {                                                                                                                     \
+        static DevOnce attr_set;                                                                                             \
+        if (attr_set.need()) {                                                                                               \
+            ISB_HIP(hipFuncSetAttribute((const void*)mbfront16_kernel<CIN_, F16_>, hipFuncAttributeMaxDynamicSharedMemorySize, Mf16<CIN_>::LDS)); \
+            attr_set.mark();                                                                                                 \
+            if (getenv("ISB_OCC")) {                                                                                         \
+                int nb = -1;                                                                                                 \
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)mbfront16_kernel<CIN_, F16_>, 256, Mf16<CIN_>::LDS); \
+                fprintf(stderr, "[isb] mbfront16<%d>: %d workgroups per CU by the occupancy API (LDS %d B)\n", CIN_, nb, Mf16<CIN_>::LDS);  \
+            }                                                                                                                \
+        }                                                                                                                    \
+        hipLaunchKernelGGL((mbfront16_kernel<CIN_, F16_>), dim3(nsl * Q), dim3(256), Mf16<CIN_>::LDS, st, aa);                \
+    } while (0)
+    if (a.cin == 224) { if (a.f16) ISB_MBF16(224, true); else ISB_MBF16(224, false); }
+    else { if (a.f16) ISB_MBF16(192, true); else ISB_MBF16(192, false); }
+#undef ISB_MBF16
+    ISB_LAUNCHED("mbfront16", st);
+    return ISB_OK;
+}
+
+}  // namespace isb

@@ -555,6 +555,16 @@ __global__ __launch_bounds__(256, 2) void mbfront8_kernel(MbFront8Args p) {
     if (p.stamps) st_t0 = __builtin_amdgcn_s_memtime();
     int it = 0;
     for (int smp = q; smp < p.B; smp += Q, ++it) {
+        // two workgroups share a CU and the OLDER wave is served first: the workgroup with more samples still to do outranks the
+        // other, so that both arrive together (conv_mb16.hip has the census that showed the effect)
+        {
+            const int left = (p.B - 1 - smp) / Q, total = (p.B - 1 - q) / Q + 1;       // samples still to do after this one, of `total`
+            const int bucket = min(3, (4 * left + total - 1) / total);
+            if (bucket == 3) __builtin_amdgcn_s_setprio(3);
+            else if (bucket == 2) __builtin_amdgcn_s_setprio(2);
+            else if (bucket == 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
         uint64_t ta = 0, tb = 0;
         if (p.stamps) ta = __builtin_amdgcn_s_memtime();
         // the sample's tiles landed: requested after the previous sample's MFMAs, ahead of that sample's five stores (four D rows, the

@@ -30,6 +30,7 @@ struct BlockW {
     int cin = 0, cout = 0, cexp = 0, stride = 1, cse = 0, in_hw = 0, out_hw = 0;
     ConvW expand, project;
     DevBuf dw_w16, dw_b, se_w1, se_b1, se_w2, se_b2;   // dw_w16: the depthwise taps in the stage's 16-bit type
+    DevBuf mbf16_w1p;                 // stride-1 MBConv blocks with 192 / 224 inputs on 16 x 16 maps: the expand weights in fragment order (mbfront16_kernel)
     DevBuf fmb_w2p;                   // Fused-MBConv blocks: the projection weights in the register-E kernel's fragment order (launch_fmb_pack_w2)
     DevBuf mbf_w1p;                   // stride-1 MBConv blocks with 384 inputs on 8 x 8 maps: the expand weights in fragment order (mbfront8_kernel)
     DevBuf mb_w1p, mb_w2p, mb_se1p;   // stride-1 blocks of the 8 x 8 stages: the weights in mb8_chain_kernel's streaming layouts (conv_mb8.hip)
@@ -78,6 +79,10 @@ struct isb_hpe {
     bool mb8_on = false;
     // the FRONT half (expand + SiLU + depthwise + SiLU + pool) of the stride-1 MBConv blocks with 384 input channels on 8 x 8 maps in one
     // launch on stationary weights (conv_mb8.hip mbfront8_kernel; bit-identical to the two launches): batches >= mbf8_min_batch
+    bool dwmm16 = true;           // small batches of the 16 x 16 blocks on the matrix-pipe depthwise kernel (the fused front's arithmetic); follows
+                                  // ISB_MBF16 unless ISB_DWMM16 says otherwise (the bit-identity test's reference: ISB_MBF16=0 ISB_DWMM16=1)
+    bool stamp16 = false;         // ISB_STAMP16=1: isb_debug_hpe_mb8_stamps arms the 16 x 16 front's clocks instead of the 8 x 8 front's
+    bool mbf16_on = true;         // ISB_MBF16=0: expand GEMM + depthwise kernel on the 16 x 16 maps (the bit-identity test's reference)
     bool fmb_rege = true;         // ISB_FMB_REGE=0: Fused-MBConv blocks with the E tile in LDS (the round-2 form; A/B switch)
     bool dwmm_on = true;          // ISB_DWMM=0: (tests of the probe-only chain kernel) small batches of fused-front blocks on the v_dot2 depthwise kernel
     bool mbf8_on = true;          // ISB_MBF8=0: expand GEMM + depthwise kernel (the bit-identity test's reference)
@@ -361,7 +366,7 @@ int backbone_blocks(isb_hpe* h, Lane& L, hipStream_t st, int B, size_t i0, size_
                 a.x = (const uint16_t*)X; a.w1p = (const uint4*)b.mbf_w1p.p; a.b1 = b.expand.bias.as<float>();
                 a.dww = b.dw_w16.as<uint16_t>(); a.dwb = b.dw_b.as<float>(); a.d = L.bufD.as<uint16_t>(); a.pooled = L.pooled.as<float>();
                 a.B = B; a.cin = b.cin; a.f16 = b.f16 ? 1 : 0;
-                a.stamps = h->mb8_stamps.p ? h->mb8_stamps.as<uint64_t>() : nullptr;
+                a.stamps = (h->mb8_stamps.p && !h->stamp16) ? h->mb8_stamps.as<uint64_t>() : nullptr;
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (h->prof) {
                     ISB_HIP(hipEventCreate(&e0));
@@ -369,6 +374,24 @@ int backbone_blocks(isb_hpe* h, Lane& L, hipStream_t st, int B, size_t i0, size_
                     ISB_HIP(hipEventRecord(e0, st));
                 }
                 ISB_TRY(launch_mbfront8(a, st));
+                if (h->prof) {
+                    ISB_HIP(hipEventRecord(e1, st));
+                    h->prof_ev.emplace_back(e0, e1);
+                    h->prof_launches += 1;
+                }
+            } else if (h->mbf16_on && b.mbf16_w1p.p && B >= h->mbf8_min_batch) {
+                MbFront16Args a{};
+                a.x = (const uint16_t*)X; a.w1p = (const uint4*)b.mbf16_w1p.p; a.b1 = b.expand.bias.as<float>();
+                a.dww = b.dw_w16.as<uint16_t>(); a.dwb = b.dw_b.as<float>(); a.d = L.bufD.as<uint16_t>(); a.pooled = L.pooled.as<float>();
+                a.B = B; a.cin = b.cin; a.cexp = b.cexp; a.f16 = b.f16 ? 1 : 0;
+                a.stamps = (h->mb8_stamps.p && h->stamp16 && b.cin == 224) ? h->mb8_stamps.as<uint64_t>() : nullptr;
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (h->prof) {
+                    ISB_HIP(hipEventCreate(&e0));
+                    ISB_HIP(hipEventCreate(&e1));
+                    ISB_HIP(hipEventRecord(e0, st));
+                }
+                ISB_TRY(launch_mbfront16(a, st));
                 if (h->prof) {
                     ISB_HIP(hipEventRecord(e1, st));
                     h->prof_ev.emplace_back(e0, e1);
@@ -384,7 +407,8 @@ int backbone_blocks(isb_hpe* h, Lane& L, hipStream_t st, int B, size_t i0, size_
                 d.pooled = L.pooled.as<float>();
                 // a block that has a fused front (mbfront8_kernel, batches >= mbf8_min_batch) runs the stand-alone kernel with ITS
                 // arithmetic below that size, so that a frame's bits do not depend on the batch it arrives in
-                d.general = (h->dwmm_on && b.stride == 1 && b.in_hw == 8 && b.cin == 384 && b.f16_in == b.f16) ? 3 : 0;
+                d.general = (h->dwmm_on && b.stride == 1 && b.f16_in == b.f16 &&
+                             ((b.in_hw == 8 && b.cin == 384) || (h->dwmm16 && b.in_hw == 16 && (b.cin == 192 || b.cin == 224)))) ? 3 : 0;
                 if (B == 1) {   // one frame: FC1 of the squeeze-excite rides in the depthwise launch (batches: measured slower)
                     d.se_w1 = b.se_w1.as<float>(); d.se_part = L.semid.as<float>(); d.cse = b.cse;
                     se_parts = dw_slabs(d);
@@ -490,6 +514,10 @@ extern "C" int isb_hpe_create(const isb_hpe_cfg* cfg, isb_hpe** out) {
 #endif
     if (const char* e = getenv("ISB_DWMM")) h->dwmm_on = atoi(e) != 0;
     if (const char* e = getenv("ISB_FMB_REGE")) h->fmb_rege = atoi(e) != 0;
+    if (const char* e = getenv("ISB_MBF16")) h->mbf16_on = atoi(e) != 0;
+    if (const char* e = getenv("ISB_STAMP16")) h->stamp16 = atoi(e) != 0;
+    h->dwmm16 = h->mbf16_on;
+    if (const char* e = getenv("ISB_DWMM16")) h->dwmm16 = atoi(e) != 0;
     if (const char* e = getenv("ISB_MBF8")) h->mbf8_on = atoi(e) != 0;
     if (!isb::mbf8_verified()) h->mbf8_on = false;      // fail closed: the build could not confirm the kernel's counted wait (wsreg_guard.cpp)
     if (const char* e = getenv("ISB_MB8_MIN_BATCH")) h->mb8_min_batch = std::max(1, atoi(e));
@@ -616,6 +644,11 @@ extern "C" int isb_hpe_load_weights(isb_hpe* h, const void* blob, size_t nbytes)
                             wt16[(size_t)t * b->cexp + c] = hb;
                         }
                     }
+                if (h->mbf16_on && b->stride == 1 && b->in_hw == 16 && (b->cin == 192 || b->cin == 224) && b->f16_in == b->f16) {
+                    ISB_TRY(b->mbf16_w1p.alloc((size_t)b->cexp * b->cin * 2));
+                    ISB_TRY(launch_mb8_pack_frag(b->expand.w16.as<uint16_t>(), b->mbf16_w1p.p, b->cexp, b->cin, 1, st));
+                    ISB_HIP(hipStreamSynchronize(st));
+                }
                 if (h->mbf8_on && b->stride == 1 && b->in_hw == 8 && b->cin == 384 && b->f16_in == b->f16) {
                     ISB_TRY(b->mbf_w1p.alloc((size_t)b->cexp * b->cin * 2));
                     ISB_TRY(launch_mb8_pack_frag(b->expand.w16.as<uint16_t>(), b->mbf_w1p.p, b->cexp, b->cin, 1, st));

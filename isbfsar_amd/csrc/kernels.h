@@ -224,6 +224,21 @@ struct MbFront8Args {
 };
 int launch_mbfront8(const MbFront8Args& a, hipStream_t st);
 int mbf8_verified();        // wsreg_guard.cpp: 1 only if the build confirmed mbfront8_kernel's counted wait in the disassembly
+// conv_mb16.hip: the same front half on 16 x 16 maps (192 / 224 inputs; expanded channels in slices of 192), in bands of two image rows
+struct MbFront16Args {
+    const uint16_t* x;      // [B][256][cin] 16-bit block input (NHWC)
+    const uint4* w1p;       // expand weights, fragment-packed (launch_mb8_pack_frag, G = 1)
+    const float* b1;        // [cexp]
+    const uint16_t* dww;    // depthwise taps [9][cexp] 16-bit
+    const float* dwb;       // [cexp]
+    uint16_t* d;            // out [B][256][cexp] 16-bit
+    float* pooled;          // out [B][cexp] f32 spatial means
+    int B, cin, cexp, f16;
+    int exp;                // open experiments (isb::exp_flags(), set by the launcher): bit 16 = the stamps are a census of every workgroup's start / end
+    uint64_t* stamps;       // tuning probe or null: [32 workgroups][6 waves][10] = loop cycles, band steps, then per-phase sums: tile wait + barrier,
+                            // expand MFMAs, second barrier, E epilogue, depthwise MFMAs, SiLU + D rows, pooled means
+};
+int launch_mbfront16(const MbFront16Args& a, hipStream_t st);
 int launch_mb8_pack_frag(const uint16_t* w, void* dst, int N, int K, int G, hipStream_t st);
 int launch_mb8_pack_se1(const float* w1, float* dst, int cse, int C, hipStream_t st);
 int mb8_proj_group(int cout);

@@ -900,3 +900,37 @@ def test_fused_front_of_the_8x8_blocks_is_bit_identical(bbone_state, assets, mon
     assert np.isfinite(res["1"][0]).all() and float(np.abs(res["1"][0]).max()) > 0
     for a, b in zip(res["1"], res["0"]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("precision", ["f16", "bf16"])
+def test_fused_front_of_the_16x16_blocks_is_bit_identical(bbone_state, assets, monkeypatch, precision):
+    """conv_mb16.hip mbfront16_kernel (round 5): expand 1x1 + SiLU + depthwise 3x3 + SiLU + squeeze-excite pool of the 28 stride-1
+    MBConv blocks on 16 x 16 maps in ONE launch, a sample walked in bands of two image rows (ring of six expanded rows per wave,
+    depthwise taps on the matrix pipe): features and poses are the bits of the expand-GEMM + dwconv3x3_mm_kernel path (ISB_MBF16=0/1,
+    read when the engine is created). B = 45: above the batch threshold, more samples than sample sequences share out evenly."""
+    from isbfsar_amd.hpe_engine import HpeEngine
+    from oracle import hpe_oracle as ho
+    W, st = assets
+    idx = st["smpl+head_30"]["indices"]
+    B = 45
+    fr, bb = synth.frames(B, seed=5), synth.bboxes(B, seed=5)
+    crops = np.stack([ho.warp(fr[b], ho.crop_params(bb[b], _K())[2][0]) for b in range(3)])
+    crops = np.concatenate([crops] * 15)[:B]
+    res = {}
+    monkeypatch.setenv("ISB_DWMM16", "1")              # the reference path keeps the fused front's depthwise arithmetic
+    for flag in ("1", "0"):
+        monkeypatch.setenv("ISB_MBF16", flag)
+        e = HpeEngine(device=0, max_batch=64, precision=precision)
+        try:
+            e.set_joint_map(W, idx)
+            e.load_weights(bbone_state)
+            feat, logits = e.backbone(crops)
+            joints, valid = e.forward(fr, bb)
+            again, _ = e.forward(fr, bb)
+        finally:
+            e.close()
+        assert np.array_equal(joints, again)
+        res[flag] = (feat, logits, joints, valid)
+    assert np.isfinite(res["1"][0]).all() and float(np.abs(res["1"][0]).max()) > 0
+    for a, b in zip(res["1"], res["0"]):
+        assert np.array_equal(a, b)
