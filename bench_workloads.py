@@ -142,6 +142,11 @@ def ar_proto_algorithmic_bytes(windows: int, way: int, L: int = 30) -> float:
     return windows * (Tp * 128 * 2 + way * Tp * 4 + Tp * 128 * 4) + 2.0 * way * Tp * 128 * 2
 
 
+def dw_macs_per_crop() -> int:
+    """MACs of the 57 depthwise 3x3 convolutions per crop"""
+    return sum(9 * b.cexp * b.out_hw * b.out_hw for b in effnetv2.blocks() if b.kind != "fused")
+
+
 class _HpeBase:
     L, J = 30, 122
     precision = "f16"          # 16-bit storage type of the pose backbone (isb_hpe_cfg.precision 0 / 2) and of the AR attention operands
@@ -168,6 +173,7 @@ class _HpeBase:
             self.step()
         self.torch.cuda.synchronize()
         ms, launches = self.hpe.profile_read()
+        ms_dw, launches_dw = self.hpe.profile_read_dw()
         self.hpe.profile(False)
         flops = 2.0 * igemm_macs_per_crop() * self.B * steps
         achieved = flops / (ms / 1e3) / 1e12
@@ -184,7 +190,15 @@ class _HpeBase:
                 "traffic_unit": "HBM bytes per forward pass over all convolution launches (PMC, measured at B=256)",
                 "algorithmic_bytes": alg, "traffic_over_algorithmic": round(traffic / alg, 3) if traffic else None,
                 "avg_launch_ms": round(ms / max(launches, 1), 5), "launches": int(launches),
-                "flops_per_step": flops / steps}
+                "flops_per_step": flops / steps,
+                # the fused MBConv fronts (mbfront8 / mbfront16) are family launches that carry their blocks' depthwise + SiLU + pool work:
+                # every fusion of that kind moves time INTO the family and takes a depthwise launch away. Comparable across rounds:
+                "with_depthwise": {
+                    "what": "all convolution AND depthwise launches of a forward pass: their algorithmic FLOPs / their summed HIP-event time",
+                    "achieved": round((flops + 2.0 * dw_macs_per_crop() * self.B * steps) / ((ms + ms_dw) / 1e3) / 1e12, 2),
+                    "frac": round((flops + 2.0 * dw_macs_per_crop() * self.B * steps) / ((ms + ms_dw) / 1e3) / 1e12 / MFMA_PEAK_TFLOPS_BF16, 4),
+                    "family_ms_per_pass": round(ms / steps, 3), "depthwise_ms_per_pass": round(ms_dw / steps, 3),
+                    "depthwise_launches_per_pass": int(launches_dw // max(steps, 1))}}
 
     def step_flops(self):
         """algorithmic FLOPs of one step of this workload (for roofline.step_frac)"""

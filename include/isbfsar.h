@@ -272,6 +272,9 @@ int isb_hpe_post_host(isb_hpe* h, const float* h_logits, const int32_t* h_bbox, 
  * HIP events on the launch stream; used by bench.py's roofline object */
 int isb_hpe_profile(isb_hpe* h, int32_t enable);
 int isb_hpe_profile_read(isb_hpe* h, double* ms_total, int64_t* launches);
+/* the same for the STAND-ALONE depthwise launches of the profiled passes (the fused MBConv fronts carry their depthwise work inside
+ * the family's launches): family + depthwise time is what stays comparable when a fusion moves work from one list to the other */
+int isb_hpe_profile_read_dw(isb_hpe* h, double* ms_total, int64_t* launches);
 
 /* test / tuning hook: ONE backbone convolution (the conv_igemm kernel family) on host tensors.
  *   h_x bf16 [B,H,W,Cin], h_w f32 [Cout,k,k,Cin], folded BN h_scale/h_shift [Cout], optional residual

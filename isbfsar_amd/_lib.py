@@ -78,6 +78,7 @@ SIGNATURES = {
     "isb_hpe_post_host": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P]),
     "isb_hpe_profile": (C.c_int, [_P, C.c_int32]),
     "isb_hpe_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "isb_hpe_profile_read_dw": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "isb_pose_windows": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "isb_pose_distance": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
     "isb_hpe_select_person": (C.c_int, [_P, _P, _P, C.c_int32, C.c_float, _P, _P, _P]),

@@ -156,6 +156,9 @@ struct isb_hpe {
     // profiling of conv_igemm launches
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev_dw;      // the stand-alone depthwise launches (isb_hpe_profile_read_dw)
+    double prof_dw_ms = 0.0;
+    int64_t prof_dw_launches = 0;
     double prof_ms = 0.0;
     int64_t prof_launches = 0;
 };
@@ -413,7 +416,18 @@ int backbone_blocks(isb_hpe* h, Lane& L, hipStream_t st, int B, size_t i0, size_
                     d.se_w1 = b.se_w1.as<float>(); d.se_part = L.semid.as<float>(); d.cse = b.cse;
                     se_parts = dw_slabs(d);
                 }
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (h->prof) {
+                    ISB_HIP(hipEventCreate(&e0));
+                    ISB_HIP(hipEventCreate(&e1));
+                    ISB_HIP(hipEventRecord(e0, st));
+                }
                 ISB_TRY(launch_dwconv3x3(d, st));
+                if (h->prof) {
+                    ISB_HIP(hipEventRecord(e1, st));
+                    h->prof_ev_dw.emplace_back(e0, e1);
+                    h->prof_dw_launches += 1;
+                }
             }
             SeFcArgs se{};
             se.nparts = se_parts;
@@ -1151,6 +1165,27 @@ extern "C" int isb_hpe_profile_read(isb_hpe* h, double* ms_total, int64_t* launc
     *launches = h->prof_launches;
     h->prof_ms = 0.0;
     h->prof_launches = 0;
+    return ISB_OK;
+    });
+}
+
+extern "C" int isb_hpe_profile_read_dw(isb_hpe* h, double* ms_total, int64_t* launches) {
+    return isb::guard([&]() -> int {
+    ISB_REQUIRE(h && ms_total && launches, ISB_ERR_INVALID, "null argument");
+    ISB_HIP(hipSetDevice(h->cfg.device));
+    for (auto& e : h->prof_ev_dw) {
+        ISB_HIP(hipEventSynchronize(e.second));
+        float ms = 0.f;
+        ISB_HIP(hipEventElapsedTime(&ms, e.first, e.second));
+        h->prof_dw_ms += ms;
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    h->prof_ev_dw.clear();
+    *ms_total = h->prof_dw_ms;
+    *launches = h->prof_dw_launches;
+    h->prof_dw_ms = 0.0;
+    h->prof_dw_launches = 0;
     return ISB_OK;
     });
 }

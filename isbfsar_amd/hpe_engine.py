@@ -209,6 +209,13 @@ class HpeEngine:
         _lib.check(_lib.lib().isb_hpe_profile_read(self._h, C.byref(ms), C.byref(n)), "isb_hpe_profile_read")
         return ms.value, n.value
 
+    def profile_read_dw(self):
+        """(ms, launches) of the stand-alone depthwise launches of the profiled passes"""
+        ms = C.c_double()
+        n = C.c_int64()
+        _lib.check(_lib.lib().isb_hpe_profile_read_dw(self._h, C.byref(ms), C.byref(n)), "isb_hpe_profile_read_dw")
+        return ms.value, n.value
+
 
 def f32_to_f16(a: np.ndarray) -> np.ndarray:
     """round-to-nearest-even f32 -> IEEE fp16 bit patterns (uint16)"""

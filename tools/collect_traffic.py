@@ -12,7 +12,7 @@ import sys
 def family(name: str) -> str:
     if "dwconv3x3" in name:
         return "dwconv3x3_pool"
-    if "conv_igemm" in name or "gemm1x1" in name or "conv3x3_dma" in name or "conv3x3_c32_rows" in name or "fused_mb" in name or "mbfront8" in name or "mb8_chain" in name:
+    if "conv_igemm" in name or "gemm1x1" in name or "conv3x3_dma" in name or "conv3x3_c32_rows" in name or "fused_mb" in name or "mbfront8" in name or "mbfront16" in name or "mb8_chain" in name:
         return "conv_igemm"
     if "se_fc" in name:
         return "se_fc"

@@ -10,7 +10,7 @@ from isbfsar_amd import effnetv2 as E
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "dwconv3x3" in r["Kernel_Name"]]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 seq = [(f"dw {b.cexp}ch {b.in_hw}->{b.out_hw}", 2.0 * B * b.cexp * (b.in_hw ** 2 + b.out_hw ** 2)) for b in E.blocks() if b.kind == "mb"
-       and not (b.stride == 1 and b.in_hw == 8 and b.cin == 384 and B >= 32)]       # those run inside mbfront8_kernel (layer_breakdown.py)
+       and not (b.stride == 1 and B >= 32 and ((b.in_hw == 8 and b.cin == 384) or (b.in_hw == 16 and b.cin in (192, 224))))]       # those run inside mbfront8 / mbfront16 (layer_breakdown.py)
 last = rows[-len(seq):]
 agg = collections.OrderedDict()
 tot = 0.0

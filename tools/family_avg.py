@@ -6,7 +6,7 @@ import csv
 import json
 import sys
 
-FAMILY = ("conv_igemm", "gemm1x1", "conv3x3_dma", "conv3x3_c32_rows", "fused_mb", "mbfront8", "splitk_reduce")
+FAMILY = ("conv_igemm", "gemm1x1", "conv3x3_dma", "conv3x3_c32_rows", "fused_mb", "mbfront8", "mbfront16", "splitk_reduce")
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if any(k in r["Name"] for k in FAMILY)]
 calls = sum(int(r["Calls"]) for r in rows)
 total_ns = sum(float(r["TotalDurationNs"]) for r in rows)

@@ -2,7 +2,8 @@
 usage: python tools/layer_breakdown.py <kernel_trace.csv> [B]
 The expected launch sequence follows csrc/hpe_api.cpp::run_backbone: Fused-MBConv blocks with <= 256 expanded channels
 are ONE launch (fused_mb), the others expand + project; MBConv blocks are expand + project (depthwise / SE are not
-convolution-family launches), except that the 8 x 8 stride-1 blocks with 384 inputs run expand + depthwise as one launch (mbfront8).
+convolution-family launches), except that the stride-1 MBConv blocks with 384 inputs on 8 x 8 maps (mbfront8) and with 192 / 224 inputs on
+16 x 16 maps (mbfront16, round 5) run expand + depthwise + pool as one launch.
 Each row also carries the layer's two floors: MFMA (its FLOPs at the 2.5 PFLOP/s dense bf16 peak) and HBM (its algorithmic bytes --
 input + output [+ residual] activations and the weights, 2 bytes per element -- at 8 TB/s), and `eff` = the larger floor / the
 measured time. The last line is the pass at the speed of light of this launch structure (sum of the larger floors)."""
@@ -13,7 +14,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from isbfsar_amd import effnetv2 as E
 
-FAMILY = ("conv_igemm", "gemm1x1", "conv3x3_dma", "conv3x3_c32_rows", "fused_mb", "mbfront8", "splitk_reduce")
+FAMILY = ("conv_igemm", "gemm1x1", "conv3x3_dma", "conv3x3_c32_rows", "fused_mb", "mbfront8", "mbfront16", "splitk_reduce")
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if any(k in r["Kernel_Name"] for k in FAMILY)]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 PEAK_F, PEAK_B = 2.5e15, 8.0e12
@@ -35,7 +36,7 @@ for b in E.blocks():
     else:
         # stride-1 blocks with 384 inputs on 8 x 8 maps: expand + depthwise + pool are ONE launch (mbfront8_kernel) -- its time holds the
         # depthwise work, its floors here are the expand GEMM's (the expanded tensor is written once, as the depthwise output)
-        front = b.stride == 1 and b.in_hw == 8 and b.cin == 384 and B >= 32
+        front = b.stride == 1 and B >= 32 and ((b.in_hw == 8 and b.cin == 384) or (b.in_hw == 16 and b.cin in (192, 224)))       # mbfront8 / mbfront16
         seq.append((f"{'front(exp+dw)' if front else 'exp1x1'} {b.cin}->{b.cexp} @{b.in_hw}", 2.0 * B * b.in_hw * b.in_hw * b.cin * b.cexp,
                     2.0 * (B * b.in_hw ** 2 * (b.cin + b.cexp) + b.cin * b.cexp)))
         seq.append((f"proj(SE) {b.cexp}->{b.cout} @{b.out_hw}", 2.0 * B * o * b.cexp * b.cout,
