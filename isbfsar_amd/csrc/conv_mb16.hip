@@ -50,7 +50,10 @@ __global__ __launch_bounds__(256, 3) void mbfront16_kernel(MbFront16Args p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int CEXP = p.cexp, NSL = (CEXP + 127) / 128;
-    const int slice = blockIdx.x % NSL, q = blockIdx.x / NSL, Q = gridDim.x / NSL;
+    // workgroup -> (slice, sample sequence): ids 8 apart share an XCD, and all slices of a sample sequence sit on ONE XCD, so that its L2
+    // fetches a sample's input once (slices dealt round-robin over the XCDs read every sample through every L2: +4.8 GB per pass)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int slice = slot % NSL, q = (slot / NSL) * 8 + xcd, Q = (int)(gridDim.x / (8 * NSL)) * 8;
     if (q >= p.B) return;
     const int cb = min(slice * NW + wave, CEXP / 32 - 1), c0 = cb * 32;
     const bool live = (slice * NW + wave) * 32 < CEXP;     // 1344 channels = 10 slices + 64: the last slice's upper waves only stage tiles and meet the barriers
@@ -289,7 +292,7 @@ int launch_mbfront16(const MbFront16Args& a, hipStream_t st) {
         return ISB_ERR_INVALID;
     }
     const int nsl = cdiv(a.cexp, 128);
-    const int Q = std::max(1, std::min(a.B, 768 / nsl));             // sample sequences: three workgroups per CU
+    const int Qx = std::max(1, std::min(cdiv(a.B, 8), 768 / (8 * nsl)));     // sample sequences per XCD: three workgroups per CU
     MbFront16Args aa = a;
     aa.exp = exp_flags();
 #define ISB_MBF16(CIN_, F16_)                                                                                                \
@@ -304,7 +307,7 @@ int launch_mbfront16(const MbFront16Args& a, hipStream_t st) {
                 fprintf(stderr, "[isb] mbfront16<%d>: %d workgroups per CU by the occupancy API (LDS %d B)\n", CIN_, nb, Mf16<CIN_>::LDS);  \
             }                                                                                                                \
         }                                                                                                                    \
-        hipLaunchKernelGGL((mbfront16_kernel<CIN_, F16_>), dim3(nsl * Q), dim3(256), Mf16<CIN_>::LDS, st, aa);                \
+        hipLaunchKernelGGL((mbfront16_kernel<CIN_, F16_>), dim3(8 * nsl * Qx), dim3(256), Mf16<CIN_>::LDS, st, aa);                \
     } while (0)
     if (a.cin == 224) { if (a.f16) ISB_MBF16(224, true); else ISB_MBF16(224, false); }
     else { if (a.f16) ISB_MBF16(192, true); else ISB_MBF16(192, false); }
