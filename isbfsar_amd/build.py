@@ -136,6 +136,48 @@ def mbfront8_wait_counted(lib_path: str):
     return None
 
 
+# kernels whose f32 -> fp16 conversions need no saturation, with the reason
+FP16_NO_OVERFLOW = {"ar_proto_all_kernel": "converts softmax probabilities exp2(s' - lse) <= 1 (the MFMA's P operand)"}
+
+
+def fp16_conversions_saturate(lib_path: str, text: str = None):
+    """ADVICE r4: T16<true>::pack2 / from_f32 no longer clamp -- they rely on MODE.FP16_OVFL, which a kernel sets by calling
+    T16<F16>::enter() (conv_common.h); a kernel that forgets it would store inf and poison every later layer, silently. Enforced on
+    the built code: every kernel of the code object that executes a v_cvt_*f16_f32 must EITHER set the mode bit
+    (s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1)) OR clamp every converted value explicitly (f2h_: at least one v_med3_f32 per
+    conversion; the stem, the weight conversion, the AR tuple images) OR be listed in FP16_NO_OVERFLOW with its reason.
+    Returns None when the library passes, else the reason."""
+    if text is None:
+        text = _disassemble(lib_path)
+    if not text.startswith("\n"):
+        return text
+    kern, cur = {}, None
+    for line in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            cur = m.group(1)
+            kern[cur] = [0, 0, 0]
+        elif cur and line.strip():
+            t = line.split("//")[0]
+            if re.search(r"\bv_cvt_(pk_|pkrtz_)?f16_f32", t):
+                kern[cur][0] += 1
+            elif "s_setreg_imm32_b32" in t and "HW_REG_MODE, 23, 1), 1" in t:
+                kern[cur][1] += 1
+            elif "v_med3_f32" in t:
+                kern[cur][2] += 1
+    n_mode = 0
+    for name, (cvt, mode, med3) in kern.items():
+        if not cvt:
+            continue
+        if mode:
+            n_mode += 1
+        elif med3 < cvt and not any(k in name for k in FP16_NO_OVERFLOW):
+            return f"{name}: {cvt} f32 -> fp16 conversions, MODE.FP16_OVFL never set and only {med3} explicit clamps (T16<F16>::enter() missing?)"
+    if n_mode < 30:
+        return f"only {n_mode} kernels set MODE.FP16_OVFL: the disassembly was not understood"
+    return None
+
+
 def wspipe_registers_private(lib_path: str):
     """gemm1x1_wspipe_kernel (csrc/conv_ws.hip) keeps global loads in flight in literally named registers -- a[200:255]
     with one wave per SIMD, v[228:255] with two -- that the register allocator sees only as clobbers of the request asm.
@@ -233,6 +275,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
             print(f"[build] WARNING: fused front of the 8x8 MBConv blocks DISABLED (expand + depthwise launches run instead): {why8}", flush=True)
         if why is None or why8 is None:
             guard(int(why is None), int(why8 is None))
+        why16 = fp16_conversions_saturate(LIB)
+        if why16 is not None:       # no fallback exists for a kernel that could store inf: refuse the library
+            os.remove(LIB)
+            raise RuntimeError(f"fp16 storage kernels must saturate: {why16}")
     return LIB
 
 

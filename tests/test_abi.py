@@ -158,3 +158,25 @@ def test_mbfront8_counted_wait_is_guarded_by_the_build(built_lib):
             assert "scratch" in (build.mbfront8_wait_counted(built_lib) or "")
         finally:
             build._disassemble = orig
+
+
+def test_every_fp16_storing_kernel_saturates(built_lib):
+    """ADVICE r4 (low): T16<true>::pack2 / from_f32 rely on MODE.FP16_OVFL (T16<F16>::enter()) instead of clamping; nothing used to
+    enforce that a new fp16 kernel sets it. The build now refuses a library in which a kernel converts f32 -> fp16 without the mode
+    bit, without an explicit clamp per conversion, and without an entry (with its reason) in build.FP16_NO_OVERFLOW; the check must
+    pass on the shipped library and reject a kernel that lost its s_setreg."""
+    from isbfsar_amd import build
+    why = build.fp16_conversions_saturate(built_lib)
+    if not os.path.exists(build.OBJDUMP):
+        assert why is not None
+        return
+    assert why is None, why
+    text = build._disassemble(built_lib)
+    lines = text.splitlines()
+    # doctor the disassembly: drop the mode write of the first mbfront16_kernel<.., true> instantiation
+    start = next(i for i, ln in enumerate(lines) if "mbfront16_kernel" in ln and ln.rstrip().endswith(">:") and "Lb1" in ln)
+    drop = next(i for i in range(start, len(lines)) if "s_setreg_imm32_b32" in lines[i])
+    assert not any(ln.rstrip().endswith(">:") for ln in lines[start + 1:drop]), "the instantiation sets no mode bit"
+    bad = "\n".join(lines[:drop] + lines[drop + 1:])
+    why_bad = build.fp16_conversions_saturate(built_lib, text=bad)
+    assert why_bad is not None and "mbfront16_kernel" in why_bad, why_bad
