@@ -735,13 +735,16 @@ int launch_se_fcs(const SeFcArgs& a, hipStream_t st) {
 // =====================================================================================
 // stem: conv3x3 stride 2 (TF SAME on an even input: pad bottom/right), 3 -> 32, bias, SiLU.
 // f32 crop [B,256,256,3] -> bf16 [B,128,128,32]. thread = one output pixel, all 32 channels;
-// weights [32][3][3][3] f32 (scale folded) are wave-uniform -> scalar loads.
+// weights [16 channel pairs][27 taps][2] f32 (scale folded) are wave-uniform -> scalar loads, 54 consecutive floats per pair.
 // =====================================================================================
+template <bool OUT_F16>
 __global__ __launch_bounds__(256) void stem_kernel(StemArgs p) {
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int OH = p.H / 2, OW = p.W / 2;
-    if (idx >= (size_t)p.B * OH * OW) return;
-    const int ox = (int)(idx % OW), oy = (int)((idx / OW) % OH), b = (int)(idx / ((size_t)OW * OH));
+    const unsigned pix = blockIdx.x * 256u + threadIdx.x;       // grid = (pixels of an image / 256, B): 32-bit index arithmetic
+    if (pix - (threadIdx.x & 63) >= (unsigned)(OH * OW)) return;                 // (whole waves only: a wave's lanes store for one another)
+    const unsigned pixc = min(pix, (unsigned)(OH * OW) - 1u);
+    const int b = blockIdx.y, oy = (int)(pixc / (unsigned)OW), ox = (int)(pixc - (unsigned)oy * (unsigned)OW);
+    const size_t idx = (size_t)b * OH * OW + pix;
     float x[27];
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
@@ -749,32 +752,55 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs p) {
         for (int kx = 0; kx < 3; ++kx) {
             const int iy = 2 * oy + ky, ix = 2 * ox + kx;
             const bool ok = iy < p.H && ix < p.W;
-            const float* src = p.in + ((size_t)(b * p.H + (ok ? iy : 0)) * p.W + (ok ? ix : 0)) * 3;
+            // unconditional loads from clamped addresses, the select on the VALUE (a select on the load is a branch + vmcnt(0) per tap)
+            const float* src = p.in + ((size_t)(b * p.H + min(iy, p.H - 1)) * p.W + min(ix, p.W - 1)) * 3;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) x[(ky * 3 + kx) * 3 + c] = ok ? src[c] : 0.f;
+            for (int c = 0; c < 3; ++c) {
+                const float v = src[c];
+                x[(ky * 3 + kx) * 3 + c] = ok ? v : 0.f;
+            }
         }
+    // output channels in PAIRS: the pair-major weights wt[co / 2][k][co & 1] put (co, co + 1) into adjacent scalar registers, so one v_pk_fma_f32
+    // (same IEEE fma per half, same k order: the bits of the scalar chain) does two of the 864 multiply-adds of a pixel. Round 5: the
+    // kernel ran AT the vector ALU's issue rate (valu_active_share 1.05, 184 us per 256 frames; 1104 v_fma + a 15-instruction IEEE
+    // division per SiLU); SiLU now is the x * rcp(1 + exp2(-x log2 e)) of every other layer.
+    const f32x2_t* w2 = reinterpret_cast<const f32x2_t*>(p.wt);
+    const f32x2_t* b2 = reinterpret_cast<const f32x2_t*>(p.bias);
     uint32_t o[16];
 #pragma unroll
-    for (int co = 0; co < 32; co += 2) {
-        float a0 = p.bias[co], a1 = p.bias[co + 1];
+    for (int c2 = 0; c2 < 16; ++c2) {                  // one channel pair at a time: its 27 weight pairs fit the scalar registers
+        f32x2_t acc = b2[c2];
 #pragma unroll
         for (int k = 0; k < 27; ++k) {
-            a0 = fmaf(x[k], p.w[co * 27 + k], a0);
-            a1 = fmaf(x[k], p.w[(co + 1) * 27 + k], a1);
+            const f32x2_t xk = {x[k], x[k]};
+            acc = __builtin_elementwise_fma(xk, w2[c2 * 27 + k], acc);
         }
-        o[co >> 1] = p.out_f16 ? ((uint32_t)f2h_(silu_(a0)) | ((uint32_t)f2h_(silu_(a1)) << 16))
-                               : ((uint32_t)f2bf_(silu_(a0)) | ((uint32_t)f2bf_(silu_(a1)) << 16));
+        const float a0 = silu_fast(acc.x), a1 = silu_fast(acc.y);
+        o[c2] = OUT_F16 ? ((uint32_t)f2h_(a0) | ((uint32_t)f2h_(a1) << 16)) : ((uint32_t)f2bf_(a0) | ((uint32_t)f2bf_(a1) << 16));
     }
-    uint4* dst = reinterpret_cast<uint4*>(p.out + idx * 32);
-    dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
-    dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
-    dst[2] = make_uint4(o[8], o[9], o[10], o[11]);
-    dst[3] = make_uint4(o[12], o[13], o[14], o[15]);
+    // a lane holds its pixel's 64 bytes; stored from here every instruction would write 16 bytes into each of 64 different rows. Through
+    // LDS (wave-local, slots rotated by (pixel >> 2) & 3: conflict-free both ways) a store instruction writes 16 whole pixels = 1 KiB
+    __shared__ __attribute__((aligned(16))) unsigned char tile[256 * 64];
+    {
+        const int t = threadIdx.x, sw = (t >> 2) & 3;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            *reinterpret_cast<uint4*>(tile + t * 64 + ((c ^ sw) << 4)) = make_uint4(o[4 * c], o[4 * c + 1], o[4 * c + 2], o[4 * c + 3]);
+        const int lane = t & 63, w0 = t & ~63, cc = lane & 3;
+        uint16_t* const base = p.out + (idx - lane) * 32;          // the wave's first pixel (a wave never straddles images: OH * OW % 64 == 0)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pp = (lane >> 2) + 16 * i;
+            const uint4 v = *reinterpret_cast<const uint4*>(tile + (w0 + pp) * 64 + ((cc ^ ((pp >> 2) & 3)) << 4));
+            if (pix - lane + pp < (unsigned)(OH * OW)) *reinterpret_cast<uint4*>(base + pp * 32 + cc * 8) = v;
+        }
+    }
 }
 
 int launch_stem(const StemArgs& a, hipStream_t st) {
-    const size_t total = (size_t)a.B * (a.H / 2) * (a.W / 2);
-    hipLaunchKernelGGL(stem_kernel, dim3((unsigned)cdivz(total, 256)), dim3(256), 0, st, a);
+    const dim3 grid((unsigned)cdiv((a.H / 2) * (a.W / 2), 256), (unsigned)a.B);
+    if (a.out_f16) hipLaunchKernelGGL(stem_kernel<true>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(stem_kernel<false>, grid, dim3(256), 0, st, a);
     ISB_LAUNCHED("stem", st);
     return ISB_OK;
 }

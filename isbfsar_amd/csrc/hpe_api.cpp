@@ -101,7 +101,7 @@ struct isb_hpe {
     int n_out = 0;
     double K[9] = {0};
     // weights
-    DevBuf stem_w, stem_b;
+    DevBuf stem_w, stem_wt, stem_b;
     std::vector<std::unique_ptr<BlockW>> blocks;
     ConvW headconv;
     DevBuf head_w, head_b;
@@ -297,7 +297,7 @@ int gemm(hipStream_t st, const float* A, int lda, const float* W, int ldw, const
 // launches take the host ~2 ms to submit, and submitted lane after lane the second lane's first kernel would wait that long
 int backbone_begin(isb_hpe* h, Lane& L, hipStream_t st, const float* crops, int B) {
     StemArgs sa{};
-    sa.in = crops; sa.w = h->stem_w.as<float>(); sa.bias = h->stem_b.as<float>(); sa.out = L.bufX.as<uint16_t>();
+    sa.in = crops; sa.w = h->stem_w.as<float>(); sa.wt = h->stem_wt.as<float>(); sa.bias = h->stem_b.as<float>(); sa.out = L.bufX.as<uint16_t>();
     sa.B = B; sa.H = 256; sa.W = 256; sa.out_f16 = h->f16_from <= 0 ? 1 : 0;
     ISB_TRY(launch_stem(sa, st));
     L.X = L.bufX.p;
@@ -602,6 +602,10 @@ extern "C" int isb_hpe_load_weights(isb_hpe* h, const void* blob, size_t nbytes)
         for (int o = 0; o < 32; ++o)
             for (int k = 0; k < 27; ++k) w[o * 27 + k] = it->second.data[o * 27 + k] * sc->data[o];
         ISB_TRY(upload(h->stem_w, w.data(), w.size() * 4));
+        std::vector<float> wt(27 * 32);                    // pair-major copy [16][27][2]: stem_kernel reads channel pairs as adjacent scalars
+        for (int o = 0; o < 32; ++o)
+            for (int k = 0; k < 27; ++k) wt[((o >> 1) * 27 + k) * 2 + (o & 1)] = w[o * 27 + k];
+        ISB_TRY(upload(h->stem_wt, wt.data(), wt.size() * 4));
         ISB_TRY(upload(h->stem_b, sh->data, 32 * 4));
     }
     int idx = 0, hw = 128, stage = 0;

@@ -111,11 +111,19 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs p) {
     const int fb = p.n_aug > 1 ? b / p.n_aug : b;        // source frame
     const int pix = blockIdx.x * 256 + threadIdx.x;      // 0..65535
     const int y = pix >> 8, x = pix & 255;
-    const float* H = p.H + 9 * b;
-    const float h8 = H[8];
-    const float t0 = __fdiv_rn(H[0], h8), t1 = __fdiv_rn(H[1], h8), t2 = __fdiv_rn(H[2], h8);
-    const float t3 = __fdiv_rn(H[3], h8), t4 = __fdiv_rn(H[4], h8), t5 = __fdiv_rn(H[5], h8);
-    const float t6 = __fdiv_rn(H[6], h8), t7 = __fdiv_rn(H[7], h8);
+    // per workgroup, once: the eight homography quotients (the same for every pixel of a sample) and the 256 values an 8-bit channel can
+    // take, each by the reference's own operations (H[i] / H[8] in f32; int / 255.0 in f64, cast to f32) -- the kernel ran AT the vector
+    // ALU's issue rate with eight IEEE f32 divisions and three f64 divisions per pixel (valu_active_share 1.0, 94 us per 256 frames)
+    __shared__ __attribute__((aligned(16))) float tq[8];
+    __shared__ float u8f[256];
+    {
+        const float* H = p.H + 9 * b;
+        if (threadIdx.x < 8) tq[threadIdx.x] = __fdiv_rn(H[threadIdx.x], H[8]);
+        u8f[threadIdx.x] = (float)((double)threadIdx.x / 255.0);        // hpe.py:100
+    }
+    __syncthreads();
+    const float4 tqa = *reinterpret_cast<const float4*>(tq), tqb = *reinterpret_cast<const float4*>(tq + 4);
+    const float t0 = tqa.x, t1 = tqa.y, t2 = tqa.z, t3 = tqa.w, t4 = tqb.x, t5 = tqb.y, t6 = tqb.z, t7 = tqb.w;
     const float xf = (float)x, yf = (float)y;
     const float k = __fadd_rn(__fadd_rn(__fmul_rn(t6, xf), __fmul_rn(t7, yf)), 1.0f);
     const float xs = __fdiv_rn(__fadd_rn(__fadd_rn(__fmul_rn(t0, xf), __fmul_rn(t1, yf)), t2), k);
@@ -136,9 +144,9 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs p) {
             s = p.frames + (((size_t)fb * p.FH + yi) * p.FW + xi) * 3;
         }
         if (in) {
-        o0 = (float)((double)s[0] / 255.0);                // hpe.py:100 (int / 255.0 in f64, cast to f32)
-        o1 = (float)((double)s[1] / 255.0);
-        o2 = (float)((double)s[2] / 255.0);
+        o0 = u8f[s[0]];
+        o1 = u8f[s[1]];
+        o2 = u8f[s[2]];
         }
     }
     float* d = p.crops + ((size_t)b * 65536 + pix) * 3;

@@ -280,7 +280,8 @@ int launch_se_fcs(const SeFcArgs& a, hipStream_t st);
 
 struct StemArgs {
     const float* in;        // f32 [B,H,W,3]
-    const float* w;         // f32 [32][27], BN scale folded
+    const float* w;         // f32 [32][27], BN scale folded (the detector's stem)
+    const float* wt;        // f32 [16][27][2]: the same weights, wt[co / 2][k][co & 1] (the pose backbone's stem: a channel pair's taps are 54 consecutive scalars)
     const float* bias;      // [32]
     uint16_t* out;          // bf16 (fp16 when out_f16) [B,H/2,W/2,32]
     int B, H, W;
