@@ -215,9 +215,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_dma_kernel(ConvArgs p)
 // -------------------------------------------------------------------------------------------
 constexpr int HALO_ROWB = 144 * 64;                  // bytes per ring row
 constexpr int HALO_RING = 6 * HALO_ROWB;
-constexpr int HALO_LDS = HALO_RING + 256 * 64;       // + the step's output tile (residual in, result out: in place)
+constexpr int HALO_BIAS = HALO_RING + 256 * 64;      // the 32 biases (f32): read per step -- as 16 registers they pushed the kernel past 128 and
+constexpr int HALO_LDS = HALO_BIAS + 128;            // the second workgroup off the CU. + the step's output tile (residual in, result out: in place)
 template <bool F16>
-__global__ __launch_bounds__(512, 2) void conv3x3_c32_rows_kernel(ConvArgs p, int band) {
+__global__ __launch_bounds__(512, 4) void conv3x3_c32_rows_kernel(ConvArgs p, int band) {
     T16<F16>::enter();
     constexpr int W_ = 128;
     unsigned char* const lds = conv_lds_dyn;
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c32_rows_kernel(ConvArgs p, in
     if (has_res) load_res(ys);
     // weights: lane (r, h) holds output channel r, channels 8h..8h+7 of each 16-channel half of each tap
     bf16x8 bfr[9][2];
-    float4 bias4[4];
+    if (tid < 32) reinterpret_cast<float*>(lds + HALO_BIAS)[tid] = p.bias[tid];     // (published by the first step's barrier)
     {
         const uint16_t* wrow = p.w + (size_t)r * 288 + 8 * h;
 #pragma unroll
@@ -272,8 +273,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c32_rows_kernel(ConvArgs p, in
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
                 bfr[tap][ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wrow + tap * 32 + ks * 16));
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) bias4[qq] = *reinterpret_cast<const float4*>(p.bias + 8 * qq + 4 * h);
     }
     const int q = wave * 32 + r;                        // output pixel of the step
     const int oy = wave >> 2, ox = q & (W_ - 1);        // waves 0-3: first output row, 4-7: second
@@ -316,8 +315,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c32_rows_kernel(ConvArgs p, in
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
             unsigned char* cell = Cs + q * 64 + ((qq ^ swq) << 4) + 8 * h;
-            float v0 = acc[4 * qq] + bias4[qq].x, v1 = acc[4 * qq + 1] + bias4[qq].y, v2 = acc[4 * qq + 2] + bias4[qq].z,
-                  v3 = acc[4 * qq + 3] + bias4[qq].w;
+            const float4 b4 = *reinterpret_cast<const float4*>(lds + HALO_BIAS + (8 * qq + 4 * h) * 4);
+            float v0 = acc[4 * qq] + b4.x, v1 = acc[4 * qq + 1] + b4.y, v2 = acc[4 * qq + 2] + b4.z, v3 = acc[4 * qq + 3] + b4.w;
             if (p.act == 1) { v0 = silu_fast(v0); v1 = silu_fast(v1); v2 = silu_fast(v2); v3 = silu_fast(v3); }
             else if (p.act) { v0 = act_other(p.act, v0); v1 = act_other(p.act, v1); v2 = act_other(p.act, v2); v3 = act_other(p.act, v3); }
             if (has_res) {
