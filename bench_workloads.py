@@ -8,6 +8,7 @@ hpe      : BASELINE.json configs[1] -- 256 frames, pose stage only
 """
 from __future__ import annotations
 
+import contextlib
 import json
 import os
 import time
@@ -157,17 +158,64 @@ class _HpeBase:
         self.B = args.batch or 256
         self.dev = dev
         self.bb_state = effnetv2.make_state(0)
-        self.hpe = HpeEngine(device=dev, max_batch=min(self.B, int(os.environ.get("ISB_HPE_MICROBATCH", "1024"))),
-                             precision=getattr(args, "hpe_precision", "f16"))
+        # Steps in flight. One step = one 256-frame batch through the pose stage. The library's own arrangement splits a batch into two
+        # 128-frame halves on two streams; keeping TWO whole batches in flight instead -- consecutive steps on two one-lane engines, each
+        # on its own stream, started pairwise -- runs 256-frame launches (better tiles, fewer workgroup rounds) that still fill each
+        # other's gaps: 15.05 vs 15.7 ms per 256 frames (tools/exp_lane_offset.py 8 256). Consecutive batches are independent (the pose
+        # ring that carries over is updated in step order on the match stream), every step still does all of its work, and the
+        # timed region ends on a device-wide synchronize. ISB_BENCH_INFLIGHT=1 = one batch at a time on the library's two lanes.
+        self.n_flight = max(1, min(2, int(os.environ.get("ISB_BENCH_INFLIGHT", "2")))) if self.B >= 64 else 1
+        self.hpe_precision_arg = getattr(args, "hpe_precision", "f16")
+        self.hpes = [self._make_hpe(self.hpe_precision_arg) for _ in range(self.n_flight)]
+        self.hpe = self.hpes[0]
+        self.pose_streams = [torch.cuda.Stream(device=dev) for _ in range(self.n_flight)] if self.n_flight > 1 else None
+        self.step_no = 0
+        self.serial = False           # the roofline pass: one engine, whole-batch launches one after the other on the current stream
+        self.pose_done = None
         self.precision = self.hpe.precision if self.hpe.precision != "bf16_f16tail" else "bf16"
-        self.hpe.load_weights(self.bb_state)
-        self.hpe.set_joint_map(np.load(os.path.join(_ASSETS, "32_to_122.npy")), None)   # skeleton=None -> 122 joints
         self.frames_host = synth.frames(self.B, seed=10_000 * rank)
         self.bbox_host = synth.bboxes(self.B, seed=10_000 * rank)
         self.frames = torch.from_numpy(self.frames_host).cuda(dev)
         self.bbox = torch.from_numpy(self.bbox_host).cuda(dev)
 
+    def _make_hpe(self, precision):
+        e = HpeEngine(device=self.dev, max_batch=min(self.B, int(os.environ.get("ISB_HPE_MICROBATCH", "1024"))), precision=precision)
+        e.load_weights(self.bb_state)
+        e.set_joint_map(np.load(os.path.join(_ASSETS, "32_to_122.npy")), None)   # skeleton=None -> 122 joints
+        if self.n_flight > 1:
+            e.set_lanes(1)
+        return e
+
+    def _pose(self, frames, bbox):
+        """The pose stage of one step -> (joints, valid). One batch in flight: on the current stream. Two: on the step's own engine
+        and stream, behind the inputs the current stream has produced so far; `self.pose_done` is the event a consumer stream waits
+        for. Pairs of steps start together."""
+        torch = self.torch
+        if self.pose_streams is None or self.serial:
+            self.pose_done = None
+            return self.hpe.forward(frames, bbox)
+        k = self.step_no % self.n_flight
+        self.step_no += 1
+        ps = self.pose_streams[k]
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+        ps.wait_event(ready)
+        frames.record_stream(ps)                              # (the caching allocator must not recycle them under the pose stream)
+        bbox.record_stream(ps)
+        with torch.cuda.stream(ps):
+            joints, valid = self.hpes[k].forward(frames, bbox)
+            self.pose_done = torch.cuda.Event()
+            self.pose_done.record(ps)
+        if k == self.n_flight - 1:                            # a pair is enqueued: the next pair starts when both are through
+            for a in self.pose_streams:
+                for b in self.pose_streams:
+                    if a is not b:
+                        a.wait_stream(b)
+        return joints, valid
+
     def _hpe_roofline(self, steps):
+        self.torch.cuda.synchronize()
+        self.serial = True
         self.hpe.profile(True)
         for _ in range(steps):
             self.step()
@@ -175,6 +223,7 @@ class _HpeBase:
         ms, launches = self.hpe.profile_read()
         ms_dw, launches_dw = self.hpe.profile_read_dw()
         self.hpe.profile(False)
+        self.serial = False
         flops = 2.0 * igemm_macs_per_crop() * self.B * steps
         achieved = flops / (ms / 1e3) / 1e12
         traffic = None
@@ -269,7 +318,7 @@ class HpeWorkload(_HpeBase):
         elif self.host_input:        # H2D of the frames + kernels + D2H of the poses + synchronise, inside the step
             self.out = self.hpe.forward(self.frames_pinned, self.bbox_host)
         else:
-            self.out = self.hpe.forward(self.frames, self.bbox)
+            self.out = self._pose(self.frames, self.bbox)
 
     def roofline(self, steps):
         return self._hpe_roofline(steps)
@@ -287,7 +336,8 @@ class HpeWorkload(_HpeBase):
                             + (" -- frames in pinned HOST memory, H2D + D2H inside the step (isb_hpe_forward_host)" if self.host_input else "")
                             + ("; two batches in flight (isb_hpe_submit_host / isb_hpe_wait_host)" if self.pipelined else ""),
                 "input": ("host (pinned), two batches in flight" if self.pipelined else "host (pinned)") if self.host_input else "resident in HBM",
-                "per_gpu_batch": self.B, "n_joints": self.J, "parallelism": f"dp{world}"}
+                "per_gpu_batch": self.B, "n_joints": self.J, "parallelism": f"dp{world}",
+                "steps_in_flight": 1 if (self.host_input or self.pose_streams is None) else self.n_flight}
 
 
 class PipelineWorkload(_HpeBase):
@@ -319,7 +369,8 @@ class PipelineWorkload(_HpeBase):
         # travels over xGMI while the pose stage of step i+1 computes (consecutive batches are independent; the pose ring
         # that carries over lives on the first stream). On one GPU the same arrangement changes nothing (measured:
         # the two pose lanes already fill the chip), so N = 1 runs the stages back to back.
-        self.side = torch.cuda.Stream(device=dev) if world > 1 and os.environ.get("ISB_BENCH_OVERLAP", "1") != "0" else None
+        self.side = (torch.cuda.Stream(device=dev)
+                     if (world > 1 and os.environ.get("ISB_BENCH_OVERLAP", "1") != "0") or self.n_flight > 1 else None)
         self.gather, self.force = make_gather(args, world, dev)
 
     def units_per_step(self):
@@ -335,19 +386,23 @@ class PipelineWorkload(_HpeBase):
             boxes, confs = self.det.forward(self.frames)
             det_bbox, found = self.hpe.select_person(boxes, confs, 0.3)
             bbox = torch.where(found.bool()[:, None], det_bbox, self.bbox)
-        joints, valid = self.hpe.forward(self.frames, bbox)                      # [B,122,3]
-        if not self.checked:
-            assert bool(valid.all().item()), "synthetic frames are expected to give in-FOV poses"
-            self.checked = True
-        self.ring[:, self.L - 1:] = joints.view(self.N_CAM, self.steps_per_cam, self.J, 3)
-        windows = pose_windows(self.ring, self.L)                                 # [B,L,3J], root-centred
-        self.ring[:, : self.L - 1] = self.ring[:, self.steps_per_cam:].clone()     # slide the history
-        if self.side is not None:
-            self.side.wait_stream(torch.cuda.current_stream())                    # the windows are complete
-            windows.record_stream(self.side)
-            with torch.cuda.stream(self.side):
-                self._match(windows)
-        else:
+        joints, valid = self._pose(self.frames, bbox)                            # [B,122,3]
+        # everything behind the pose stage -- the pose ring (carried from step to step), the windows, the match stage, the all-gather
+        # -- runs in step order on the match stream; with one batch in flight on one GPU that is the current stream
+        ms = self.side
+        if ms is not None:
+            ms.wait_stream(torch.cuda.current_stream())
+            if self.pose_done is not None:
+                ms.wait_event(self.pose_done)
+            joints.record_stream(ms)
+            valid.record_stream(ms)
+        with (torch.cuda.stream(ms) if ms is not None else contextlib.nullcontext()):
+            if not self.checked:
+                assert bool(valid.all().item()), "synthetic frames are expected to give in-FOV poses"
+                self.checked = True
+            self.ring[:, self.L - 1:] = joints.view(self.N_CAM, self.steps_per_cam, self.J, 3)
+            windows = pose_windows(self.ring, self.L)                             # [B,L,3J], root-centred
+            self.ring[:, : self.L - 1] = self.ring[:, self.steps_per_cam:].clone()  # slide the history
             self._match(windows)
 
     def _match(self, windows):
@@ -439,6 +494,15 @@ class PipelineWorkload(_HpeBase):
             product; the reference's TRXOS is fp32);
           * whole_batch_2048 -- BASELINE configs[3]'s WHOLE batch (2048 frames -> 2048 windows) on this one GPU."""
         out = {}
+        if self.n_flight > 1:           # the same steps one at a time: one engine, the batch split into the library's two half-batch lanes
+            self.torch.cuda.synchronize()
+            self.hpe.set_lanes(2)
+            self.serial = True
+            dt = self._timed(max(3, min(args.steps, 10)))
+            self.serial = False
+            self.hpe.set_lanes(1)
+            out["value_one_step_in_flight"] = round(self.B / dt, 3)
+            out["ms_per_step_one_step_in_flight"] = round(dt * 1e3, 4)
         if self.B <= 256:
             from isbfsar_amd import yolov4
             from isbfsar_amd.det_engine import DetEngine
@@ -528,12 +592,17 @@ class PipelineWorkload(_HpeBase):
                     "joints_rootcentred_maxabs": float(np.abs((g - g[:, :1]) - (ref - ref[:, :1])).max()), "n_frames": len(ok)}
             e.load_weights(self.bb_state)
             if e is not hpe0:
+                hpes0 = self.hpes                       # the pipeline at this layout: as many engines as steps are in flight
+                if self.n_flight > 1:
+                    e.set_lanes(1)
+                self.hpes = [e] + [self._make_hpe(prec) for _ in range(self.n_flight - 1)]
                 self.hpe = e
                 dt = self._timed(5)
                 out[f"value_hpe_{prec}"] = round(self.B / dt, 3)
                 out[f"ms_per_step_hpe_{prec}"] = round(dt * 1e3, 4)
-                self.hpe = hpe0
-                e.close()
+                for x in self.hpes:
+                    x.close()
+                self.hpes, self.hpe = hpes0, hpe0
         out["parity_hpe_precisions_vs_fp32_oracle"] = parity
         return out
 
@@ -560,6 +629,10 @@ class PipelineWorkload(_HpeBase):
                             f"({self.N_CAM} cameras x {self.steps_per_cam} steps) -> HPE (EfficientNetV2-L, 122 joints) -> "
                             f"30-frame windows -> AR (way={self.way}) -> open-set score",
                 "per_gpu_batch": self.B, "seq_len": self.L, "n_joints": self.J, "way": self.way,
+                # consecutive steps (independent batches) overlap: each step's pose stage is ONE lane of whole-batch launches on its
+                # own engine + stream, pairs of steps start together, the pose ring / windows / match stage / all-gather follow in step
+                # order on a third stream. 1 = one step at a time, its batch split into two half-batch lanes (ISB_BENCH_INFLIGHT=1)
+                "steps_in_flight": self.n_flight,
                 "ar_precision": self.ar_precision,
                 "hpe_precision": self.hpe.precision + {"f16": " (IEEE fp16 weights and activations in every stage -- the reference's TensorRT precision, "
                                                               "7_create_engines.py:10; f32 accumulate, f32 head / decode, f64 reconstruction)",

@@ -190,6 +190,12 @@ int isb_hpe_forward(isb_hpe* h, const uint8_t* d_frames, const int32_t* d_bbox, 
                     uint8_t* d_valid, void* stream);
 int isb_hpe_forward_host(isb_hpe* h, const uint8_t* h_frames, const int32_t* h_bbox, int32_t B, float* h_joints,
                          uint8_t* h_valid);
+/* How a micro-batch of >= 64 frames is run: n_lanes = 2 (default; ISB_HPE_LANES overrides it at creation) splits it into two
+ * halves on two streams that fill each other's launch gaps; n_lanes = 1 keeps whole-batch launches on the caller's stream -- for a
+ * caller that keeps SEVERAL batches in flight itself (one engine per batch in flight, each on its own stream: two 256-frame
+ * batches side by side run 4 % faster per frame than one 256-frame batch split in halves, bench_workloads.py). Every frame is
+ * independent, so the choice changes no result bit. 1 <= n_lanes <= 4; synchronous (waits for the engine's work). */
+int isb_hpe_set_lanes(isb_hpe* h, int32_t n_lanes);
 /* The same call split in two for a caller that has batch k + 1 in hand while batch k computes (no counterpart in the
  * reference, whose Runner copies and waits inside one call, utils/tensorrt_runner.py:64-77):
  *   isb_hpe_submit_host  enqueues everything -- frames H2D on the copy engine (the handle's copy stream), the pose pass behind

@@ -72,6 +72,7 @@ SIGNATURES = {
     "isb_hpe_submit_host": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P]),
     "isb_hpe_wait_host": (C.c_int, [_P]),
     "isb_hpe_set_augmentations": (C.c_int, [_P, C.c_int32, _P, _P]),
+    "isb_hpe_set_lanes": (C.c_int, [_P, C.c_int32]),
     "isb_hpe_crop_params_host": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P]),
     "isb_hpe_warp_host": (C.c_int, [_P, _P, _P, C.c_int32, _P]),
     "isb_hpe_backbone_host": (C.c_int, [_P, _P, C.c_int32, _P, _P]),

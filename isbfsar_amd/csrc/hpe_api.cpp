@@ -772,6 +772,16 @@ extern "C" int isb_hpe_set_joint_map(isb_hpe* h, const float* expand, const int3
     });
 }
 
+extern "C" int isb_hpe_set_lanes(isb_hpe* h, int32_t n_lanes) {
+    return isb::guard([&]() -> int {
+        ISB_REQUIRE(h && n_lanes >= 1 && n_lanes <= kMaxLanes, ISB_ERR_INVALID, "n_lanes must be 1..%d", kMaxLanes);
+        ISB_HIP(hipSetDevice(h->cfg.device));
+        ISB_HIP(hipDeviceSynchronize());            // no forward pass of this engine is in flight when its lane count changes
+        h->n_lanes = n_lanes;
+        return ISB_OK;
+    });
+}
+
 extern "C" int isb_hpe_set_augmentations(isb_hpe* h, int32_t n_aug, const double* rotflip, const double* scales) {
     return isb::guard([&]() -> int {
     ISB_REQUIRE(h, ISB_ERR_INVALID, "null handle");

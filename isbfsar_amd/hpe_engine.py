@@ -121,6 +121,11 @@ class HpeEngine:
         _, joints, valid = self._inflight.pop(0)
         return joints, valid
 
+    def set_lanes(self, n_lanes: int):
+        """1 = whole-batch launches on the caller's stream (for callers that keep several batches in flight on several engines),
+        2 = the default split of a batch into two halves on two streams (isb_hpe_set_lanes). Changes no result bit."""
+        _lib.check(_lib.lib().isb_hpe_set_lanes(self._h, int(n_lanes)), "isb_hpe_set_lanes")
+
     # -- stage-level hooks ----------------------------------------------------------------
     def set_augmentations(self, num_aug: int):
         """Test-time augmentation (MetrabsTRTConfig.num_aug, hpe.py:88-93): crop_params / warp then return num_aug

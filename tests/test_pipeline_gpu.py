@@ -318,3 +318,36 @@ def test_record_gather_behind_the_c_abi_and_in_a_hipgraph():
             assert torch.equal(dst, (rec + k) * 2.0)
     finally:
         g.close()
+
+
+def test_two_steps_in_flight_give_the_bits_of_one_step_at_a_time(monkeypatch):
+    """bench_workloads keeps TWO consecutive steps in flight (each step's pose stage one lane of whole-batch launches on its own
+    engine and stream, pairs started together; pose ring, windows and match stage in step order on a third stream). The steps are
+    the steps of the one-at-a-time arrangement (ISB_BENCH_INFLIGHT=1: one engine, the batch split into the library's two half-batch
+    lanes): the same logits and open-set scores, bit for bit, step by step -- frames are independent units and the carried pose
+    ring is updated in step order."""
+    import argparse
+    import sys
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench_workloads as bw
+    args = argparse.Namespace(batch=64, way=8, precision="f16", hpe_precision="f16", dist_backend="nccl", force_dist=False)
+    outs = {}
+    for mode in ("2", "1"):
+        monkeypatch.setenv("ISB_BENCH_INFLIGHT", mode)
+        w = bw.PipelineWorkload(args, 0, 1, 0)
+        assert w.n_flight == int(mode) and (w.pose_streams is None) == (mode == "1")
+        steps = []
+        for i in range(5):
+            # a different batch every step: the frames of step i must meet the ring state of step i
+            w.frames = torch.roll(w.frames, shifts=3 * i + 1, dims=0)
+            w.step()
+            steps.append(w.out)
+        torch.cuda.synchronize()
+        outs[mode] = [[t.cpu().numpy().copy() for t in o] for o in steps]
+        for e in w.hpes:
+            e.close()
+        w.ar.close()
+    for a, b in zip(outs["2"], outs["1"]):
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert not np.array_equal(outs["2"][0][0], outs["2"][3][0])
