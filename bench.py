@@ -23,6 +23,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# before the HIP runtime starts: one hardware queue per stream this process keeps busy (three pose streams, the match stream, the
+# caller's stream, the library's copy stream); the runtime's default of four multiplexes them and serialises the third pose stream
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 

@@ -159,12 +159,16 @@ class _HpeBase:
         self.dev = dev
         self.bb_state = effnetv2.make_state(0)
         # Steps in flight. One step = one 256-frame batch through the pose stage. The library's own arrangement splits a batch into two
-        # 128-frame halves on two streams; keeping TWO whole batches in flight instead -- consecutive steps on two one-lane engines, each
-        # on its own stream, started pairwise -- runs 256-frame launches (better tiles, fewer workgroup rounds) that still fill each
+        # 128-frame halves on two streams; keeping SEVERAL whole batches in flight instead -- consecutive steps on one-lane engines, each
+        # on its own stream, started group by group -- runs 256-frame launches (better tiles, fewer workgroup rounds) that still fill each
         # other's gaps: 15.05 vs 15.7 ms per 256 frames (tools/exp_lane_offset.py 8 256). Consecutive batches are independent (the pose
         # ring that carries over is updated in step order on the match stream), every step still does all of its work, and the
         # timed region ends on a device-wide synchronize. ISB_BENCH_INFLIGHT=1 = one batch at a time on the library's two lanes.
-        self.n_flight = max(1, min(2, int(os.environ.get("ISB_BENCH_INFLIGHT", "2")))) if self.B >= 64 else 1
+        # three steps need a hardware queue per stream: HIP multiplexes streams onto GPU_MAX_HW_QUEUES (default 4) queues, and three pose
+        # streams + the match stream + the caller's on four queues serialise (19.3 ms per step against 17.55 on eight queues; two steps in
+        # flight: 17.75; four: 18.1-20.9). bench.py sets GPU_MAX_HW_QUEUES=8 before the runtime starts unless the caller has set it.
+        dflt = "3" if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) >= 8 else "2"
+        self.n_flight = max(1, min(4, int(os.environ.get("ISB_BENCH_INFLIGHT", dflt)))) if self.B >= 64 else 1
         self.hpe_precision_arg = getattr(args, "hpe_precision", "f16")
         self.hpes = [self._make_hpe(self.hpe_precision_arg) for _ in range(self.n_flight)]
         self.hpe = self.hpes[0]
@@ -206,7 +210,7 @@ class _HpeBase:
             joints, valid = self.hpes[k].forward(frames, bbox)
             self.pose_done = torch.cuda.Event()
             self.pose_done.record(ps)
-        if k == self.n_flight - 1:                            # a pair is enqueued: the next pair starts when both are through
+        if k == self.n_flight - 1:                            # a group is enqueued: the next group starts when all of it is through
             for a in self.pose_streams:
                 for b in self.pose_streams:
                     if a is not b:
@@ -389,7 +393,7 @@ class PipelineWorkload(_HpeBase):
         joints, valid = self._pose(self.frames, bbox)                            # [B,122,3]
         # everything behind the pose stage -- the pose ring (carried from step to step), the windows, the match stage, the all-gather
         # -- runs in step order on the match stream; with one batch in flight on one GPU that is the current stream
-        ms = self.side
+        ms = self.side if (not self.serial or self.world > 1) else None      # (one step at a time on one GPU: everything on the caller's stream)
         if ms is not None:
             ms.wait_stream(torch.cuda.current_stream())
             if self.pose_done is not None:
@@ -416,12 +420,14 @@ class PipelineWorkload(_HpeBase):
     def roofline(self, steps):
         r = self._hpe_roofline(steps)
         # the match stage's dominant kernel in the same line: ar_proto_all over this step's windows (HIP events on its launch stream)
+        self.serial = True              # (alone on the chip, like the convolution family above: a kernel's duration, not its share of an overlap)
         self.ar.profile(True)
         for _ in range(steps):
             self.step()
         self.torch.cuda.synchronize()
         ms, launches = self.ar.profile_read()
         self.ar.profile(False)
+        self.serial = False
         T = self.L * (self.L - 1) // 2
         fl = self.B * self.way * 2 * (2 * T * T * 128)
         ach = fl / (ms / max(launches, 1) / 1e3) / 1e12 if ms > 0 else None
@@ -630,7 +636,7 @@ class PipelineWorkload(_HpeBase):
                             f"30-frame windows -> AR (way={self.way}) -> open-set score",
                 "per_gpu_batch": self.B, "seq_len": self.L, "n_joints": self.J, "way": self.way,
                 # consecutive steps (independent batches) overlap: each step's pose stage is ONE lane of whole-batch launches on its
-                # own engine + stream, pairs of steps start together, the pose ring / windows / match stage / all-gather follow in step
+                # own engine + stream, groups of steps start together, the pose ring / windows / match stage / all-gather follow in step
                 # order on a third stream. 1 = one step at a time, its batch split into two half-batch lanes (ISB_BENCH_INFLIGHT=1)
                 "steps_in_flight": self.n_flight,
                 "ar_precision": self.ar_precision,

@@ -321,8 +321,8 @@ def test_record_gather_behind_the_c_abi_and_in_a_hipgraph():
 
 
 def test_two_steps_in_flight_give_the_bits_of_one_step_at_a_time(monkeypatch):
-    """bench_workloads keeps TWO consecutive steps in flight (each step's pose stage one lane of whole-batch launches on its own
-    engine and stream, pairs started together; pose ring, windows and match stage in step order on a third stream). The steps are
+    """bench_workloads keeps several (two or three) consecutive steps in flight (each step's pose stage one lane of whole-batch launches on its own
+    engine and stream, groups started together; pose ring, windows and match stage in step order on a third stream). The steps are
     the steps of the one-at-a-time arrangement (ISB_BENCH_INFLIGHT=1: one engine, the batch split into the library's two half-batch
     lanes): the same logits and open-set scores, bit for bit, step by step -- frames are independent units and the carried pose
     ring is updated in step order."""
@@ -333,7 +333,7 @@ def test_two_steps_in_flight_give_the_bits_of_one_step_at_a_time(monkeypatch):
     import bench_workloads as bw
     args = argparse.Namespace(batch=64, way=8, precision="f16", hpe_precision="f16", dist_backend="nccl", force_dist=False)
     outs = {}
-    for mode in ("2", "1"):
+    for mode in ("3", "2", "1"):
         monkeypatch.setenv("ISB_BENCH_INFLIGHT", mode)
         w = bw.PipelineWorkload(args, 0, 1, 0)
         assert w.n_flight == int(mode) and (w.pose_streams is None) == (mode == "1")
@@ -348,6 +348,7 @@ def test_two_steps_in_flight_give_the_bits_of_one_step_at_a_time(monkeypatch):
         for e in w.hpes:
             e.close()
         w.ar.close()
-    for a, b in zip(outs["2"], outs["1"]):
-        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    for many in ("3", "2"):
+        for a, b in zip(outs[many], outs["1"]):
+            assert all(np.array_equal(x, y) for x, y in zip(a, b))
     assert not np.array_equal(outs["2"][0][0], outs["2"][3][0])
