@@ -6,8 +6,8 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 echo "== PMC traffic"
-ISB_HPE_LANES=1 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o run -- python3 bench.py --workload hpe --steps 1 --warmup 1 --no-cpu-baseline --no-extras --min-gpu-seconds 0 > gpurun_out/pmc_fetch.log 2>&1
-ISB_HPE_LANES=1 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o run -- python3 bench.py --workload hpe --steps 1 --warmup 1 --no-cpu-baseline --no-extras --min-gpu-seconds 0 > gpurun_out/pmc_write.log 2>&1
+ISB_BENCH_INFLIGHT=1 ISB_HPE_LANES=1 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o run -- python3 bench.py --workload hpe --steps 1 --warmup 1 --no-cpu-baseline --no-extras --min-gpu-seconds 0 > gpurun_out/pmc_fetch.log 2>&1
+ISB_BENCH_INFLIGHT=1 ISB_HPE_LANES=1 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o run -- python3 bench.py --workload hpe --steps 1 --warmup 1 --no-cpu-baseline --no-extras --min-gpu-seconds 0 > gpurun_out/pmc_write.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_ar_fetch -o run -- python3 bench.py --workload ar --steps 1 --warmup 1 --no-cpu-baseline --no-extras --min-gpu-seconds 0 > gpurun_out/pmc_ar_fetch.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_ar_write -o run -- python3 bench.py --workload ar --steps 1 --warmup 1 --no-cpu-baseline --no-extras --min-gpu-seconds 0 > gpurun_out/pmc_ar_write.log 2>&1
 python3 tools/collect_traffic.py gpurun_out/pmc_fetch/run_counter_collection.csv gpurun_out/pmc_write/run_counter_collection.csv gpurun_out/traffic.json gpurun_out/pmc_ar_fetch/run_counter_collection.csv gpurun_out/pmc_ar_write/run_counter_collection.csv
@@ -32,7 +32,7 @@ for f in ar_bf16x3 ar_bf16 hpe_host hpe_host_wholeframes hpe_host_pipelined hpe_
 echo "== kernel stats (pipeline)"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_pipe -o run -- python3 bench.py --workload pipeline --steps 5 --warmup 2 --no-cpu-baseline --no-extras --min-gpu-seconds 0 > gpurun_out/prof_pipe.log 2>&1
 echo "== kernel stats (hpe, one lane: every convolution launch is a 256-frame launch, as in bench.py's roofline pass)"
-ISB_HPE_LANES=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_hpe1 -o run -- python3 bench.py --workload hpe --steps 5 --warmup 2 --no-cpu-baseline --min-gpu-seconds 0 > gpurun_out/prof_hpe1.log 2>&1
+ISB_BENCH_INFLIGHT=1 ISB_HPE_LANES=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_hpe1 -o run -- python3 bench.py --workload hpe --steps 5 --warmup 2 --no-cpu-baseline --min-gpu-seconds 0 > gpurun_out/prof_hpe1.log 2>&1
 python3 tools/family_avg.py gpurun_out/prof_hpe1/run_kernel_stats.csv gpurun_out/bench_hpe.json
 python3 tools/layer_breakdown.py gpurun_out/prof_hpe1/run_kernel_trace.csv > gpurun_out/layer_breakdown.txt 2>&1 || true
 python3 tools/dw_breakdown.py gpurun_out/prof_hpe1/run_kernel_trace.csv > gpurun_out/dw_breakdown.txt 2>&1 || true
@@ -42,11 +42,11 @@ python3 tools/det_breakdown.py gpurun_out/prof_det/run_kernel_trace.csv > gpurun
 echo "== kernel stats (ar)"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_ar -o run -- python3 bench.py --workload ar --steps 3 --warmup 1 --no-cpu-baseline --min-gpu-seconds 0 > gpurun_out/prof_ar.log 2>&1
 echo "== PMC matrix-pipe utilisation (SQ counters + GRBM_GUI_ACTIVE, own passes)"
-ISB_HPE_LANES=1 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_mfma_hpe -o run -- python3 bench.py --workload hpe --steps 1 --warmup 1 --no-cpu-baseline --no-extras --min-gpu-seconds 0 > gpurun_out/pmc_mfma_hpe.log 2>&1
+ISB_BENCH_INFLIGHT=1 ISB_HPE_LANES=1 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_mfma_hpe -o run -- python3 bench.py --workload hpe --steps 1 --warmup 1 --no-cpu-baseline --no-extras --min-gpu-seconds 0 > gpurun_out/pmc_mfma_hpe.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_mfma_ar -o run -- python3 bench.py --workload ar --steps 1 --warmup 1 --no-cpu-baseline --no-extras --min-gpu-seconds 0 > gpurun_out/pmc_mfma_ar.log 2>&1
 python3 tools/collect_mfma.py gpurun_out/mfma_hpe.json gpurun_out/pmc_mfma_hpe/run_counter_collection.csv
 python3 tools/collect_mfma.py gpurun_out/mfma_ar.json gpurun_out/pmc_mfma_ar/run_counter_collection.csv
 echo "== SQ counters of the three MFMA-bound early-stage kernels (VERDICT r3 item 5), own pass"
-ISB_HPE_LANES=1 timeout -k 10 300 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d gpurun_out/pmc_lds_hpe -o run -- python3 bench.py --workload hpe --steps 1 --warmup 1 --no-cpu-baseline --no-extras --min-gpu-seconds 0 > gpurun_out/pmc_lds_hpe.log 2>&1 || true
+ISB_BENCH_INFLIGHT=1 ISB_HPE_LANES=1 timeout -k 10 300 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d gpurun_out/pmc_lds_hpe -o run -- python3 bench.py --workload hpe --steps 1 --warmup 1 --no-cpu-baseline --no-extras --min-gpu-seconds 0 > gpurun_out/pmc_lds_hpe.log 2>&1 || true
 python3 tools/collect_lds.py gpurun_out/lds_hpe.json gpurun_out/pmc_lds_hpe/run_counter_collection.csv || true
 echo done
