@@ -7,6 +7,7 @@ at ONE rounding point / stage at a time (effnetv2_oracle.EffNetV2LOracle(roundin
 mixed layouts (fp16 in the last stages, f32 or hi+lo residual stream in the MBConv stages, ...). CPU only, torch fp32 convolutions.
 
     python -m oracle.error_budget [--frames 4] [--profile default|signal|both] [--quick]
+    python -m oracle.error_budget --silu [--frames 8]       # cheaper SiLU arithmetic under the product's storage layout (round 5)
 
 Writes a table to stdout (kept in DESIGN.md section 4 and profiles/r03_pose_error_budget.txt).
 """
@@ -92,13 +93,87 @@ def policies(quick=False):
     return P
 
 
+def silu_forms():
+    """Cheaper SiLUs priced BEFORE anyone builds them: what does the pose lose if the activation's two
+    transcendentals and three plain operations (x * rcp(1 + exp2(-x log2 e)), f32: ~23 issue cycles per element and wave, 37 % of the
+    fused 16x16 front's time) run in a cheaper arithmetic? Every form is the same expression; what changes is where its intermediate
+    results are rounded. name -> callable(x: f32 tensor) -> f32 tensor (the value that is then rounded to the 16-bit storage type)."""
+    import torch
+    h = lambda t: t.clamp(-65504.0, 65504.0).half().float()       # one fp16 rounding (saturating like the device)
+    b = lambda t: t.bfloat16().float()
+    L2E = 1.4426950408889634
+
+    def exact(x):
+        return x * torch.sigmoid(x)
+
+    def f32_fast(x):                  # the product: v_exp_f32 / v_rcp_f32 (each ~1 ulp), f32 multiplies
+        return x * (1.0 / (1.0 + torch.exp2(-L2E * x)))
+
+    def f16_all(x):                   # everything in fp16: v_cvt, v_pk_mul_f16, v_exp_f16, v_pk_add_f16, v_rcp_f16, v_pk_mul_f16
+        xh = h(x)
+        e = h(torch.exp2(h(-L2E * xh)))
+        return h(xh * h(1.0 / h(1.0 + e)))
+
+    def f16_transc(x):                # f32 multiplies and add, only the two transcendentals in fp16 (v_exp_f16 / v_rcp_f16)
+        e = h(torch.exp2(h(-L2E * x)))
+        return x * h(1.0 / h(1.0 + e))
+
+    def f16_rcp(x):                   # v_exp_f32, the reciprocal in fp16
+        return x * h(1.0 / h(1.0 + torch.exp2(-L2E * x)))
+
+    def bf16_gate(x):                 # sigmoid rounded to bf16 before the multiply (an 8-bit gate)
+        return x * b(1.0 / (1.0 + torch.exp2(-L2E * x)))
+
+    return {"exact x * sigmoid(x) in f32 (the definition)": exact,
+            "f32 exp2 / rcp (PRODUCT: silu_fast)": f32_fast,
+            "exp2 and rcp in fp16, f32 multiplies": f16_transc,
+            "rcp in fp16 only": f16_rcp,
+            "everything in fp16 (packed fp16 multiplies, fp16 transcendentals)": f16_all,
+            "sigmoid rounded to bf16": bf16_gate}
+
+
+def silu_study(a, crops, nks, rs, W, idx):
+    """The product's storage layout (fp16 everywhere) with each SiLU form, against the fp32 definition, on both weight profiles."""
+    from oracle import effnetv2_oracle as eo
+    pol = lambda s, p: "f16"
+    res = {}
+    for prof in (["default", "signal"] if a.profile == "both" else [a.profile]):
+        # the "signal" profile as tests/test_hpe_gpu.py and bench.py judge it: head gain 0.5 (peaked but not one-hot heat-maps)
+        state = effnetv2.make_state(0, profile=prof) if prof == "default" else effnetv2.make_state(0, prof, head_gain=0.5)
+        base = _poses(EffNetV2LOracle(state, "f32"), crops, nks, rs, W, idx)
+        print(f"# profile {prof}: {a.frames} frames; storage fp16 in every stage; columns: max-abs against the fp32 definition", flush=True)
+        print(f"{'SiLU form':72s} {'pred3d':>9s} {'pred2d px':>9s} {'root-c.':>9s} {'absolute':>9s}")
+        res[prof] = {}
+        keep = eo._silu
+        try:
+            for name, fn in silu_forms().items():
+                eo._silu = fn
+                e = _errs(_poses(EffNetV2LOracle(state, "f32", rounding=pol), crops, nks, rs, W, idx), base)
+                res[prof][name] = e
+                print(f"{name:72s} {e['pred3d']:9.2e} {e['pred2d_px']:9.2e} {e['rc']:9.2e} {e['abs']:9.2e}", flush=True)
+        finally:
+            eo._silu = keep
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=4)
     ap.add_argument("--profile", default="both")
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--silu", action="store_true", help="price cheaper SiLU arithmetic under the product's fp16 storage layout")
     ap.add_argument("--json", default=None)
     a = ap.parse_args()
+    if a.silu:
+        assets = os.path.join(ROOT, "isbfsar_amd", "assets")
+        W = np.load(os.path.join(assets, "32_to_122.npy"))
+        idx = json.load(open(os.path.join(assets, "skeleton_types.json")))["smpl+head_30"]["indices"]
+        crops, nks, rs = _inputs(a.frames)
+        res = silu_study(a, crops, nks, rs, W, idx)
+        if a.json:
+            with open(a.json, "w") as f:
+                json.dump(res, f, indent=1)
+        return
     assets = os.path.join(ROOT, "isbfsar_amd", "assets")
     W = np.load(os.path.join(assets, "32_to_122.npy"))
     idx = json.load(open(os.path.join(assets, "skeleton_types.json")))["smpl+head_30"]["indices"]
