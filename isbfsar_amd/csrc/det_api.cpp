@@ -213,7 +213,7 @@ int run(isb_det* d, hipStream_t st, const uint8_t* d_frames, int B, float* d_box
             case OP_STEM: {
                 const DetConv& c = d->convs[o.conv];
                 StemArgs a{};
-                a.in = d->tens[o.in0].buf.as<float>(); a.w = c.w.as<float>(); a.bias = c.bias.as<float>();
+                a.in = d->tens[o.in0].buf.as<float>(); a.w = c.w.as<float>(); a.wt = c.w.as<float>() + 32 * 27; a.bias = c.bias.as<float>();
                 a.out = d->tens[o.out].buf.as<uint16_t>(); a.B = B; a.H = 256; a.W = 256;
                 ISB_TRY(launch_det_stem(a, st));
                 break;
@@ -365,9 +365,14 @@ extern "C" int isb_det_load_weights(isb_det* d, const void* blob, size_t nbytes)
         const size_t kk = (size_t)c.k * c.k * c.cin;
         if (i == 0) {                       // first conv: f32 [32][27], scale folded
             ISB_REQUIRE(c.cin == 3 && c.cout == 32 && c.k == 3, ISB_ERR_WEIGHTS, "internal: first layer is not the 3 -> 32 stem");
-            std::vector<float> wf(32 * 27);
+            // [32][27] row-major, then the same weights pair-major [16][27][2] (det_stem_kernel: a channel pair's taps are 54 consecutive
+            // scalars, one v_pk_fma_f32 per pair and tap)
+            std::vector<float> wf(2 * 32 * 27);
             for (int o = 0; o < 32; ++o)
-                for (int k = 0; k < 27; ++k) wf[o * 27 + k] = w.data[o * 27 + k] * sc->data[o];
+                for (int k = 0; k < 27; ++k) {
+                    wf[o * 27 + k] = w.data[o * 27 + k] * sc->data[o];
+                    wf[32 * 27 + ((o >> 1) * 27 + k) * 2 + (o & 1)] = wf[o * 27 + k];
+                }
             ISB_TRY(upload(c.w, wf.data(), wf.size() * 4));
             ISB_TRY(upload(c.bias, sh->data, 32 * 4));
             c.cout_pad = 32;

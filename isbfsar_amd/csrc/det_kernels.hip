@@ -62,10 +62,17 @@ int launch_det_preprocess(const uint8_t* frames, int B, int FH, int FW, float* o
 // ------------------------------------------------------------------------------------------
 // first convolution: 3 -> 32, 3x3, stride 1, pad 1, bias (folded BN), Mish. thread = one output pixel, all 32 channels.
 // ------------------------------------------------------------------------------------------
+// (round 5, as the pose backbone's stem_kernel: 570 us per 256 frames at the vector ALU's issue rate before) channel PAIRS on v_pk_fma_f32
+// with pair-major scalar weights -- the bits of the scalar chain --, unconditional tap loads from clamped addresses with the select on the
+// value, 32-bit indexing on a (pixels / 256, B) grid, 1-KiB pixel rows stored through LDS.
 __global__ __launch_bounds__(256) void det_stem_kernel(StemArgs p) {
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (size_t)p.B * p.H * p.W) return;
-    const int ox = (int)(idx % p.W), oy = (int)((idx / p.W) % p.H), b = (int)(idx / ((size_t)p.W * p.H));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const unsigned pix = blockIdx.x * 256u + threadIdx.x;
+    const unsigned npix = (unsigned)(p.H * p.W);
+    if (pix - (threadIdx.x & 63) >= npix) return;                  // (whole waves only: a wave's lanes store for one another)
+    const unsigned pixc = min(pix, npix - 1u);
+    const int b = blockIdx.y, oy = (int)(pixc / (unsigned)p.W), ox = (int)(pixc - (unsigned)oy * (unsigned)p.W);
+    const size_t idx = (size_t)b * npix + pix;
     float x[27];
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
@@ -73,34 +80,45 @@ __global__ __launch_bounds__(256) void det_stem_kernel(StemArgs p) {
         for (int kx = 0; kx < 3; ++kx) {
             const int iy = oy - 1 + ky, ix = ox - 1 + kx;
             const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const float* src = p.in + ((size_t)(b * p.H + (ok ? iy : 0)) * p.W + (ok ? ix : 0)) * 3;
+            const float* src = p.in + ((size_t)(b * p.H + min(max(iy, 0), p.H - 1)) * p.W + min(max(ix, 0), p.W - 1)) * 3;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) x[(ky * 3 + kx) * 3 + c] = ok ? src[c] : 0.f;
+            for (int c = 0; c < 3; ++c) {
+                const float v = src[c];
+                x[(ky * 3 + kx) * 3 + c] = ok ? v : 0.f;
+            }
         }
+    const f32x2_t* w2 = reinterpret_cast<const f32x2_t*>(p.wt);
+    const f32x2_t* b2 = reinterpret_cast<const f32x2_t*>(p.bias);
     uint32_t o[16];
 #pragma unroll
-    for (int co = 0; co < 32; co += 2) {
-        float a0 = p.bias[co], a1 = p.bias[co + 1];
+    for (int c2 = 0; c2 < 16; ++c2) {                  // one channel pair at a time: its 27 weight pairs fit the scalar registers
+        f32x2_t acc = b2[c2];
 #pragma unroll
         for (int k = 0; k < 27; ++k) {
-            a0 = fmaf(x[k], p.w[co * 27 + k], a0);
-            a1 = fmaf(x[k], p.w[(co + 1) * 27 + k], a1);
+            const f32x2_t xk = {x[k], x[k]};
+            acc = __builtin_elementwise_fma(xk, w2[c2 * 27 + k], acc);
         }
         // Mish as every other layer computes it (one v_exp + one v_rcp; with the exact library functions -- expf, log1pf, tanhf
         // per output -- this launch took 570 us per 64 frames, 12 % of the detector)
-        a0 = mish_stem(a0);
-        a1 = mish_stem(a1);
-        o[co >> 1] = (uint32_t)f2bf_d(a0) | ((uint32_t)f2bf_d(a1) << 16);
+        o[c2] = (uint32_t)f2bf_d(mish_stem(acc.x)) | ((uint32_t)f2bf_d(mish_stem(acc.y)) << 16);
     }
-    uint4* dst = reinterpret_cast<uint4*>(p.out + idx * 32);
-    dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
-    dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
-    dst[2] = make_uint4(o[8], o[9], o[10], o[11]);
-    dst[3] = make_uint4(o[12], o[13], o[14], o[15]);
+    __shared__ __attribute__((aligned(16))) unsigned char tile[256 * 64];
+    const int t = threadIdx.x, sw = (t >> 2) & 3;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        *reinterpret_cast<uint4*>(tile + t * 64 + ((c ^ sw) << 4)) = make_uint4(o[4 * c], o[4 * c + 1], o[4 * c + 2], o[4 * c + 3]);
+    const int lane = t & 63, w0 = t & ~63, cc = lane & 3;
+    uint16_t* const base = p.out + (idx - lane) * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pp = (lane >> 2) + 16 * i;
+        const uint4 v = *reinterpret_cast<const uint4*>(tile + (w0 + pp) * 64 + ((cc ^ ((pp >> 2) & 3)) << 4));
+        if (pix - lane + pp < npix) *reinterpret_cast<uint4*>(base + pp * 32 + cc * 8) = v;
+    }
 }
 
 int launch_det_stem(const StemArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(det_stem_kernel, dim3((unsigned)cdivz((size_t)a.B * a.H * a.W, 256)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(det_stem_kernel, dim3((unsigned)cdiv(a.H * a.W, 256), (unsigned)a.B), dim3(256), 0, st, a);
     ISB_LAUNCHED("det_stem", st);
     return ISB_OK;
 }
