@@ -934,3 +934,29 @@ def test_fused_front_of_the_16x16_blocks_is_bit_identical(bbone_state, assets, m
     assert np.isfinite(res["1"][0]).all() and float(np.abs(res["1"][0]).max()) > 0
     for a, b in zip(res["1"], res["0"]):
         assert np.array_equal(a, b)
+
+
+def test_set_lanes_changes_no_bit_and_refuses_nonsense(bbone_state, assets):
+    """isb_hpe_set_lanes (round 5): 1 = whole-batch launches on the caller's stream (for callers that keep several batches in flight on
+    several engines), 2 = the default split into two half-batch lanes. Frames are independent: the same bits either way; lane counts
+    outside 1..4 are refused with ISB_ERR_INVALID."""
+    from isbfsar_amd._lib import IsbError
+    from isbfsar_amd.hpe_engine import HpeEngine
+    e = HpeEngine(device=0, max_batch=72)
+    try:
+        e.set_joint_map(assets[0], assets[1]["smpl+head_30"]["indices"])
+        e.load_weights(bbone_state)
+        fr = synth.frames(70, seed=301)
+        bb = synth.bboxes(70, seed=301)
+        j2, v2 = e.forward(fr, bb)                              # 35 + 35 on two lanes
+        e.set_lanes(1)
+        j1, v1 = e.forward(fr, bb)                              # one 70-frame lane
+        assert np.array_equal(j1, j2) and np.array_equal(v1, v2) and v1.sum() > 0
+        for bad in (0, 5, -1):
+            with pytest.raises(IsbError):
+                e.set_lanes(bad)
+        e.set_lanes(2)
+        j2b, _ = e.forward(fr, bb)
+        assert np.array_equal(j2b, j2)
+    finally:
+        e.close()
