@@ -24,8 +24,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 # before the HIP runtime starts: one hardware queue per stream this process keeps busy (three pose streams, the match stream, the
-# caller's stream, the library's copy stream); the runtime's default of four multiplexes them and serialises the third pose stream
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# caller's stream, the library's copy stream); the runtime's default of four multiplexes them and serialises the third pose stream.
+# The library asks for eight when it is loaded (isb_hw_queues, include/isbfsar.h: GPU_MAX_HW_QUEUES, unless the caller's environment
+# holds a value), so load it before anything makes a HIP call.
+from isbfsar_amd import _lib as _isb_lib  # noqa: E402
+
+_isb_lib.lib()
 
 import numpy as np  # noqa: E402
 
@@ -269,6 +273,10 @@ def main():
     # would wait on forever; only rank 0's numbers are reported
     roof = W.roofline(max(1, min(args.steps, 3)))
     barrier()
+    # K steps in flight: `value` is overlapped throughput. The same steps one at a time through one engine and a step's latency under
+    # overlap are first-class fields of the line (every rank steps: the steps hold the all-gather)
+    in_flight = W.in_flight_report(args.steps) if hasattr(W, "in_flight_report") else None
+    barrier()
     # N > 1: the gathered records of one step against an unsharded recomputation (rank 0), and RCCL's own count of the ranks
     gather_check, rccl_ranks = None, None
     if dist_on:
@@ -310,6 +318,11 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": W.precision if hasattr(W, "precision") else "bf16", "data": "synthetic",
             "config": dict(W.config(world), rccl_ranks=rccl_ranks, **(extras or {})), "roofline": roof, "cpu_baseline": cpu,
+            # K > 1 steps in flight (config.steps_in_flight): `value` / `ms_per_step` are overlapped throughput, a step is FINISHED every
+            # ms_per_step. in_flight.one_step_in_flight = the same steps one at a time through one engine (one isb_hpe_forward per step, the
+            # library's two half-batch lanes), in_flight.step_latency_ms = a step's first launch -> its last kernel under overlap,
+            # in_flight.engines = the engines share ONE device copy of the weights (isb_hpe_create_shared). null: one step at a time.
+            "in_flight": in_flight,
             # error half of BASELINE.json's metric ("...; open-set score L2 vs ref"): GPU outputs against the CPU oracle
             # on the cpu_baseline sample (same inputs); null when the CPU leg is skipped (N > 1, --no-cpu-baseline)
             "parity": getattr(W, "parity", None),

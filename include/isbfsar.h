@@ -61,6 +61,14 @@ int isb_version(void);
 int isb_wsreg_verified(void);
 /* number of visible HIP devices (does not initialise a context) */
 int isb_device_count(void);
+/* Hardware queues the HIP runtime multiplexes this process's streams onto (GPU_MAX_HW_QUEUES; the runtime reads it once, at its
+ * first call, default 4). Engines kept in flight on their own streams (isb_hpe_create_shared) need a queue each plus the caller's: with
+ * four, a third pose stream serialises behind another stream of the process (19.3 vs 17.55 ms per 256-frame pipeline step). The
+ * library asks for 8 when it is LOADED unless the caller's environment already holds a value; that takes effect iff no HIP call has
+ * been made in the process before (import / dlopen the library before the first HIP call, or export the variable yourself).
+ * Returns the value the runtime reads from the environment; *source (may be NULL): 0 = unset (default 4), 1 = set by the caller,
+ * 2 = set by this library at load time. No HIP call is made. */
+int isb_hw_queues(int32_t* source);
 
 /* ------------------------------------------------------------------------------------------
  * Action recognition: TRXOS skeleton branch + Discriminator
@@ -172,6 +180,19 @@ typedef struct isb_hpe_cfg {
 
 int isb_hpe_create(const isb_hpe_cfg* cfg, isb_hpe** out);
 void isb_hpe_destroy(isb_hpe* h);
+/* One more engine on the parent's device weights (no counterpart in the reference, whose worker owns one set of TensorRT engines and
+ * runs one frame at a time, utils/tensorrt_runner.py:64-77; main.py:336-342): the child READS the parent's model -- folded and packed
+ * weights, joint map; 240 MB for EfficientNetV2-L -- and OWNS what a pass writes: its streams, events and activation workspaces. A
+ * caller that keeps K batches in flight (one engine per batch in flight, each isb_hpe_forward on its own stream; with
+ * isb_hpe_set_lanes(h, 1) every launch covers the whole batch) pays one model + K workspaces instead of K of each, and gets the same
+ * bits as one engine run batch after batch. The child copies the parent's configuration (device, precision, max_batch, lanes at the
+ * time of the call); isb_hpe_load_weights / isb_hpe_set_joint_map are refused on a child (ISB_ERR_STATE) and, on the parent, wait for
+ * the device and update the model every engine of the family reads. Either may be destroyed first. Needs a hardware queue per stream in
+ * flight: isb_hw_queues(). */
+int isb_hpe_create_shared(isb_hpe* parent, isb_hpe** out);
+/* device memory behind a handle: bytes of the model it reads (shared by *engines_on_model handles), bytes of the workspaces it owns
+ * (allocated lazily by the first passes). Any output may be NULL. */
+int isb_hpe_memory(isb_hpe* h, uint64_t* model_bytes, uint64_t* workspace_bytes, int32_t* engines_on_model);
 /* ISBW blob with bbone.* (EfficientNetV2-L, folded BN) and head.{weight,bias} (Linear(1280,288),
  * modules/hpe/setup/4_create_heads_onnx.py:10,22-25). Replaces the bbone1/heads1 engine
  * deserialisation (hpe.py:45-46). Synchronous. */

@@ -49,6 +49,7 @@ SIGNATURES = {
     "isb_version": (C.c_int, []),
     "isb_wsreg_verified": (C.c_int, []),
     "isb_device_count": (C.c_int, []),
+    "isb_hw_queues": (C.c_int, [C.POINTER(C.c_int32)]),
     "isb_ar_create": (C.c_int, [C.POINTER(isb_ar_cfg), C.POINTER(_P)]),
     "isb_ar_destroy": (None, [_P]),
     "isb_ar_precision": (C.c_int, [_P]),
@@ -73,6 +74,8 @@ SIGNATURES = {
     "isb_hpe_wait_host": (C.c_int, [_P]),
     "isb_hpe_set_augmentations": (C.c_int, [_P, C.c_int32, _P, _P]),
     "isb_hpe_set_lanes": (C.c_int, [_P, C.c_int32]),
+    "isb_hpe_create_shared": (C.c_int, [_P, C.POINTER(_P)]),
+    "isb_hpe_memory": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]),
     "isb_hpe_crop_params_host": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P]),
     "isb_hpe_warp_host": (C.c_int, [_P, _P, _P, C.c_int32, _P]),
     "isb_hpe_backbone_host": (C.c_int, [_P, _P, C.c_int32, _P, _P]),

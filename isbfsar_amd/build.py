@@ -100,8 +100,11 @@ def _disassemble(lib_path: str) -> str:
 def mbfront8_wait_counted(lib_path: str):
     """mbfront8_kernel (csrc/conv_mb8.hip) waits for the next sample's LDS-DMA input tiles with a hand-counted
     `s_waitcnt vmcnt(5)`: exactly five vector-memory operations (four 16-byte D-row stores, one pooled-means store) may be
-    issued between those requests and the wait. A register spill (scratch traffic counts in vmcnt) or a store the compiler
-    split would leave tiles in flight at the barrier and the MFMAs would read stale LDS -- silently. So the built
+    issued between those requests and the wait. vmcnt(N) waits until all but the N YOUNGEST vector-memory operations are done, so
+    the dangerous direction is FEWER operations behind the requests than counted (a store the compiler merged or dropped: the wait
+    would then let a tile piece stay in flight at the barrier and the MFMAs would read stale LDS -- silently); MORE
+    operations (spill traffic, a split store) only make the wait stricter, but they also mean the code is not the code that was
+    measured, so the check is an exact match either way and a future edit must not relax it towards "at most". So the built
     code is checked: every instantiation must be free of scratch instructions and hold exactly four global_store_dwordx4 and
     one global_store_dword between its loop's LDS-DMA requests and the end of the loop body (the stamp stores of the tuning
     probe follow the loop). Returns None when the library passes, else the reason."""
@@ -126,7 +129,9 @@ def mbfront8_wait_counted(lib_path: str):
         if "vmcnt(5)" not in " ".join(" ".join(t) for t in lines):
             return f"{name}: the counted wait is gone"
         # the loop body: from the LAST LDS-DMA request (the next sample's tiles) to the backward branch; stamp stores come after it
-        last_dma = max(i for i, o in enumerate(ops) if o == "global_load_lds_dwordx4")
+        last_dma = max((i for i, o in enumerate(ops) if o == "global_load_lds_dwordx4"), default=None)
+        if last_dma is None:          # (another lowering of the request, e.g. buffer_load ... lds: fail closed, not with a traceback)
+            return f"{name}: no global_load_lds_dwordx4 found -- the input requests are lowered differently than the check knows"
         vm = [o for o in ops[last_dma + 1:] if o.startswith(("global_", "buffer_", "flat_"))]
         body = vm[:5]
         if sorted(body) != ["global_store_dword"] + ["global_store_dwordx4"] * 4:

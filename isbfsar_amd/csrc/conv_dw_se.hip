@@ -737,7 +737,7 @@ int launch_se_fcs(const SeFcArgs& a, hipStream_t st) {
 // f32 crop [B,256,256,3] -> bf16 [B,128,128,32]. thread = one output pixel, all 32 channels;
 // weights [16 channel pairs][27 taps][2] f32 (scale folded) are wave-uniform -> scalar loads, 54 consecutive floats per pair.
 // =====================================================================================
-template <bool OUT_F16>
+template <bool OUT_F16, int SILU>
 __global__ __launch_bounds__(256) void stem_kernel(StemArgs p) {
     const int OH = p.H / 2, OW = p.W / 2;
     const unsigned pix = blockIdx.x * 256u + threadIdx.x;       // grid = (pixels of an image / 256, B): 32-bit index arithmetic
@@ -775,7 +775,10 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs p) {
             const f32x2_t xk = {x[k], x[k]};
             acc = __builtin_elementwise_fma(xk, w2[c2 * 27 + k], acc);
         }
-        const float a0 = silu_fast(acc.x), a1 = silu_fast(acc.y);
+        // SILU 0: x * v_rcp(1 + v_exp(..)) (1 ulp each); 1: the reciprocal refined by one Newton step (the stem's output is what all 79 blocks
+        // amplify: the hard weight profile's distance to fp32, priced in EXPERIMENTS.md round 6); 2: IEEE division (round 4's form)
+        const float a0 = SILU == 2 ? silu_(acc.x) : SILU == 1 ? silu_nr(acc.x) : silu_fast(acc.x);
+        const float a1 = SILU == 2 ? silu_(acc.y) : SILU == 1 ? silu_nr(acc.y) : silu_fast(acc.y);
         o[c2] = OUT_F16 ? ((uint32_t)f2h_(a0) | ((uint32_t)f2h_(a1) << 16)) : ((uint32_t)f2bf_(a0) | ((uint32_t)f2bf_(a1) << 16));
     }
     // a lane holds its pixel's 64 bytes; stored from here every instruction would write 16 bytes into each of 64 different rows. Through
@@ -799,8 +802,14 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs p) {
 
 int launch_stem(const StemArgs& a, hipStream_t st) {
     const dim3 grid((unsigned)cdiv((a.H / 2) * (a.W / 2), 256), (unsigned)a.B);
-    if (a.out_f16) hipLaunchKernelGGL(stem_kernel<true>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(stem_kernel<false>, grid, dim3(256), 0, st, a);
+    static const int silu = [] { const char* e = getenv("ISB_STEM_SILU"); return e ? atoi(e) : 0; }();
+    if (a.out_f16) {
+        if (silu == 2) hipLaunchKernelGGL((stem_kernel<true, 2>), grid, dim3(256), 0, st, a);
+        else if (silu == 1) hipLaunchKernelGGL((stem_kernel<true, 1>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((stem_kernel<true, 0>), grid, dim3(256), 0, st, a);
+    } else {
+        hipLaunchKernelGGL((stem_kernel<false, 0>), grid, dim3(256), 0, st, a);
+    }
     ISB_LAUNCHED("stem", st);
     return ISB_OK;
 }

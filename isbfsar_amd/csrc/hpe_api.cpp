@@ -64,12 +64,29 @@ struct Lane {
     void* Y = nullptr;
 };
 
+// Everything an engine READS during a forward pass and never writes: the folded / packed weights, the joint map, the zero line.
+// An engine family (isb_hpe_create + isb_hpe_create_shared) holds one of these on the device -- 240 MB for EfficientNetV2-L --
+// while every engine owns its streams, events and activation workspaces (the part that is written).
+struct HpeModel {
+    bool weights = false, jointmap = false;
+    int n_out = 0;
+    DevBuf stem_w, stem_wt, stem_b;
+    std::vector<std::unique_ptr<BlockW>> blocks;
+    ConvW headconv;
+    DevBuf head_w, head_b;
+    DevBuf expand, indices;
+    bool has_indices = false;
+    DevBuf zeros;
+    int mb8_first = -1, mb8_count = 0;
+    DevBuf mb8_desc;
+    size_t device_bytes() const;
+};
+
 }  // namespace
 
 struct isb_hpe {
     isb_hpe_cfg cfg{};
     hipStream_t own_stream = nullptr;
-    bool weights = false, jointmap = false;
     // the stride-1 MBConv blocks of the two 8 x 8 stages (blocks mb8_first .. + mb8_count) as ONE launch (conv_mb8.hip: a workgroup
     // owns a sample for the whole chain; bit-identical to the five-launch path, tested). MEASURED SLOWER (round 4: 22.0 vs 16.7 ms per
     // 256-frame pose step; a 384 -> 2304 -> 384 block 545 k cycles against ~310 k for its five launches): every workgroup pulls ALL of
@@ -88,8 +105,6 @@ struct isb_hpe {
     bool mbf8_on = true;          // ISB_MBF8=0: expand GEMM + depthwise kernel (the bit-identity test's reference)
     int mbf8_min_batch = 32;
     int mb8_min_batch = 48;
-    int mb8_first = -1, mb8_count = 0;
-    DevBuf mb8_desc;
     DevBuf mb8_stamps;            // tuning probe (isb_debug_hpe_mb8_stamps)
     bool fuse_se = true;          // single-frame split-K projections compute their SE gate in the GEMM; ISB_FUSE_SE=0 disables (tests)
     // 16-bit storage type per stage: stages >= f16_from (index into kStages) and the 640 -> 1280 convolution keep activations AND
@@ -98,20 +113,14 @@ struct isb_hpe {
     // run (7_create_engines.py:10; f16_from = 0, the stem stores fp16 too); 3 = bf16 with fp16 in the two 8x8 stages (round 3's
     // layout; f16_from = 5); 1 = bf16 everywhere (f16_from = 7)
     int f16_from = 0;
-    int n_out = 0;
     double K[9] = {0};
-    // weights
-    DevBuf stem_w, stem_wt, stem_b;
-    std::vector<std::unique_ptr<BlockW>> blocks;
-    ConvW headconv;
-    DevBuf head_w, head_b;
-    DevBuf expand, indices;
-    bool has_indices = false;
+    // weights: ONE device copy per engine family (isb_hpe_create_shared: the children hold the parent's model)
+    std::shared_ptr<HpeModel> m;
+    isb_hpe* parent = nullptr;    // non-null in an engine made by isb_hpe_create_shared (informational: the model is kept alive by `m`)
     // test-time augmentation tables (hpe.py:88-93); n_aug = 0: off
     int n_aug = 0;
     DevBuf aug_rotflip, aug_scale;
     // workspace
-    DevBuf zeros;
     Lane lanes[kMaxLanes];
     int n_lanes = 2;              // ISB_HPE_LANES=1 disables the split, up to kMaxLanes
     hipEvent_t fork_ev = nullptr, join_ev[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
@@ -245,7 +254,7 @@ int conv(isb_hpe* h, hipStream_t st, const ConvW& cw, const void* in, int B, int
     a.pad = (cw.k == 3 && stride == 1) ? 1 : 0;          // TF SAME: stride 2 on an even input pads bottom/right only
     a.M = B * a.OH * a.OW; a.K = cw.k * cw.k * cw.cin;
     a.act = act ? 1 : 0; a.out_f32 = out_f32 ? 1 : 0;
-    a.zeros = h->zeros.as<uint16_t>();
+    a.zeros = h->m->zeros.as<uint16_t>();
     // ONE frame (the live loop) x a long K: the SE-gated projections of the last stages are 3-8 tiles of 64 x 128
     // each walking up to 120 k-tiles in series. Split K across workgroups so that the launch covers more of the chip.
     // Only for single-frame calls, and with a split count that depends on the layer alone: batches of two or more
@@ -297,7 +306,7 @@ int gemm(hipStream_t st, const float* A, int lda, const float* W, int ldw, const
 // launches take the host ~2 ms to submit, and submitted lane after lane the second lane's first kernel would wait that long
 int backbone_begin(isb_hpe* h, Lane& L, hipStream_t st, const float* crops, int B) {
     StemArgs sa{};
-    sa.in = crops; sa.w = h->stem_w.as<float>(); sa.wt = h->stem_wt.as<float>(); sa.bias = h->stem_b.as<float>(); sa.out = L.bufX.as<uint16_t>();
+    sa.in = crops; sa.w = h->m->stem_w.as<float>(); sa.wt = h->m->stem_wt.as<float>(); sa.bias = h->m->stem_b.as<float>(); sa.out = L.bufX.as<uint16_t>();
     sa.B = B; sa.H = 256; sa.W = 256; sa.out_f16 = h->f16_from <= 0 ? 1 : 0;
     ISB_TRY(launch_stem(sa, st));
     L.X = L.bufX.p;
@@ -308,13 +317,13 @@ int backbone_begin(isb_hpe* h, Lane& L, hipStream_t st, const float* crops, int 
 int backbone_blocks(isb_hpe* h, Lane& L, hipStream_t st, int B, size_t i0, size_t i1) {
     void*& X = L.X;
     void*& Y = L.Y;
-    for (size_t bi = i0; bi < std::min(i1, h->blocks.size()); ++bi) {
-        BlockW& b = *h->blocks[bi];
-        if (h->mb8_on && h->mb8_count > 0 && B >= h->mb8_min_batch && (int)bi >= h->mb8_first && (int)bi < h->mb8_first + h->mb8_count) {
-            if ((int)bi > h->mb8_first) continue;         // the chain ran when its first block came up
+    for (size_t bi = i0; bi < std::min(i1, h->m->blocks.size()); ++bi) {
+        BlockW& b = *h->m->blocks[bi];
+        if (h->mb8_on && h->m->mb8_count > 0 && B >= h->mb8_min_batch && (int)bi >= h->m->mb8_first && (int)bi < h->m->mb8_first + h->m->mb8_count) {
+            if ((int)bi > h->m->mb8_first) continue;         // the chain ran when its first block came up
             Mb8Args a{};
             a.x = (const uint16_t*)X; a.out = (uint16_t*)Y; a.dscratch = L.bufE.p; a.dscratch_stride = (size_t)64 * 3840 * 2;
-            a.blocks = h->mb8_desc.as<Mb8Block>(); a.nblocks = h->mb8_count; a.B = B; a.cin0 = b.cin; a.f16 = b.f16 ? 1 : 0;
+            a.blocks = h->m->mb8_desc.as<Mb8Block>(); a.nblocks = h->m->mb8_count; a.B = B; a.cin0 = b.cin; a.f16 = b.f16 ? 1 : 0;
             a.stamps = h->mb8_stamps.p ? h->mb8_stamps.as<uint64_t>() : nullptr;
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (h->prof) {
@@ -443,26 +452,26 @@ int backbone_blocks(isb_hpe* h, Lane& L, hipStream_t st, int B, size_t i0, size_
 
 int backbone_end(isb_hpe* h, Lane& L, hipStream_t st, int B) {
     void* X = L.X;
-    ISB_TRY(conv(h, st, h->headconv, X, B, 8, 8, 1, true, nullptr, nullptr, L.feat.p, true));
+    ISB_TRY(conv(h, st, h->m->headconv, X, B, 8, 8, 1, true, nullptr, nullptr, L.feat.p, true));
     if (B == 1) {
         // one frame: 64 rows x 288 outputs are 5 tiles walking 40 k-tiles each -> 8 K-splits + an in-order reduction
         constexpr int kHeadSplits = 8;
         GemmF32Args g{};
-        g.A = L.feat.as<float>(); g.lda = 1280; g.W = h->head_w.as<float>(); g.ldw = 1280; g.C = L.part.as<float>(); g.ldc = 288;
+        g.A = L.feat.as<float>(); g.lda = 1280; g.W = h->m->head_w.as<float>(); g.ldw = 1280; g.C = L.part.as<float>(); g.ldc = 288;
         g.M = 64; g.N = 288; g.K = 1280; g.add_period = 1; g.act = GEMM_ACT_NONE;
         g.splits = kHeadSplits; g.split_stride = (size_t)64 * 288;
         ISB_TRY(launch_gemm_f32(g, st));
-        return launch_reduce_parts(L.part.as<float>(), kHeadSplits, g.split_stride, h->head_b.as<float>(), GEMM_ACT_NONE,
+        return launch_reduce_parts(L.part.as<float>(), kHeadSplits, g.split_stride, h->m->head_b.as<float>(), GEMM_ACT_NONE,
                                    L.logits.as<float>(), 64, 288, st);
     }
-    ISB_TRY(gemm(st, L.feat.as<float>(), 1280, h->head_w.as<float>(), 1280, h->head_b.as<float>(), L.logits.as<float>(), 288,
+    ISB_TRY(gemm(st, L.feat.as<float>(), 1280, h->m->head_w.as<float>(), 1280, h->m->head_b.as<float>(), L.logits.as<float>(), 288,
                  B * 64, 288, 1280, GEMM_ACT_NONE));
     return ISB_OK;
 }
 
 int run_backbone(isb_hpe* h, Lane& L, hipStream_t st, const float* crops, int B) {
     ISB_TRY(backbone_begin(h, L, st, crops, B));
-    ISB_TRY(backbone_blocks(h, L, st, B, 0, h->blocks.size()));
+    ISB_TRY(backbone_blocks(h, L, st, B, 0, h->m->blocks.size()));
     return backbone_end(h, L, st, B);
 }
 
@@ -470,9 +479,9 @@ int run_post(isb_hpe* h, Lane& L, hipStream_t st, const float* logits, int B, fl
              const int32_t* bbox = nullptr) {
     PostArgs a{};
     a.bbox = bbox;
-    a.logits = logits; a.newK = L.newK.as<double>(); a.R = L.R.as<double>(); a.expand = h->expand.as<float>();
-    a.indices = h->has_indices ? h->indices.as<int32_t>() : nullptr;
-    a.joints = joints; a.valid = valid; a.dbg = dbg; a.B = B; a.n_out = h->n_out;
+    a.logits = logits; a.newK = L.newK.as<double>(); a.R = L.R.as<double>(); a.expand = h->m->expand.as<float>();
+    a.indices = h->m->has_indices ? h->m->indices.as<int32_t>() : nullptr;
+    a.joints = joints; a.valid = valid; a.dbg = dbg; a.B = B; a.n_out = h->m->n_out;
     return launch_hpe_post(a, st);
 }
 
@@ -494,6 +503,47 @@ int run_warp(isb_hpe* h, Lane& L, hipStream_t st, const uint8_t* d_frames, int B
     a.B = B * a.n_aug;                      // B frames -> B x n_aug crops
     a.FH = h->cfg.height; a.FW = h->cfg.width;
     return launch_warp(a, st);
+}
+
+// finished depthwise-launch event pairs -> prof_dw_ms (isb_hpe_profile_read_dw reports and resets it). Called by every reader and by
+// isb_hpe_profile(0), so a caller of the family-only API does not accumulate events without bound.
+int drain_prof_dw(isb_hpe* h) {
+    for (auto& e : h->prof_ev_dw) {
+        ISB_HIP(hipEventSynchronize(e.second));
+        float ms = 0.f;
+        ISB_HIP(hipEventElapsedTime(&ms, e.first, e.second));
+        h->prof_dw_ms += ms;
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    h->prof_ev_dw.clear();
+    return ISB_OK;
+}
+
+int create_streams(isb_hpe* h) {
+    ISB_HIP(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
+    ISB_HIP(hipEventCreateWithFlags(&h->last_ev, hipEventDisableTiming));
+    ISB_HIP(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    for (auto& e : h->h2d_ev) ISB_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& sl : h->slot) {
+        ISB_HIP(hipEventCreateWithFlags(&sl.h2d, hipEventDisableTiming));
+        ISB_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    }
+    for (int l = 1; l < kMaxLanes; ++l) {
+        ISB_HIP(hipStreamCreateWithFlags(&h->lanes[l].side, hipStreamNonBlocking));
+        ISB_HIP(hipEventCreateWithFlags(&h->join_ev[l], hipEventDisableTiming));
+    }
+    return ISB_OK;
+}
+
+size_t HpeModel::device_bytes() const {
+    size_t n = stem_w.bytes + stem_wt.bytes + stem_b.bytes + headconv.w16.bytes + headconv.bias.bytes + head_w.bytes + head_b.bytes +
+               expand.bytes + indices.bytes + zeros.bytes + mb8_desc.bytes;
+    for (const auto& b : blocks)
+        for (const DevBuf* d : {&b->expand.w16, &b->expand.bias, &b->project.w16, &b->project.bias, &b->dw_w16, &b->dw_b, &b->se_w1, &b->se_b1,
+                                &b->se_w2, &b->se_b2, &b->mbf16_w1p, &b->fmb_w2p, &b->mbf_w1p, &b->mb_w1p, &b->mb_w2p, &b->mb_se1p})
+            n += d->bytes;
+    return n;
 }
 
 }  // namespace
@@ -520,8 +570,9 @@ extern "C" int isb_hpe_create(const isb_hpe_cfg* cfg, isb_hpe** out) {
     // K as float32 values (hpe.py:28-33)
     h->K[0] = (double)cfg->fx; h->K[2] = (double)cfg->ppx; h->K[4] = (double)cfg->fy; h->K[5] = (double)cfg->ppy; h->K[8] = 1.0;
     ISB_HIP(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
-    ISB_TRY(h->zeros.alloc(256));
-    ISB_HIP(hipMemset(h->zeros.p, 0, 256));
+    h->m = std::make_shared<HpeModel>();
+    ISB_TRY(h->m->zeros.alloc(256));
+    ISB_HIP(hipMemset(h->m->zeros.p, 0, 256));
     if (const char* e = getenv("ISB_FUSE_SE")) h->fuse_se = atoi(e) != 0;
 #ifdef ISB_BUILD_PROBES
     if (const char* e = getenv("ISB_MB8")) h->mb8_on = atoi(e) != 0;       // (the per-sample chain kernel exists in probe builds only)
@@ -538,19 +589,54 @@ extern "C" int isb_hpe_create(const isb_hpe_cfg* cfg, isb_hpe** out) {
     h->f16_from = cfg->precision == 1 ? 7 : (cfg->precision == 3 ? 5 : 0);
     if (const char* e = getenv("ISB_HPE_ROI")) h->roi_mode = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("ISB_HPE_LANES")) h->n_lanes = std::max(1, std::min(kMaxLanes, atoi(e)));
-    ISB_HIP(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
-    ISB_HIP(hipEventCreateWithFlags(&h->last_ev, hipEventDisableTiming));
-    ISB_HIP(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
-    for (auto& e : h->h2d_ev) ISB_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    for (auto& sl : h->slot) {
-        ISB_HIP(hipEventCreateWithFlags(&sl.h2d, hipEventDisableTiming));
-        ISB_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
-    }
-    for (int l = 1; l < kMaxLanes; ++l) {
-        ISB_HIP(hipStreamCreateWithFlags(&h->lanes[l].side, hipStreamNonBlocking));
-        ISB_HIP(hipEventCreateWithFlags(&h->join_ev[l], hipEventDisableTiming));
-    }
+    ISB_TRY(create_streams(h.get()));
     *out = h.release();
+    return ISB_OK;
+    });
+}
+
+// One more engine on the SAME device weights: the child shares the parent's model -- folded / packed weights, joint
+// map -- and owns what a pass writes: its streams, events and activation workspaces. Keeping K batches in flight (one engine per batch,
+// each on its own stream) then costs one copy of the weights + K workspaces instead of K copies of both.
+extern "C" int isb_hpe_create_shared(isb_hpe* parent, isb_hpe** out) {
+    return isb::guard([&]() -> int {
+    ISB_REQUIRE(parent && out, ISB_ERR_INVALID, "isb_hpe_create_shared: null argument");
+    ISB_HIP(hipSetDevice(parent->cfg.device));
+    std::unique_ptr<isb_hpe> h(new (std::nothrow) isb_hpe());
+    ISB_REQUIRE(h, ISB_ERR_NOMEM, "out of host memory");
+    h->cfg = parent->cfg;
+    memcpy(h->K, parent->K, sizeof(h->K));
+    h->m = parent->m;                         // (the model outlives whichever of the two is destroyed first)
+    h->parent = parent;
+    // the plan switches select which packed weight images exist: a child runs the parent's plan
+    h->mb8_on = parent->mb8_on; h->dwmm16 = parent->dwmm16; h->stamp16 = parent->stamp16; h->mbf16_on = parent->mbf16_on;
+    h->fmb_rege = parent->fmb_rege; h->dwmm_on = parent->dwmm_on; h->mbf8_on = parent->mbf8_on;
+    h->mbf8_min_batch = parent->mbf8_min_batch; h->mb8_min_batch = parent->mb8_min_batch; h->fuse_se = parent->fuse_se;
+    h->f16_from = parent->f16_from; h->roi_mode = parent->roi_mode; h->n_lanes = parent->n_lanes;
+    ISB_HIP(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    ISB_TRY(create_streams(h.get()));
+    *out = h.release();
+    return ISB_OK;
+    });
+}
+
+extern "C" int isb_hpe_memory(isb_hpe* h, uint64_t* model_bytes, uint64_t* workspace_bytes, int32_t* engines_on_model) {
+    return isb::guard([&]() -> int {
+    ISB_REQUIRE(h, ISB_ERR_INVALID, "null handle");
+    if (model_bytes) *model_bytes = h->m->device_bytes();
+    if (workspace_bytes) {
+        size_t w = 0;
+        for (const Lane& L : h->lanes)
+            for (const DevBuf* b : {&L.H, &L.newK, &L.R, &L.crops, &L.bufX, &L.bufY, &L.bufE, &L.bufD, &L.pooled, &L.semid, &L.gate, &L.feat,
+                                    &L.logits, &L.part})
+                w += b->bytes;
+        for (const DevBuf* b : {&h->hs_frames, &h->hs_bbox, &h->hs_joints, &h->hs_valid, &h->hs_H, &h->hs_newK, &h->hs_R, &h->hs_roi,
+                                &h->aug_rotflip, &h->aug_scale, &h->mb8_stamps})
+            w += b->bytes;
+        for (const auto& sl : h->slot) w += sl.frames.bytes + sl.bbox.bytes + sl.joints.bytes + sl.valid.bytes;
+        *workspace_bytes = w;
+    }
+    if (engines_on_model) *engines_on_model = (int32_t)h->m.use_count();
     return ISB_OK;
     });
 }
@@ -559,10 +645,11 @@ extern "C" void isb_hpe_destroy(isb_hpe* h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     (void)hipDeviceSynchronize();
-    for (auto& e : h->prof_ev) {
-        (void)hipEventDestroy(e.first);
-        (void)hipEventDestroy(e.second);
-    }
+    for (auto* list : {&h->prof_ev, &h->prof_ev_dw})
+        for (auto& e : *list) {
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     for (int l = 1; l < kMaxLanes; ++l) {
         if (h->lanes[l].side) (void)hipStreamDestroy(h->lanes[l].side);
@@ -585,12 +672,14 @@ extern "C" int isb_hpe_load_weights(isb_hpe* h, const void* blob, size_t nbytes)
     return isb::guard([&]() -> int {
     ISB_REQUIRE(h, ISB_ERR_INVALID, "null handle");
     ISB_REQUIRE(!h->slot[0].busy && !h->slot[1].busy, ISB_ERR_STATE, "submitted host batches are outstanding: isb_hpe_wait_host first");
+    ISB_REQUIRE(!h->parent, ISB_ERR_STATE, "isb_hpe_load_weights on an engine made by isb_hpe_create_shared: load into the parent (the family reads one model)");
     ISB_HIP(hipSetDevice(h->cfg.device));
+    ISB_HIP(hipDeviceSynchronize());           // engines that share this model may have passes in flight on their own streams
     hipStream_t st = h->own_stream;
     std::map<std::string, BlobTensor> m;
     ISB_TRY(parse_blob(blob, nbytes, m));
-    h->weights = false;
-    h->blocks.clear();
+    h->m->weights = false;
+    h->m->blocks.clear();
     // stem: f32 [32][27] with the BN scale folded
     {
         auto it = m.find("bbone.stem.w");
@@ -601,12 +690,12 @@ extern "C" int isb_hpe_load_weights(isb_hpe* h, const void* blob, size_t nbytes)
         std::vector<float> w(32 * 27);
         for (int o = 0; o < 32; ++o)
             for (int k = 0; k < 27; ++k) w[o * 27 + k] = it->second.data[o * 27 + k] * sc->data[o];
-        ISB_TRY(upload(h->stem_w, w.data(), w.size() * 4));
+        ISB_TRY(upload(h->m->stem_w, w.data(), w.size() * 4));
         std::vector<float> wt(27 * 32);                    // pair-major copy [16][27][2]: stem_kernel reads channel pairs as adjacent scalars
         for (int o = 0; o < 32; ++o)
             for (int k = 0; k < 27; ++k) wt[((o >> 1) * 27 + k) * 2 + (o & 1)] = w[o * 27 + k];
-        ISB_TRY(upload(h->stem_wt, wt.data(), wt.size() * 4));
-        ISB_TRY(upload(h->stem_b, sh->data, 32 * 4));
+        ISB_TRY(upload(h->m->stem_wt, wt.data(), wt.size() * 4));
+        ISB_TRY(upload(h->m->stem_b, sh->data, 32 * 4));
     }
     int idx = 0, hw = 128, stage = 0;
     bool stream_f16 = false;        // type of the tensor the next block reads
@@ -688,23 +777,23 @@ extern "C" int isb_hpe_load_weights(isb_hpe* h, const void* blob, size_t nbytes)
                 }
                 ISB_TRY(upload(b->se_b2, b2->data, b2->numel() * 4));
             }
-            h->blocks.push_back(std::move(b));
+            h->m->blocks.push_back(std::move(b));
         }
     }
     ISB_REQUIRE(hw == 8, ISB_ERR_WEIGHTS, "internal: backbone plan ends at %dx%d", hw, hw);
     // the chain of stride-1 MBConv blocks on 8 x 8 maps (the tail of the network): weights in the fused kernel's streaming layouts
     {
-        h->mb8_first = -1; h->mb8_count = 0;
+        h->m->mb8_first = -1; h->m->mb8_count = 0;
         std::vector<Mb8Block> desc;
-        for (size_t bi = 0; bi < h->blocks.size(); ++bi) {
-            BlockW& b = *h->blocks[bi];
+        for (size_t bi = 0; bi < h->m->blocks.size(); ++bi) {
+            BlockW& b = *h->m->blocks[bi];
             const bool fits = h->mb8_on && !b.fused && b.stride == 1 && b.in_hw == 8 && b.f16_in == b.f16 && (b.cin == 384 || b.cin == 640) &&
                               (b.cout == 384 || b.cout == 640) && b.cexp == 6 * b.cin && b.cse == b.cin / 4 && !(b.cin == 640 && b.cout == 384);
             if (!fits) {
                 ISB_REQUIRE(desc.empty(), ISB_ERR_WEIGHTS, "internal: the 8 x 8 chain is not the tail of the block list (block %zu)", bi);
                 continue;
             }
-            if (desc.empty()) h->mb8_first = (int)bi;
+            if (desc.empty()) h->m->mb8_first = (int)bi;
             ISB_TRY(b.mb_w1p.alloc((size_t)b.cexp * b.cin * 2));
             ISB_TRY(b.mb_w2p.alloc((size_t)b.cout * b.cexp * 2));
             ISB_TRY(b.mb_se1p.alloc((size_t)b.cse * b.cexp * 4));
@@ -719,16 +808,16 @@ extern "C" int isb_hpe_load_weights(isb_hpe* h, const void* blob, size_t nbytes)
             desc.push_back(d);
         }
         ISB_HIP(hipStreamSynchronize(st));
-        h->mb8_count = (int)desc.size();
-        if (!desc.empty()) ISB_TRY(upload(h->mb8_desc, desc.data(), desc.size() * sizeof(Mb8Block)));
+        h->m->mb8_count = (int)desc.size();
+        if (!desc.empty()) ISB_TRY(upload(h->m->mb8_desc, desc.data(), desc.size() * sizeof(Mb8Block)));
     }
-    ISB_TRY(upload_conv(m, "bbone.head", 1280, 1, 640, h->headconv, st, stream_f16));
+    ISB_TRY(upload_conv(m, "bbone.head", 1280, 1, 640, h->m->headconv, st, stream_f16));
     const BlobTensor *hwt, *hb;
     ISB_TRY(blob_get(m, "head.weight", 288, 1280, &hwt));
     ISB_TRY(blob_get(m, "head.bias", 288, 1, &hb));
-    ISB_TRY(upload(h->head_w, hwt->data, hwt->numel() * 4));
-    ISB_TRY(upload(h->head_b, hb->data, 288 * 4));
-    h->weights = true;
+    ISB_TRY(upload(h->m->head_w, hwt->data, hwt->numel() * 4));
+    ISB_TRY(upload(h->m->head_b, hb->data, 288 * 4));
+    h->m->weights = true;
     return ISB_OK;
     });
 }
@@ -759,15 +848,17 @@ extern "C" int isb_hpe_set_joint_map(isb_hpe* h, const float* expand, const int3
     ISB_REQUIRE(n_out >= 1 && n_out <= 122, ISB_ERR_INVALID, "n_out %d outside [1,122]", n_out);
     ISB_REQUIRE(indices || n_out == 122, ISB_ERR_INVALID, "without indices n_out must be 122");
     ISB_REQUIRE(!h->slot[0].busy && !h->slot[1].busy, ISB_ERR_STATE, "submitted host batches are outstanding: isb_hpe_wait_host first");
+    ISB_REQUIRE(!h->parent, ISB_ERR_STATE, "isb_hpe_set_joint_map on an engine made by isb_hpe_create_shared: set it on the parent (the family reads one model)");
     if (indices)
         for (int i = 0; i < n_out; ++i)
             ISB_REQUIRE(indices[i] >= 0 && indices[i] < 122, ISB_ERR_INVALID, "joint index %d outside [0,122)", indices[i]);
     ISB_HIP(hipSetDevice(h->cfg.device));
-    ISB_TRY(upload(h->expand, expand, 32 * 122 * 4));
-    h->has_indices = indices != nullptr;
-    if (indices) ISB_TRY(upload(h->indices, indices, (size_t)n_out * 4));
-    h->n_out = n_out;
-    h->jointmap = true;
+    ISB_HIP(hipDeviceSynchronize());           // (see isb_hpe_load_weights)
+    ISB_TRY(upload(h->m->expand, expand, 32 * 122 * 4));
+    h->m->has_indices = indices != nullptr;
+    if (indices) ISB_TRY(upload(h->m->indices, indices, (size_t)n_out * 4));
+    h->m->n_out = n_out;
+    h->m->jointmap = true;
     return ISB_OK;
     });
 }
@@ -806,7 +897,7 @@ extern "C" int isb_hpe_forward(isb_hpe* h, const uint8_t* d_frames, const int32_
     ISB_REQUIRE(h->n_aug == 0, ISB_ERR_STATE,
                 "test-time augmentation is on: the reference defines it up to the augmented crops only (hpe.py:88-100; its "
                 "decode reshapes to one sample, hpe.py:108) -- use the crop_params / warp / backbone stages");
-    ISB_REQUIRE(h->weights && h->jointmap, ISB_ERR_STATE, "isb_hpe_forward needs weights and a joint map");
+    ISB_REQUIRE(h->m->weights && h->m->jointmap, ISB_ERR_STATE, "isb_hpe_forward needs weights and a joint map");
     ISB_HIP(hipSetDevice(h->cfg.device));
     hipStream_t st = (hipStream_t)stream;   // NULL = the HIP null stream (torch's default stream)
     const int Bm_max = std::min<int>(B, h->cfg.max_batch);
@@ -814,7 +905,7 @@ extern "C" int isb_hpe_forward(isb_hpe* h, const uint8_t* d_frames, const int32_
     // a lane's pass in phases: 0 = crop parameters, (ROI gather,) warp, stem; 1 .. n = kPhaseBlocks blocks each; last = 640 -> 1280
     // convolution, pose head, decode + reconstruction
     constexpr size_t kPhaseBlocks = 6;
-    const int n_phases = 2 + (int)((h->blocks.size() + kPhaseBlocks - 1) / kPhaseBlocks);
+    const int n_phases = 2 + (int)((h->m->blocks.size() + kPhaseBlocks - 1) / kPhaseBlocks);
     auto run_phase = [&](Lane& L, hipStream_t s, int b0, int Bm, int ph, int lane_no) -> int {
         if (ph == 0) {
             ISB_TRY(ensure_ws(L, Bm));
@@ -833,7 +924,7 @@ extern "C" int isb_hpe_forward(isb_hpe* h, const uint8_t* d_frames, const int32_
         }
         if (ph < n_phases - 1) return backbone_blocks(h, L, s, Bm, (size_t)(ph - 1) * kPhaseBlocks, (size_t)ph * kPhaseBlocks);
         ISB_TRY(backbone_end(h, L, s, Bm));
-        return run_post(h, L, s, L.logits.as<float>(), Bm, d_joints + (size_t)b0 * h->n_out * 3, d_valid + b0, nullptr,
+        return run_post(h, L, s, L.logits.as<float>(), Bm, d_joints + (size_t)b0 * h->m->n_out * 3, d_valid + b0, nullptr,
                         d_bbox + (size_t)b0 * 4);
     };
     // (not while the stream is being captured into a graph: a replayed step is ordered by its own launches)
@@ -947,7 +1038,7 @@ extern "C" int isb_hpe_forward_host(isb_hpe* h, const uint8_t* frames, const int
     ISB_REQUIRE(h && frames && bbox && joints && valid, ISB_ERR_INVALID, "null argument");
     ISB_REQUIRE(B >= 1, ISB_ERR_INVALID, "batch %d < 1", B);
     ISB_REQUIRE(h->n_aug == 0, ISB_ERR_STATE, "test-time augmentation is on: the reference defines it up to the augmented crops only (hpe.py:88-100)");
-    ISB_REQUIRE(h->weights && h->jointmap, ISB_ERR_STATE, "isb_hpe_forward_host needs weights and a joint map");
+    ISB_REQUIRE(h->m->weights && h->m->jointmap, ISB_ERR_STATE, "isb_hpe_forward_host needs weights and a joint map");
     ISB_HIP(hipSetDevice(h->cfg.device));
     hipStream_t st = h->own_stream;
     const size_t fsz = (size_t)h->cfg.height * h->cfg.width * 3;
@@ -996,10 +1087,10 @@ extern "C" int isb_hpe_forward_host(isb_hpe* h, const uint8_t* frames, const int
         const int b0 = c * per, n = std::min(per, B - b0);
         if (n <= 0) break;
         ISB_HIP(hipStreamWaitEvent(st, h->h2d_ev[c], 0));
-        ISB_TRY(isb_hpe_forward(h, df + (size_t)b0 * fsz, db + (size_t)b0 * 4, n, dj + (size_t)b0 * h->n_out * 3, dv + b0, st));
+        ISB_TRY(isb_hpe_forward(h, df + (size_t)b0 * fsz, db + (size_t)b0 * 4, n, dj + (size_t)b0 * h->m->n_out * 3, dv + b0, st));
     }
     }
-    ISB_HIP(hipMemcpyAsync(joints, dj, (size_t)B * h->n_out * 12, hipMemcpyDeviceToHost, st));
+    ISB_HIP(hipMemcpyAsync(joints, dj, (size_t)B * h->m->n_out * 12, hipMemcpyDeviceToHost, st));
     ISB_HIP(hipMemcpyAsync(valid, dv, (size_t)B, hipMemcpyDeviceToHost, st));
     ISB_HIP(hipStreamSynchronize(st));
     return ISB_OK;
@@ -1022,7 +1113,7 @@ extern "C" int isb_hpe_submit_host(isb_hpe* h, const uint8_t* frames, const int3
     ISB_REQUIRE(h && frames && bbox && joints && valid, ISB_ERR_INVALID, "null argument");
     ISB_REQUIRE(B >= 1, ISB_ERR_INVALID, "batch %d < 1", B);
     ISB_REQUIRE(h->n_aug == 0, ISB_ERR_STATE, "test-time augmentation is on: the reference defines it up to the augmented crops only (hpe.py:88-100)");
-    ISB_REQUIRE(h->weights && h->jointmap, ISB_ERR_STATE, "isb_hpe_submit_host needs weights and a joint map");
+    ISB_REQUIRE(h->m->weights && h->m->jointmap, ISB_ERR_STATE, "isb_hpe_submit_host needs weights and a joint map");
     ISB_HIP(hipSetDevice(h->cfg.device));
     isb_hpe::HostSlot& sl = h->slot[h->sub_head];
     if (sl.busy) ISB_TRY(complete_oldest(h));    // two in flight already: the oldest (this slot) is finished first
@@ -1048,11 +1139,11 @@ extern "C" int isb_hpe_submit_host(isb_hpe* h, const uint8_t* frames, const int3
     ISB_HIP(hipEventRecord(sl.h2d, cs));
     ISB_HIP(hipStreamWaitEvent(st, sl.h2d, 0));
     ISB_TRY(isb_hpe_forward(h, sl.frames.as<uint8_t>(), sl.bbox.as<int32_t>(), B, sl.joints.as<float>(), sl.valid.as<uint8_t>(), st));
-    const size_t jb = (size_t)B * h->n_out * 12;
+    const size_t jb = (size_t)B * h->m->n_out * 12;
     ISB_HIP(hipMemcpyAsync(sl.pin, sl.joints.p, jb, hipMemcpyDeviceToHost, st));
     ISB_HIP(hipMemcpyAsync(static_cast<uint8_t*>(sl.pin) + jb, sl.valid.p, (size_t)B, hipMemcpyDeviceToHost, st));
     ISB_HIP(hipEventRecord(sl.done, st));
-    sl.user_joints = joints; sl.user_valid = valid; sl.B = B; sl.n_out = h->n_out; sl.busy = true;
+    sl.user_joints = joints; sl.user_valid = valid; sl.B = B; sl.n_out = h->m->n_out; sl.busy = true;
     h->sub_head ^= 1;
     return ISB_OK;
     });
@@ -1112,7 +1203,7 @@ extern "C" int isb_hpe_warp_host(isb_hpe* h, const uint8_t* frames, const int32_
 extern "C" int isb_hpe_backbone_host(isb_hpe* h, const float* crops, int32_t B, float* features, float* logits) {
     return isb::guard([&]() -> int {
     ISB_REQUIRE(h && crops && B >= 1, ISB_ERR_INVALID, "bad argument");
-    ISB_REQUIRE(h->weights, ISB_ERR_STATE, "isb_hpe_backbone_host before isb_hpe_load_weights");
+    ISB_REQUIRE(h->m->weights, ISB_ERR_STATE, "isb_hpe_backbone_host before isb_hpe_load_weights");
     ISB_HIP(hipSetDevice(h->cfg.device));
     hipStream_t st = h->own_stream;
     Lane& L = h->lanes[0];
@@ -1131,7 +1222,7 @@ extern "C" int isb_hpe_post_host(isb_hpe* h, const float* logits, const int32_t*
                                  uint8_t* valid, double* pred) {
     return isb::guard([&]() -> int {
     ISB_REQUIRE(h && logits && bbox && joints && valid && B >= 1, ISB_ERR_INVALID, "bad argument");
-    ISB_REQUIRE(h->jointmap, ISB_ERR_STATE, "isb_hpe_post_host before isb_hpe_set_joint_map");
+    ISB_REQUIRE(h->m->jointmap, ISB_ERR_STATE, "isb_hpe_post_host before isb_hpe_set_joint_map");
     ISB_REQUIRE(h->n_aug == 0, ISB_ERR_STATE, "test-time augmentation is on: the reference's decode takes one sample (hpe.py:108)");
     ISB_HIP(hipSetDevice(h->cfg.device));
     hipStream_t st = h->own_stream;
@@ -1141,13 +1232,13 @@ extern "C" int isb_hpe_post_host(isb_hpe* h, const float* logits, const int32_t*
     DevBuf db, dl, dj, dv, dd;
     ISB_TRY(upload(db, bbox, (size_t)B * 16));
     ISB_TRY(upload(dl, logits, (size_t)B * 64 * 288 * 4));
-    ISB_TRY(dj.alloc((size_t)B * h->n_out * 12));
+    ISB_TRY(dj.alloc((size_t)B * h->m->n_out * 12));
     ISB_TRY(dv.alloc((size_t)B));
     if (pred) ISB_TRY(dd.alloc((size_t)B * 32 * 5 * 8));
     ISB_TRY(run_crop_params(h, L, st, db.as<int32_t>(), B));
     ISB_TRY(run_post(h, L, st, dl.as<float>(), B, dj.as<float>(), dv.as<uint8_t>(), pred ? dd.as<double>() : nullptr));
     ISB_HIP(hipStreamSynchronize(st));
-    ISB_HIP(hipMemcpy(joints, dj.p, (size_t)B * h->n_out * 12, hipMemcpyDeviceToHost));
+    ISB_HIP(hipMemcpy(joints, dj.p, (size_t)B * h->m->n_out * 12, hipMemcpyDeviceToHost));
     ISB_HIP(hipMemcpy(valid, dv.p, (size_t)B, hipMemcpyDeviceToHost));
     if (pred) ISB_HIP(hipMemcpy(pred, dd.p, (size_t)B * 32 * 5 * 8, hipMemcpyDeviceToHost));
     return ISB_OK;
@@ -1158,6 +1249,10 @@ extern "C" int isb_hpe_profile(isb_hpe* h, int32_t enable) {
     return isb::guard([&]() -> int {
     ISB_REQUIRE(h, ISB_ERR_INVALID, "null handle");
     h->prof = enable != 0;
+    if (!h->prof) {          // a caller that never reads the depthwise list (isb_hpe_profile_read_dw) must not keep its events alive
+        ISB_HIP(hipSetDevice(h->cfg.device));
+        ISB_TRY(drain_prof_dw(h));
+    }
     return ISB_OK;
     });
 }
@@ -1175,6 +1270,7 @@ extern "C" int isb_hpe_profile_read(isb_hpe* h, double* ms_total, int64_t* launc
         (void)hipEventDestroy(e.second);
     }
     h->prof_ev.clear();
+    ISB_TRY(drain_prof_dw(h));
     *ms_total = h->prof_ms;
     *launches = h->prof_launches;
     h->prof_ms = 0.0;
@@ -1187,15 +1283,7 @@ extern "C" int isb_hpe_profile_read_dw(isb_hpe* h, double* ms_total, int64_t* la
     return isb::guard([&]() -> int {
     ISB_REQUIRE(h && ms_total && launches, ISB_ERR_INVALID, "null argument");
     ISB_HIP(hipSetDevice(h->cfg.device));
-    for (auto& e : h->prof_ev_dw) {
-        ISB_HIP(hipEventSynchronize(e.second));
-        float ms = 0.f;
-        ISB_HIP(hipEventElapsedTime(&ms, e.first, e.second));
-        h->prof_dw_ms += ms;
-        (void)hipEventDestroy(e.first);
-        (void)hipEventDestroy(e.second);
-    }
-    h->prof_ev_dw.clear();
+    ISB_TRY(drain_prof_dw(h));
     *ms_total = h->prof_dw_ms;
     *launches = h->prof_dw_launches;
     h->prof_dw_ms = 0.0;

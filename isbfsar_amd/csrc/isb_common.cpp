@@ -98,6 +98,27 @@ extern "C" int isbfsar_probe_build(void) {
 }
 extern "C" const char* isb_last_error(void) { return isb::g_err; }
 extern "C" int isb_version(void) { return 2; }      // 2: isb_ar_cfg.precision 0 = default (fp16), bf16 = 3 (include/isbfsar.h)
+// Hardware queues. HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), read ONCE when the runtime
+// initialises; streams that share a queue serialise behind each other's barrier packets. Three pose engines in flight + the match stream
+// + the caller's stream need more than four (EXPERIMENTS.md round 3 / 5: 19.3 vs 17.55 ms per step). The library asks for 8 when it is
+// loaded -- without overriding a value the caller has set -- which takes effect iff no HIP call has been made in the process yet
+// (PyTorch makes none before its first CUDA use). isb_hw_queues() reports what the runtime will have read / has read from the
+// environment, and whether that value was set by the caller, by this library at load time, or not at all.
+namespace {
+int g_hwq_source = 0;           // 0: variable unset (runtime default 4); 1: set by the caller before load; 2: set by this library
+struct HwQueuesAtLoad {
+    HwQueuesAtLoad() {
+        if (getenv("GPU_MAX_HW_QUEUES")) g_hwq_source = 1;
+        else if (setenv("GPU_MAX_HW_QUEUES", "8", 0) == 0) g_hwq_source = 2;
+    }
+} g_hwq_at_load;
+}  // namespace
+extern "C" int isb_hw_queues(int32_t* source) {
+    if (source) *source = g_hwq_source;
+    const char* e = getenv("GPU_MAX_HW_QUEUES");
+    const int v = e ? atoi(e) : 4;
+    return v > 0 ? v : 4;
+}
 extern "C" int isb_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

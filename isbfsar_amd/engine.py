@@ -37,8 +37,22 @@ class ArEngine:
         [.., L, 2048], e.g. from RgbEngine)."""
         # "default" = ISB_AR_PREC_DEFAULT = what a zero-initialised isb_ar_cfg gets: fp16 operands (include/isbfsar.h); the
         # resolved setting is read back from the handle (isb_ar_precision), so that there is ONE default, the library's
-        prec = {"default": _lib.ISB_AR_PREC_DEFAULT, "bf16": _lib.ISB_AR_PREC_BF16, "bf16x3": _lib.ISB_AR_PREC_BF16X3,
-                "f16": _lib.ISB_AR_PREC_F16}.get(precision, precision)
+        names = {"default": _lib.ISB_AR_PREC_DEFAULT, "bf16": _lib.ISB_AR_PREC_BF16, "bf16x3": _lib.ISB_AR_PREC_BF16X3,
+                 "f16": _lib.ISB_AR_PREC_F16}
+        if isinstance(precision, str):
+            if precision not in names:
+                raise ValueError(f"precision {precision!r} not in {sorted(names)}")
+            prec = names[precision]
+        else:
+            # a raw integer is an ABI constant. 0 changed its meaning with ABI version 2 (it was bf16, it is "the library's default" =
+            # fp16 operands now; bf16 moved to 3): a caller written against version 1 must notice, so 0 is refused here -- say
+            # "default" or "bf16" (ADVICE r5). The C ABI keeps accepting 0 (a zero-initialised isb_ar_cfg).
+            if int(precision) == 0:
+                raise ValueError('precision=0 is ambiguous across ABI versions (v1: bf16, v2: the default = fp16 operands): '
+                                 'pass "default", "f16", "bf16" or "bf16x3"')
+            if int(precision) not in (1, 2, 3):
+                raise ValueError(f"precision {precision!r}: ISB_AR_PREC_BF16X3 (1), ISB_AR_PREC_F16 (2) or ISB_AR_PREC_BF16 (3)")
+            prec = int(precision)
         if input_type not in ("skeleton", "hybrid"):
             raise ValueError(f"input_type {input_type!r}: 'skeleton' or 'hybrid' (the reference's 'rgb' type is inconsistent with "
                              "its own model: utils/params.py:81 sizes the transformer for 1000-wide features, model.py:274-277 makes 256)")

@@ -39,6 +39,24 @@ class HpeEngine:
         cfg = _lib.isb_hpe_cfg(fx, fy, ppx, ppy, width, height, device, max_batch, 0, PRECISIONS[precision])
         _lib.check(_lib.lib().isb_hpe_create(C.byref(cfg), C.byref(self._h)), "isb_hpe_create")
 
+    def share(self) -> "HpeEngine":
+        """One more engine on THIS engine's device weights (isb_hpe_create_shared): the child reads this engine's model (weights, joint
+        map) and owns its own streams and workspaces. For callers that keep several batches in flight, one engine per batch in flight,
+        each forward() on its own stream: one copy of the 240 MB model + K workspaces instead of K of each, same bits."""
+        child = HpeEngine.__new__(HpeEngine)
+        child.width, child.height, child.device, child.max_batch = self.width, self.height, self.device, self.max_batch
+        child.precision, child.n_out = self.precision, self.n_out
+        child._h = C.c_void_p()
+        child._parent = self          # (keeps the Python object of the parent alive; the library itself does not need it)
+        _lib.check(_lib.lib().isb_hpe_create_shared(self._h, C.byref(child._h)), "isb_hpe_create_shared")
+        return child
+
+    def memory(self):
+        """(bytes of the model this engine reads, bytes of the workspaces it owns, engines that share the model)"""
+        m, w, n = C.c_uint64(), C.c_uint64(), C.c_int32()
+        _lib.check(_lib.lib().isb_hpe_memory(self._h, C.byref(m), C.byref(w), C.byref(n)), "isb_hpe_memory")
+        return int(m.value), int(w.value), int(n.value)
+
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
             _lib.lib().isb_hpe_destroy(self._h)

@@ -180,3 +180,32 @@ def test_every_fp16_storing_kernel_saturates(built_lib):
     bad = "\n".join(lines[:drop] + lines[drop + 1:])
     why_bad = build.fp16_conversions_saturate(built_lib, text=bad)
     assert why_bad is not None and "mbfront16_kernel" in why_bad, why_bad
+
+
+def test_hw_queues_are_asked_for_at_load_and_reported(built_lib):
+    """isb_hw_queues: engines in flight on their own streams need a hardware queue each; the library asks the HIP
+    runtime for eight when it is LOADED (GPU_MAX_HW_QUEUES, read once at the runtime's first call) unless the caller's environment
+    already holds a value, and reports which of the two happened. No GPU needed: the call makes no HIP call."""
+    import subprocess
+    import sys
+    prog = ("import ctypes, os, sys\n"
+            f"lib = ctypes.CDLL({built_lib!r})\n"
+            "src = ctypes.c_int32(-1)\n"
+            "lib.isb_hw_queues.argtypes = [ctypes.POINTER(ctypes.c_int32)]\n"
+            "print(lib.isb_hw_queues(ctypes.byref(src)), src.value)\n")
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    out = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, check=True).stdout.split()
+    assert out == ["8", "2"], out                              # unset: the library set 8 at load time
+    env["GPU_MAX_HW_QUEUES"] = "6"
+    out = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, check=True).stdout.split()
+    assert out == ["6", "1"], out                              # the caller's value stands
+
+
+def test_raw_integer_zero_precision_is_refused_by_the_python_engine():
+    """ABI version 2 renumbered ISB_AR_PREC_BF16 from 0 to 3 (0 = the library's default = fp16 operands). A Python caller
+    written against version 1 that passes the raw integer 0 must notice instead of silently getting another precision."""
+    from isbfsar_amd.engine import ArEngine
+    with pytest.raises(ValueError, match="ambiguous"):
+        ArEngine(16, 30, 5, precision=0)
+    with pytest.raises(ValueError):
+        ArEngine(16, 30, 5, precision="fp32")

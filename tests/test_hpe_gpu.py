@@ -357,50 +357,62 @@ def test_forward_end_to_end_vs_oracle(eng_w, bbone_state, assets):
     assert np.array_equal(j2.cpu().numpy(), joints) and np.array_equal(v2.cpu().numpy(), valid)
 
 
+def _pcts(d):
+    d = np.sort(np.asarray(d, dtype=np.float64))
+    return float(np.median(d)), float(d[min(len(d) - 1, int(np.ceil(0.99 * len(d))) - 1)]), float(d[-1])
+
+
+N_STAT = 64         # frames behind the "within 1e-3 of the fp32 definition" claims (a max over 8 frames is not a guarantee)
+
+
 def test_absolute_pose_within_1e3_of_fp32_definition(bbone_state, assets):
     """estimate() RETURNS the absolute pose (hpe.py:171; main.py:102 takes its distance), so it has to sit within the north
-    star's 1e-3 of the fp32 path too, not only of the storage-faithful oracle. 16 frames (the first 8 are the frames
-    bench.py's parity object uses), default weights, all three storage layouts against the fp32 oracle: the default (fp16
-    everywhere = the reference's TensorRT precision) and round 3's mixed layout at a flat 1e-3; plain bf16 is run beside
-    them and must be the worst (its distance to fp32 is a property of bf16 storage: oracle/error_budget.py)."""
+    star's 1e-3 of the fp32 path too, not only of the storage-faithful oracle. 64 frames (the first 32 are the frames
+    bench.py's parity object uses), default weights, against the fp32 oracle: the default layout (fp16 everywhere = the
+    reference's TensorRT precision) at a flat 1e-3 on the MAX over all 64, with the p50 / p99 / max printed; round 3's mixed
+    layout and plain bf16 are run beside it on the first 16 frames (mixed: flat 1e-3 too; bf16 must be the worst -- its distance
+    to fp32 is a property of bf16 storage: oracle/error_budget.py)."""
     from isbfsar_amd.hpe_engine import HpeEngine
     from oracle import hpe_oracle as ho
     from oracle.effnetv2_oracle import EffNetV2LOracle
     W, st = assets
     idx = st["smpl+head_30"]["indices"]
-    B = 16
+    B = N_STAT
     fr, bb = synth.frames(B, seed=0), synth.bboxes(B, seed=0)
     crops = np.stack([ho.warp(fr[b], ho.crop_params(bb[b], _K())[2][0]) for b in range(B)])
     o32 = EffNetV2LOracle(bbone_state, "f32")
-    l32 = o32.head(o32.backbone(crops))
+    l32 = np.concatenate([o32.head(o32.backbone(crops[i:i + 16])) for i in range(0, B, 16)])
     errs = {}
-    for prec in ("f16", "bf16_f16tail", "bf16"):
-        e = HpeEngine(device=0, max_batch=16, precision=prec)
+    for prec, n in (("f16", B), ("bf16_f16tail", 16), ("bf16", 16)):
+        e = HpeEngine(device=0, max_batch=B, precision=prec)
         try:
             e.set_joint_map(W, idx)
             e.load_weights(bbone_state)
-            joints, valid = e.forward(fr, bb)
+            joints, valid = e.forward(fr[:n], bb[:n])
         finally:
             e.close()
         d = []
-        for b in range(B):
+        for b in range(n):
             nk, r, _ = ho.crop_params(bb[b], _K())
             ref = ho.postprocess(l32[b:b + 1], nk, r, W, idx)
             assert ref is not None and valid[b] == 1
             d.append(float(np.abs(joints[b] - ref).max()))
         errs[prec] = np.array(d)
-        print(f"absolute pose vs fp32 definition, precision {prec}: median {np.median(d):.2e} max {max(d):.2e}")
+        p50, p99, mx = _pcts(d)
+        print(f"absolute pose vs fp32 definition, default weights, precision {prec}, {n} frames: p50 {p50:.2e} p99 {p99:.2e} max {mx:.2e}")
     assert errs["f16"].max() < 1e-3
     assert errs["bf16_f16tail"].max() < 1e-3
-    assert np.median(errs["f16"]) < np.median(errs["bf16"]) and np.median(errs["bf16_f16tail"]) < np.median(errs["bf16"])
+    assert np.median(errs["f16"][:16]) < np.median(errs["bf16"]) and np.median(errs["bf16_f16tail"]) < np.median(errs["bf16"])
 
 
 def test_signal_profile_fp16_vs_fp32_definition(assets):
     """The "signal" weight profile (activations that carry the input, peaked heat-maps: the regime of a trained MetrABS) is the
     hard one: a random 79-block SiLU network amplifies every rounding. fp16 storage in every stage (the default, the reference's
     own TensorRT precision, 7_create_engines.py:10) has to stay inside the north star's 1e-3 of the FP32 ORACLE here too --
-    decoded 3D AND the absolute pose estimate() returns (measured 3.4e-4 / 5.6e-4) -- and the bf16-carrying
-    layouts, reported beside it, must be the worse ones (1.6e-3 / 9.1e-3 and 2.1e-3 / 6.7e-3)."""
+    decoded 3D AND the absolute pose estimate() returns -- on the max over 64 frames, with the per-frame p50 / p99 / max printed
+    (the absolute pose goes through a least-squares solve that amplifies heat-map noise: a max over 8 frames moved between 5e-4 and
+    9e-4 with rounding details alone). The bf16-carrying layouts, run beside it on the first 8 frames, must be
+    the worse ones (1.6e-3 / 9.1e-3 and 2.1e-3 / 6.7e-3)."""
     from isbfsar_amd import effnetv2
     from isbfsar_amd.hpe_engine import HpeEngine
     from oracle import hpe_oracle as ho
@@ -408,36 +420,40 @@ def test_signal_profile_fp16_vs_fp32_definition(assets):
     W, st = assets
     idx = st["smpl+head_30"]["indices"]
     state = effnetv2.make_state(0, "signal", head_gain=0.5)
-    B = 8
+    B = N_STAT
     fr, bb = synth.frames(B, seed=0), synth.bboxes(B, seed=0)
     crops = np.stack([ho.warp(fr[b], ho.crop_params(bb[b], _K())[2][0]) for b in range(B)])
     o32 = EffNetV2LOracle(state, "f32")
-    l32 = o32.head(o32.backbone(crops))
+    l32 = np.concatenate([o32.head(o32.backbone(crops[i:i + 16])) for i in range(0, B, 16)])
     p2_32, p3_32 = ho.decode(l32)
     res = {}
-    for prec in ("f16", "bf16_f16tail", "bf16"):
-        e = HpeEngine(device=0, max_batch=8, precision=prec)
+    for prec, n in (("f16", B), ("bf16_f16tail", 8), ("bf16", 8)):
+        e = HpeEngine(device=0, max_batch=B, precision=prec)
         try:
             e.set_joint_map(W, idx)
             e.load_weights(state)
-            joints, valid = e.forward(fr, bb)
-            _, lg = e.backbone(crops)
+            joints, valid = e.forward(fr[:n], bb[:n])
+            _, lg = e.backbone(crops[:n])
         finally:
             e.close()
         p2, p3 = ho.decode(lg)
-        e3 = float(np.abs(p3 - p3_32).max())
-        e2 = float(np.abs(p2 - p2_32).max())
-        ea = 0.0
-        for b in range(B):
+        e3 = np.abs(p3 - p3_32[:n]).reshape(n, -1).max(axis=1)
+        e2 = float(np.abs(p2 - p2_32[:n]).max())
+        ea = []
+        for b in range(n):
             nk, r, _ = ho.crop_params(bb[b], _K())
             ref = ho.postprocess(l32[b:b + 1], nk, r, W, idx)
             if ref is not None and valid[b]:
-                ea = max(ea, float(np.abs(joints[b] - ref).max()))
-        res[prec] = (e3, e2, ea)
-        print(f"signal profile vs fp32 definition, precision {prec}: decoded 3D {e3:.2e}, 2D {e2:.3f} px, absolute pose {ea:.2e}")
+                ea.append(float(np.abs(joints[b] - ref).max()))
+        assert len(ea) >= n - n // 8, (len(ea), n)          # (a frame whose joints leave the field of view has no pose to compare)
+        res[prec] = (float(e3.max()), e2, max(ea), float(e3[:8].max()))
+        a50, a99, amx = _pcts(ea)
+        d50, d99, dmx = _pcts(e3)
+        print(f"signal profile vs fp32 definition, precision {prec}, {len(ea)} of {n} frames: decoded 3D p50 {d50:.2e} p99 {d99:.2e} max {dmx:.2e}; "
+              f"2D {e2:.3f} px; absolute pose p50 {a50:.2e} p99 {a99:.2e} max {amx:.2e}")
     assert res["f16"][0] < 1e-3, res["f16"]                   # decoded 3D (heat-map units): the north star's 1e-3
     assert res["f16"][2] < 1e-3, res["f16"]                   # absolute pose: the same flat 1e-3
-    assert res["f16"][0] < 0.5 * res["bf16"][0] and res["f16"][0] < 0.5 * res["bf16_f16tail"][0]
+    assert res["f16"][3] < 0.5 * res["bf16"][0] and res["f16"][3] < 0.5 * res["bf16_f16tail"][0]      # (same 8 frames)
 
 
 def test_mixed_precision_vs_its_oracle(bbone_state, assets):
@@ -960,3 +976,62 @@ def test_set_lanes_changes_no_bit_and_refuses_nonsense(bbone_state, assets):
         assert np.array_equal(j2b, j2)
     finally:
         e.close()
+
+
+def test_shared_engines_read_one_model_and_give_the_same_bits(bbone_state, assets):
+    """isb_hpe_create_shared: engines that keep several batches in flight share ONE device copy of the weights. Three
+    engines of a family (parent + two children), each with its own batch on its own stream at the same time, give bit for bit what the
+    parent gives batch after batch; the family's device memory is one model + one workspace per engine; a child refuses weights and
+    joint maps of its own; the model outlives the parent."""
+    import torch
+    from isbfsar_amd._lib import IsbError
+    from isbfsar_amd.hpe_engine import HpeEngine
+    W, st = assets
+    B = 40
+    parent = HpeEngine(device=0, max_batch=B)
+    parent.set_joint_map(W, st["smpl+head_30"]["indices"])
+    parent.load_weights(bbone_state)
+    parent.set_lanes(1)
+    kids = [parent.share(), parent.share()]
+    try:
+        batches = [(torch.from_numpy(synth.frames(B, seed=900 + k)).cuda(), torch.from_numpy(synth.bboxes(B, seed=900 + k)).cuda()) for k in range(3)]
+        ref = []
+        for f, b in batches:                                    # one at a time through the parent
+            j, v = parent.forward(f, b)
+            torch.cuda.synchronize()
+            ref.append((j.cpu().numpy(), v.cpu().numpy()))
+        assert all(v.sum() > 0 for _, v in ref)
+        streams = [torch.cuda.Stream() for _ in range(3)]
+        outs = []
+        torch.cuda.synchronize()
+        for e, s, (f, b) in zip([parent] + kids, streams, batches):     # all three in flight
+            with torch.cuda.stream(s):
+                outs.append(e.forward(f, b))
+        torch.cuda.synchronize()
+        for (j, v), (jr, vr) in zip(outs, ref):
+            assert np.array_equal(j.cpu().numpy(), jr) and np.array_equal(v.cpu().numpy(), vr)
+        m0, w0, n0 = parent.memory()
+        assert n0 == 3 and m0 > 200e6                           # EfficientNetV2-L: ~240 MB of folded 16-bit weights + packed copies
+        for k in kids:
+            m, w, n = k.memory()
+            assert m == m0 and n == 3 and 0 < w <= w0 * 1.01    # the same model, a workspace of its own (same batch size)
+        free_before = torch.cuda.mem_get_info()[0]
+        extra = parent.share()
+        j, _ = extra.forward(*batches[0])
+        torch.cuda.synchronize()
+        used = free_before - torch.cuda.mem_get_info()[0]
+        assert used < w0 + 64e6 and used < m0, (used, w0, m0)   # a fourth engine costs a workspace, not a model
+        assert np.array_equal(j.cpu().numpy(), ref[0][0])
+        extra.close()
+        with pytest.raises(IsbError):
+            kids[0].load_weights(bbone_state)
+        with pytest.raises(IsbError):
+            kids[0].set_joint_map(W, None)
+        parent.close()                                          # the children keep the model alive
+        j, v = kids[1].forward(*batches[2])
+        torch.cuda.synchronize()
+        assert np.array_equal(j.cpu().numpy(), ref[2][0]) and kids[1].memory()[2] == 2
+    finally:
+        for k in kids:
+            k.close()
+        parent.close()
