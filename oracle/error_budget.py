@@ -156,14 +156,56 @@ def silu_study(a, crops, nks, rs, W, idx):
     return res
 
 
+def f16_points_study(a):
+    """Round 6: the product's layout IS fp16 everywhere; which of its rounding points carries the distance to the
+    fp32 definition on the hard ("signal") profile, as a DISTRIBUTION over frames (all 122 joints: what bench.py judges)? fp16 storage
+    switched on at one point / in one group of stages at a time, exact SiLU and the product's SiLU."""
+    from oracle import effnetv2_oracle as eo
+    assets = os.path.join(ROOT, "isbfsar_amd", "assets")
+    W = np.load(os.path.join(assets, "32_to_122.npy"))
+    crops, nks, rs = _inputs(a.frames)
+    forms = silu_forms()
+    exact, fast = forms["exact x * sigmoid(x) in f32 (the definition)"], forms["f32 exp2 / rcp (PRODUCT: silu_fast)"]
+    P = {"fp16 everywhere, exact SiLU": (lambda s, p: "f16", exact),
+         "fp16 everywhere, product SiLU (v_exp / v_rcp)": (lambda s, p: "f16", fast),
+         "f32 storage, product SiLU": (lambda s, p: "f32", fast)}
+    for pt in ROUND_POINTS:
+        P[f"only '{pt}' fp16"] = ((lambda pt: lambda s, p: "f16" if p == pt else "f32")(pt), exact)
+    for lo, hi, nm in ((-1, 2, "stem + stages 0-2"), (3, 4, "stages 3-4 (16x16 maps)"), (5, 7, "stages 5-6 + head conv (8x8 maps)")):
+        P[f"only {nm} fp16"] = ((lambda lo, hi: lambda s, p: "f16" if lo <= s <= hi else "f32")(lo, hi), exact)
+    P["fp16 everywhere but the residual stream (f32 'out')"] = (lambda s, p: "f32" if p == "out" else "f16", exact)
+    P["fp16 everywhere but the weights"] = (lambda s, p: "f32" if p == "w" else "f16", exact)
+    for prof in (["default", "signal"] if a.profile == "both" else [a.profile]):
+        state = effnetv2.make_state(0, profile=prof) if prof == "default" else effnetv2.make_state(0, prof, head_gain=0.5)
+        base = _poses(EffNetV2LOracle(state, "f32"), crops, nks, rs, W, None)
+        print(f"# profile {prof}: {a.frames} frames, 122 joints; |absolute pose - fp32 definition| per frame: p50 / p90 / max; decoded 3D max", flush=True)
+        keep = eo._silu
+        try:
+            for name, (pol, fn) in P.items():
+                if a.only and a.only not in name:
+                    continue
+                eo._silu = fn
+                got = _poses(EffNetV2LOracle(state, "f32", rounding=pol), crops, nks, rs, W, None)
+                d = np.sort([float(np.abs(g[2] - b[2]).max()) for g, b in zip(got, base) if g[2] is not None and b[2] is not None])
+                d3 = max(float(np.abs(g[1] - b[1]).max()) for g, b in zip(got, base))
+                print(f"{name:60s} {np.median(d):9.2e} {d[int(0.9 * (len(d) - 1))]:9.2e} {d[-1]:9.2e}   {d3:9.2e}", flush=True)
+        finally:
+            eo._silu = keep
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="", help="--f16points: only the layouts whose name holds this substring")
+    ap.add_argument("--f16points", action="store_true", help="round 6: the fp16 layout's distance to fp32 by rounding point, per-frame distribution")
     ap.add_argument("--frames", type=int, default=4)
     ap.add_argument("--profile", default="both")
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--silu", action="store_true", help="price cheaper SiLU arithmetic under the product's fp16 storage layout")
     ap.add_argument("--json", default=None)
     a = ap.parse_args()
+    if a.f16points:
+        f16_points_study(a)
+        return
     if a.silu:
         assets = os.path.join(ROOT, "isbfsar_amd", "assets")
         W = np.load(os.path.join(assets, "32_to_122.npy"))
