@@ -362,6 +362,15 @@ int isb_debug_dwconv_fc1(int32_t device, const uint16_t* h_x, const float* h_w, 
                          int32_t B, int32_t H, int32_t C, int32_t stride, int32_t iters, uint16_t* h_out, float* h_pooled,
                          float* ms_per_iter, const float* h_se_w1, int32_t cse, float* h_se_part, int32_t* n_parts);
 
+/* test / tuning hook: the FRONT half of a stride-1 MBConv block on 16 x 16 maps -- 1x1 expand + folded BN + SiLU -> depthwise 3x3 + folded
+ * BN + SiLU -> D [B,16,16,cexp] (what the gated projection reads) + the squeeze-excite pool [B,cexp] -- on host tensors, three ways that
+ * must give the same bits: form 0 = two launches (expand GEMM, matrix-pipe depthwise kernel), 1 = the fused front of round 5 (every
+ * wave does everything, three waves per SIMD), 2 = the fused front with producer / consumer waves (round 6, four waves per SIMD).
+ *   h_x 16-bit [B,16,16,cin] (cin 192 / 224), h_w1 f32 [cexp,cin], h_dww f32 [cexp,3,3]; f16: the 16-bit type is IEEE fp16, else bf16 */
+int isb_debug_mbfront16(int32_t device, const uint16_t* h_x, const float* h_w1, const float* h_scale1, const float* h_shift1,
+                        const float* h_dww, const float* h_dwscale, const float* h_dwshift, int32_t B, int32_t cin, int32_t cexp,
+                        int32_t f16, int32_t form, int32_t iters, uint16_t* h_d, float* h_pooled, float* ms_per_iter);
+
 /* ------------------------------------------------------------------------------------------
  * Glue between the two stages (main.py:102-105 + ar.py:42-50): root-centre every pose on joint 0,
  * flatten to 3J and cut sliding windows of L consecutive frames per camera.

@@ -285,6 +285,280 @@ __global__ __launch_bounds__(256, 3) void mbfront16_kernel(MbFront16Args p) {
     }
 }
 
+// =====================================================================================
+// Round 6: the same front half with the waves of a workgroup in DIFFERENT ROLES -- four waves per SIMD.
+//
+// mbfront16_kernel above keeps three waves per SIMD (164 registers: 56 stationary weight registers + the depthwise stage's fragments and
+// sums in the same wave) and every wave walks expand -> SiLU -> taps -> SiLU in turn: its clocks say each phase takes 3-4x its issue cost
+// (EXPERIMENTS.md round 5: vector ALU 52 % busy, matrix pipe 19 %). Here a workgroup is EIGHT waves on one 128-channel slice:
+//   waves 0-3  PRODUCERS  (one per SIMD): the expand GEMM of a band (32 pixels x the wave's 32 channels, weights stationary in 56
+//              registers, bias in 16), SiLU, one rounding, the two E rows into the channel block's ring in LDS; they also issue the
+//              LDS-DMA of the next band's input tile (two buffers) and have no other vector-memory operation, so their wait for it is a
+//              plain vmcnt(0);
+//   waves 4-7  CONSUMERS  (one per SIMD): depthwise 3x3 on the matrix pipe from the ring (weight fragments stationary in 48 registers:
+//              the Toeplitz fragments depend on the lane and the tap, not on the data), SiLU, one rounding, pooled sums, the two D rows.
+// Neither role needs the other's registers: 128 suffice and TWO such workgroups share a CU -- four waves per SIMD, two of them in an
+// MFMA + SiLU stream and two in a fragment-read + MFMA + SiLU + store stream, two ticks apart. One workgroup barrier per band ("tick"):
+// at tick T the producers write band T's rows while the consumers compute the output rows of band T - 2 from rows that are complete.
+// The ring has 8 slots per channel block; rows are numbered through the samples of a segment, G = 17 j + 1 + y (sample j, image row y;
+// row 16 of a sample and row -1 of the next are ONE zero row), slot = G & 7: live at tick T are the 7 rows 2T - 5 .. 2T + 1.
+// Arithmetic and orders are the first kernel's (k ascending in one accumulator; tap MFMAs; lane sums over the bands in order, then the
+// 32 slots in order): bit-identical to it and to the two-launch path (tested).
+// Work: units (slice, sample) of an XCD's samples in slice-major order, cut into equal contiguous ranges for the XCD's 64 workgroup
+// slots (a range that crosses a slice boundary drains and reloads: at most one of the 64).
+template <int CIN>
+struct Mf16r {
+    static constexpr int NK16 = CIN / 16, NKT = CIN / 32;
+    static constexpr int XBUF = NKT * 2048;                 // a band's input tile: [NKT][32 rows][64 B], swizzled (gemm1x1's A image)
+    static constexpr int ROW = 18 * 64;                     // one padded ring row: [18 pixels][32 ch x 2 B]
+    static constexpr int RING = 8 * ROW;                    // eight slots per channel block
+    static constexpr int RING_OFF = 2 * XBUF;
+    static constexpr int TBL_OFF = RING_OFF + 4 * RING;
+    static constexpr int TBL_BYTES = 1024;                  // per channel block: depthwise bias [32] f32 at 128 | taps [9][32] 16-bit at 256
+    static constexpr int LDS = TBL_OFF + 4 * TBL_BYTES;
+    static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
+};
+
+template <int CIN, bool F16>
+__global__ __launch_bounds__(512, 4) void mbfront16r_kernel(MbFront16Args p) {
+    using S = Mf16r<CIN>;
+    constexpr int NK16 = S::NK16, ROW = S::ROW;
+    T16<F16>::enter();
+    unsigned char* const lds = conv_lds_dyn;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wave < 4;
+    const int cbw = wave & 3;                                          // channel block of the slice this wave works on
+    const int CEXP = p.cexp, NSL = (CEXP + 127) / 128;
+    // this workgroup's units: XCD x (ids 8 apart share one) owns samples [x Bx, x Bx + nx); its slots cut NSL * nx units evenly
+    const int xcd = blockIdx.x & 7, slot_id = blockIdx.x >> 3, nslots = (int)(gridDim.x >> 3);
+    const int Bx = (p.B + 7) / 8, smp0 = xcd * Bx, nx = min(Bx, p.B - smp0);
+    if (nx <= 0) return;
+    const int U = NSL * nx;
+    int u = (int)((long long)slot_id * U / nslots);
+    const int u1 = (int)((long long)(slot_id + 1) * U / nslots);
+    if (u >= u1) return;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)lds;
+    unsigned char* const ring = lds + S::RING_OFF + cbw * S::RING;
+    unsigned char* const tbl = lds + S::TBL_OFF + cbw * S::TBL_BYTES;
+
+    // band (sample smp, band bnd) -> X buffer buf: piece pc = (k-tile pc >> 1, rows 16 (pc & 1) ..), 1 KiB each; issued by the producers
+    auto dma_x = [&](int smp, int bnd, int buf) {
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(p.x) + ((size_t)smp * 256 + bnd * 32) * (CIN * 2);
+        for (int pc = cbw; pc < S::NKT * 2; pc += 4) {
+            const int kt = pc >> 1, row = 16 * (pc & 1) + (lane >> 2);
+            const int logical = (lane & 3) ^ ((row >> 2) & 3);
+            dma16_s(src, (uint32_t)(row * CIN * 2 + kt * 64 + logical * 16), lds0 + (uint32_t)(buf * S::XBUF + pc * 1024));
+        }
+    };
+    // the ring, zero columns included (only interiors are ever written afterwards): once per workgroup, by all eight waves
+    for (int i = tid; i < 4 * S::RING / 16; i += 512) *reinterpret_cast<uint4*>(lds + S::RING_OFF + i * 16) = make_uint4(0, 0, 0, 0);
+
+    // a segment: n samples of one slice (the role branch is OUTSIDE the segment loop: inside it the compiler hoists both roles' lane
+    // constants above the branch and spills 47 registers)
+#define ISB_MBF16R_SEGMENT                                                                                                  \
+        const int slice = u / nx, i0 = u % nx, n = min(nx - i0, u1 - u);                                                      \
+        u += n;                                                                                                               \
+        const int sbase = smp0 + i0;                                                                                          \
+        const int cb = min(slice * 4 + cbw, CEXP / 32 - 1), c0 = cb * 32;                                                     \
+        const bool live = (slice * 4 + cbw) * 32 < CEXP;    /* 1344 channels = 10 slices + 64: the last slice's upper waves only keep the barriers (producers: and stage tiles) */ \
+        const int nticks = 8 * n + 2;
+    if (producer) {
+        while (u < u1) {
+            ISB_MBF16R_SEGMENT
+            // ---------------------------------------------------------------- producer
+            const int r = lane & 31, h = lane >> 5;
+            uint4 wreg[NK16];
+            {
+                const uint4* src = p.w1p + (size_t)cb * NK16 * 64 + lane;
+#pragma unroll
+                for (int s = 0; s < NK16; ++s) wreg[s] = src[s * 64];
+            }
+            float4 bias[4];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) bias[qq] = *reinterpret_cast<const float4*>(p.b1 + c0 + 8 * qq + 4 * h);
+            const int a_sw0 = swz(r, h), a_sw1 = swz(r, 2 + h);
+            // E write: lane = pixel r of the band (row r >> 4, column r & 15), 16 channels 4 h + 8 qq + i; chunk slots turned by
+            // f(y, x) = ((x >> 2) & 1) | ((y & 1) << 1) as in the first kernel (the band's first row 2 t is even)
+            const int e_x = (r & 15) + 1, e_rr = r >> 4;
+            const int e_lane = e_x * 64 + h * 8;
+            const int e_f = ((e_x >> 2) & 1) | (e_rr << 1);
+            dma_x(sbase, 0, 0);
+            *reinterpret_cast<uint4*>(ring + 64 + lane * 16) = make_uint4(0, 0, 0, 0);          // Z_0 (slot 0): row -1 of the first sample
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll 1
+            for (int T = 0; T < nticks; ++T) {
+                if (T < 8 * n) {
+                    const int j = T >> 3, t = T & 7;
+                    if (T + 1 < 8 * n) dma_x(sbase + ((T + 1) >> 3), (T + 1) & 7, (T + 1) & 1);
+                    const int g0 = 17 * j + 1 + 2 * t;              // ring row index of image row 2 t (wave-uniform)
+                    if (live) {
+                        const unsigned char* const xb = lds + (T & 1) * S::XBUF;
+                        f32x16 acc;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+                        uint4 fa[2][2];
+                        auto rd = [&](int pr2, uint4 (&f)[2]) __attribute__((always_inline)) {
+                            f[0] = *reinterpret_cast<const uint4*>(xb + pr2 * 2048 + a_sw0);
+                            f[1] = *reinterpret_cast<const uint4*>(xb + pr2 * 2048 + a_sw1);
+                        };
+                        rd(0, fa[0]);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int pr2 = 0; pr2 < NK16 / 2; ++pr2) {
+                            if (pr2 + 1 < NK16 / 2) rd(pr2 + 1, fa[(pr2 + 1) & 1]);
+                            acc = T16<F16>::mfma32(wreg[2 * pr2], fa[pr2 & 1][0], acc);
+                            acc = T16<F16>::mfma32(wreg[2 * pr2 + 1], fa[pr2 & 1][1], acc);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        // E = T16(silu(acc + bias)) -> ring rows 2 t, 2 t + 1
+                        unsigned char* const cell = ring + ((g0 + e_rr) & 7) * ROW + e_lane;
+#pragma unroll
+                        for (int qq = 0; qq < 4; ++qq) {
+                            const float v0 = silu_fast(acc[4 * qq] + bias[qq].x), v1 = silu_fast(acc[4 * qq + 1] + bias[qq].y);
+                            const float v2 = silu_fast(acc[4 * qq + 2] + bias[qq].z), v3 = silu_fast(acc[4 * qq + 3] + bias[qq].w);
+                            uint2 pk;
+                            pk.x = T16<F16>::pack2(v0, v1);
+                            pk.y = T16<F16>::pack2(v2, v3);
+                            *reinterpret_cast<uint2*>(cell + ((qq ^ e_f) << 4)) = pk;
+                        }
+                        // the zero row between this sample and the next (its slot's last tenant, row 8 of this sample, died two ticks ago)
+                        if (t == 7) *reinterpret_cast<uint4*>(ring + ((17 * (j + 1)) & 7) * ROW + 64 + lane * 16) = make_uint4(0, 0, 0, 0);
+                    }
+                }
+                // the next band's tile has landed (this wave's pieces; the barrier joins the other producers'), the E rows are written
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+        }
+    } else {
+        while (u < u1) {
+            ISB_MBF16R_SEGMENT
+            // ---------------------------------------------------------------- consumer
+            // the block's depthwise bias and taps in the channel block's LDS table, then the weight fragments for the whole segment
+            if (lane < 8) *reinterpret_cast<float4*>(tbl + 128 + lane * 16) = *reinterpret_cast<const float4*>(p.dwb + c0 + lane * 4);
+            else if (lane >= 16 && lane < 16 + 36) {
+                const int t = (lane - 16) >> 2, c4 = (lane - 16) & 3;
+                *reinterpret_cast<uint4*>(tbl + 256 + t * 64 + c4 * 16) = *reinterpret_cast<const uint4*>(p.dww + (size_t)t * CEXP + c0 + c4 * 8);
+            }
+            const DwmmLane wl(lane);
+            const int w_d = min(max(wl.d, 0), 2);
+            const int mn = lane & 15, mj = lane >> 4, ms = mj >> 1;    // pixel pair, input column / output rows, pixel of the pair
+            uint4 af[4][3];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+                    af[g][ky] = wl.place((uint32_t)*reinterpret_cast<const uint16_t*>(tbl + 256 + (ky * 3 + w_d) * 64 + (g * 8 + wl.c) * 2));
+            uint32_t one_lo, one_hi;                                    // (1, 0) / (0, 1) pairs in the storage type
+            if constexpr (F16) asm volatile("v_mov_b32 %0, 0x3c00\n\tv_lshlrev_b32 %1, 16, %0" : "=v"(one_lo), "=v"(one_hi));
+            else asm volatile("v_mov_b32 %0, 0x3f80\n\tv_lshlrev_b32 %1, 16, %0" : "=v"(one_lo), "=v"(one_hi));
+            // B fragment: output row ry of the step's two, pixel pair; input row index ry + ky of the four rows 2s - 3 .. 2s
+            const int t_ry = mn >> 3, t_x = 2 * (mn & 7) + mj;         // padded column of the fragment's pixel
+            const int t_lane = t_x * 64;
+            int t_f[2];
+            t_f[0] = ((t_x >> 2) & 1) | (((t_ry + 1) & 1) << 1);       // ky even: image row 2s - 3 + ry + ky is odd iff ry + ky is even
+            t_f[1] = ((t_x >> 2) & 1) | ((t_ry & 1) << 1);             // ky odd
+            // D staging: the step's two output rows leave through the interiors of the two ring rows its taps read LAST
+            const int d_x = 2 * (mn & 7) + ms;
+            const int d_lane = (d_x + 1) * 64 + (mj & 1) * 8;
+            const int d_f = (d_x >> 1) & 3;
+            float psum[4][4];
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll 1
+            for (int T = 0; T < nticks; ++T) {
+                if (T >= 2 && live) {
+                    const int j = (T - 2) >> 3, s = ((T - 2) & 7) + 1;     // output rows 2s - 2, 2s - 1 of sample j from ring rows 2s - 3 .. 2s
+                    if (s == 1) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) psum[g][i] = 0.f;
+                    }
+                    const int g0 = 17 * j + 2 * s - 2;                  // ring row index of image row 2s - 3 (wave-uniform)
+                    int rowoff[3];
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const int s_a = ((g0 + ky) & 7) * ROW, s_b = ((g0 + 1 + ky) & 7) * ROW;
+                        rowoff[ky] = (t_ry ? s_b : s_a) + t_lane;
+                    }
+                    f32x4 a4[4];
+                    {
+                        uint4 bf[2][3];
+                        auto rdb = [&](int g, uint4 (&f)[3]) __attribute__((always_inline)) {
+#pragma unroll
+                            for (int ky = 0; ky < 3; ++ky) f[ky] = *reinterpret_cast<const uint4*>(ring + rowoff[ky] + ((g ^ t_f[ky & 1]) << 4));
+                        };
+                        rdb(0, bf[0]);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const float4 db = *reinterpret_cast<const float4*>(tbl + 128 + (g * 8 + 4 * (mj & 1)) * 4);
+                            if (g + 1 < 4) rdb(g + 1, bf[(g + 1) & 1]);
+                            f32x4 c4 = f32x4{db.x, db.y, db.z, db.w};
+#pragma unroll
+                            for (int ky = 0; ky < 3; ++ky) c4 = mfma16<F16>(af[g][ky], bf[g & 1][ky], c4);
+                            a4[g] = c4;
+                        }
+                    }
+                    // SiLU, one rounding, pooled sums (the pool sees the stored activations), the two D rows through the dead ring rows
+                    const int d_r0 = (g0 & 7) * ROW, d_r1 = ((g0 + 1) & 7) * ROW;       // slots of image rows 2s - 3, 2s - 2
+                    const int d_row = t_ry ? d_r1 : d_r0;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const uint32_t pk0 = T16<F16>::pack2(silu_fast(a4[g][0]), silu_fast(a4[g][1]));
+                        const uint32_t pk1 = T16<F16>::pack2(silu_fast(a4[g][2]), silu_fast(a4[g][3]));
+                        psum[g][0] = T16<F16>::dot2(pk0, one_lo, psum[g][0]);
+                        psum[g][1] = T16<F16>::dot2(pk0, one_hi, psum[g][1]);
+                        psum[g][2] = T16<F16>::dot2(pk1, one_lo, psum[g][2]);
+                        psum[g][3] = T16<F16>::dot2(pk1, one_hi, psum[g][3]);
+                        *reinterpret_cast<uint2*>(ring + d_row + d_lane + ((g ^ d_f) << 4)) = make_uint2(pk0, pk1);
+                    }
+                    const int smp = sbase + j;
+                    {
+                        uint16_t* const drow = p.d + ((size_t)smp * 256 + (2 * s - 2) * 16) * CEXP + c0 + (lane & 3) * 8;
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            const int px = (lane >> 2) + 16 * i, xx = lane >> 2;
+                            const uint4 v = *reinterpret_cast<const uint4*>(ring + (i ? d_r1 : d_r0) + (xx + 1) * 64 + (((lane & 3) ^ ((xx >> 1) & 3)) << 4));
+                            *reinterpret_cast<uint4*>(drow + (size_t)px * CEXP) = v;
+                        }
+                    }
+                    if (s == 8) {
+                        // pooled means: the lanes' sums over the eight bands -> the 32 (pixel pair, pixel) slots in order, / 256. Scratch: the
+                        // interiors of the two rows the D rows just left through (2 KiB = 16 slots x 32 channels): slots 0-15, then 16-31
+                        auto red_at = [&](int fl) __attribute__((always_inline)) {    // float index -> address
+                            const int o = fl * 4;
+                            return reinterpret_cast<float*>(ring + ((o >> 10) ? d_r1 : d_r0) + 64 + (o & 1023));
+                        };
+                        float tsum = 0.f;
+#pragma unroll
+                        for (int half = 0; half < 2; ++half) {
+                            if ((mn >> 3) == half) {
+#pragma unroll
+                                for (int g = 0; g < 4; ++g)
+                                    *reinterpret_cast<float4*>(red_at((2 * (mn & 7) + ms) * 32 + g * 8 + 4 * (mj & 1))) =
+                                        make_float4(psum[g][0], psum[g][1], psum[g][2], psum[g][3]);
+                            }
+                            if (lane < 32) {
+                                float rv[16];
+#pragma unroll
+                                for (int s2 = 0; s2 < 16; ++s2) rv[s2] = *red_at(s2 * 32 + lane);
+#pragma unroll
+                                for (int s2 = 0; s2 < 16; ++s2) tsum += rv[s2];
+                            }
+                        }
+                        if (lane < 32) p.pooled[(size_t)smp * CEXP + c0 + lane] = tsum / 256.0f;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+        }
+    }
+#undef ISB_MBF16R_SEGMENT
+}
+
+
 int launch_mbfront16(const MbFront16Args& a, hipStream_t st) {
     if (a.B < 1 || !a.x || !a.w1p || !a.b1 || !a.dww || !a.dwb || !a.d || !a.pooled || (a.cin != 192 && a.cin != 224) || a.cexp % 32 != 0 ||
         a.cexp < 128) {
@@ -295,6 +569,32 @@ int launch_mbfront16(const MbFront16Args& a, hipStream_t st) {
     const int Qx = std::max(1, std::min(cdiv(a.B, 8), 768 / (8 * nsl)));     // sample sequences per XCD: three workgroups per CU
     MbFront16Args aa = a;
     aa.exp = exp_flags();
+    // round 6: producer / consumer waves, four waves per SIMD (mbfront16r_kernel). a.form: 0 = the library's choice, 1 = the first
+    // kernel (every wave does everything, three waves per SIMD), 2 = roles. ISB_MBF16_FORM overrides the choice (A/B runs, tests).
+    static const int env_form = [] { const char* e = getenv("ISB_MBF16_FORM"); return e ? atoi(e) : 0; }();
+    const int form = a.form ? a.form : (env_form ? env_form : 2);
+    if (form == 2 && !a.stamps) {
+        const int nslots = std::min(64, nsl * cdiv(a.B, 8));
+#define ISB_MBF16R(CIN_, F16_)                                                                                               \
+    do {                                                                                                                     \
+        static DevOnce attr_set;                                                                                             \
+        if (attr_set.need()) {                                                                                               \
+            ISB_HIP(hipFuncSetAttribute((const void*)mbfront16r_kernel<CIN_, F16_>, hipFuncAttributeMaxDynamicSharedMemorySize, Mf16r<CIN_>::LDS)); \
+            attr_set.mark();                                                                                                 \
+            if (getenv("ISB_OCC")) {                                                                                         \
+                int nb = -1;                                                                                                 \
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)mbfront16r_kernel<CIN_, F16_>, 512, Mf16r<CIN_>::LDS); \
+                fprintf(stderr, "[isb] mbfront16r<%d>: %d workgroups per CU by the occupancy API (LDS %d B)\n", CIN_, nb, Mf16r<CIN_>::LDS); \
+            }                                                                                                                \
+        }                                                                                                                    \
+        hipLaunchKernelGGL((mbfront16r_kernel<CIN_, F16_>), dim3(8 * nslots), dim3(512), Mf16r<CIN_>::LDS, st, aa);          \
+    } while (0)
+        if (a.cin == 224) { if (a.f16) ISB_MBF16R(224, true); else ISB_MBF16R(224, false); }
+        else { if (a.f16) ISB_MBF16R(192, true); else ISB_MBF16R(192, false); }
+#undef ISB_MBF16R
+        ISB_LAUNCHED("mbfront16r", st);
+        return ISB_OK;
+    }
 #define ISB_MBF16(CIN_, F16_)                                                                                                \
     do {                                                                                                                     \
         static DevOnce attr_set;                                                                                             \

@@ -1594,6 +1594,86 @@ extern "C" int isb_debug_fused_mb(int32_t device, const uint16_t* x, const float
     });
 }
 
+// test / tuning hook: the FRONT half of a stride-1 MBConv block on 16 x 16 maps (1x1 expand + BN + SiLU -> depthwise 3x3 + BN + SiLU ->
+// D + squeeze-excite pool) on host tensors, three ways that must give the same bits: form 0 = the two launches (expand GEMM, then
+// dwconv3x3_mm_kernel<16>), 1 = mbfront16_kernel, 2 = mbfront16r_kernel (conv_mb16.hip)
+extern "C" int isb_debug_mbfront16(int32_t device, const uint16_t* x, const float* w1, const float* scale1, const float* shift1,
+                                   const float* dww, const float* dwscale, const float* dwshift, int32_t B, int32_t cin, int32_t cexp,
+                                   int32_t f16, int32_t form, int32_t iters, uint16_t* d_out, float* pooled, float* ms_per_iter) {
+    return isb::guard([&]() -> int {
+        ISB_REQUIRE(x && w1 && scale1 && shift1 && dww && dwscale && dwshift && d_out && pooled && ms_per_iter, ISB_ERR_INVALID, "null argument");
+        ISB_REQUIRE(B >= 1 && (cin == 192 || cin == 224) && cexp % 32 == 0 && cexp >= 128 && iters >= 1 && form >= 0 && form <= 2, ISB_ERR_INVALID,
+                    "bad parameters (cin 192 / 224, cexp a multiple of 32, form 0..2)");
+        ISB_HIP(hipSetDevice(device));
+        const size_t nin = (size_t)B * 256 * cin, nout = (size_t)B * 256 * cexp;
+        std::vector<uint16_t> wt16((size_t)9 * cexp);
+        for (int c = 0; c < cexp; ++c)
+            for (int t = 0; t < 9; ++t) {
+                const float wf = dww[(size_t)c * 9 + t] * dwscale[c];
+                if (f16) {
+                    const _Float16 hh = (_Float16)wf;
+                    memcpy(&wt16[(size_t)t * cexp + c], &hh, 2);
+                } else {
+                    wt16[(size_t)t * cexp + c] = bf16_rne(wf);
+                }
+            }
+        DevBuf dx, dw1f, ds1, db1, dw1, dw1p, ddw, ddb, dE, dD, dpool, dzero;
+        ISB_TRY(upload(dx, x, nin * 2));
+        ISB_TRY(upload(dw1f, w1, (size_t)cexp * cin * 4));
+        ISB_TRY(upload(ds1, scale1, (size_t)cexp * 4));
+        ISB_TRY(upload(db1, shift1, (size_t)cexp * 4));
+        ISB_TRY(upload(ddw, wt16.data(), wt16.size() * 2));
+        ISB_TRY(upload(ddb, dwshift, (size_t)cexp * 4));
+        ISB_TRY(dw1.alloc((size_t)cexp * cin * 2));
+        ISB_TRY(dw1p.alloc((size_t)cexp * cin * 2));
+        ISB_TRY(dD.alloc(nout * 2));
+        ISB_TRY(dpool.alloc((size_t)B * cexp * 4));
+        ISB_TRY(dzero.alloc(256));
+        ISB_HIP(hipMemset(dzero.p, 0, 256));
+        ISB_HIP(hipMemset(dD.p, 0xff, nout * 2));
+        ISB_HIP(hipMemset(dpool.p, 0xff, (size_t)B * cexp * 4));
+        ISB_TRY(launch_f32_to_bf16_rows(dw1f.as<float>(), ds1.as<float>(), dw1.as<uint16_t>(), cexp, (size_t)cin, nullptr, f16));
+        ISB_TRY(launch_mb8_pack_frag(dw1.as<uint16_t>(), dw1p.p, cexp, cin, 1, nullptr));
+        if (form == 0) ISB_TRY(dE.alloc(nout * 2));
+        auto run = [&]() -> int {
+            if (form == 0) {
+                ConvArgs a{};
+                a.f16 = f16;
+                a.in = dx.as<uint16_t>(); a.w = dw1.as<uint16_t>(); a.bias = db1.as<float>(); a.out = dE.p;
+                a.B = B; a.H = 16; a.W = 16; a.Cin = cin; a.Cout = cexp; a.KH = 1; a.KW = 1; a.stride = 1; a.OH = 16; a.OW = 16;
+                a.pad = 0; a.M = B * 256; a.K = cin; a.act = 1; a.zeros = dzero.as<uint16_t>();
+                ISB_TRY(launch_conv_igemm(a, nullptr));
+                DwArgs d{};
+                d.in = dE.as<uint16_t>(); d.w = ddw.as<uint16_t>(); d.bias = ddb.as<float>(); d.out = dD.as<uint16_t>();
+                d.pooled = dpool.as<float>(); d.B = B; d.H = 16; d.W = 16; d.C = cexp; d.OH = 16; d.OW = 16; d.stride = 1; d.pad = 1;
+                d.in_f16 = f16; d.out_f16 = f16; d.general = 3;
+                return launch_dwconv3x3(d, nullptr);
+            }
+            MbFront16Args a{};
+            a.x = dx.as<uint16_t>(); a.w1p = (const uint4*)dw1p.p; a.b1 = db1.as<float>(); a.dww = ddw.as<uint16_t>(); a.dwb = ddb.as<float>();
+            a.d = dD.as<uint16_t>(); a.pooled = dpool.as<float>(); a.B = B; a.cin = cin; a.cexp = cexp; a.f16 = f16; a.form = form;
+            return launch_mbfront16(a, nullptr);
+        };
+        ISB_TRY(run());
+        ISB_HIP(hipDeviceSynchronize());
+        hipEvent_t e0, e1;
+        ISB_HIP(hipEventCreate(&e0));
+        ISB_HIP(hipEventCreate(&e1));
+        ISB_HIP(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < iters; ++i) ISB_TRY(run());
+        ISB_HIP(hipEventRecord(e1, nullptr));
+        ISB_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        ISB_HIP(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        *ms_per_iter = ms / iters;
+        ISB_HIP(hipMemcpy(d_out, dD.p, nout * 2, hipMemcpyDeviceToHost));
+        ISB_HIP(hipMemcpy(pooled, dpool.p, (size_t)B * cexp * 4, hipMemcpyDeviceToHost));
+        return ISB_OK;
+    });
+}
+
 // test / tuning hook: depthwise 3x3 + SiLU + SE mean on host tensors
 // test / tuning hook: one launch_gemm_f32 on host tensors (every A-operand option of GemmF32Args), timed with HIP events
 extern "C" int isb_debug_gemm_f32(int32_t device, const float* A, const float* W, const float* bias, const float* a_bias,

@@ -234,6 +234,8 @@ struct MbFront16Args {
     uint16_t* d;            // out [B][256][cexp] 16-bit
     float* pooled;          // out [B][cexp] f32 spatial means
     int B, cin, cexp, f16;
+    int form;               // 0 = the library's choice; 1 = mbfront16_kernel (every wave does everything, three waves per SIMD); 2 = mbfront16r_kernel
+                            // (producer / consumer waves, four per SIMD; round 6). Same bits either way.
     int exp;                // open experiments (isb::exp_flags(), set by the launcher): bit 16 = the stamps are a census of every workgroup's start / end
     uint64_t* stamps;       // tuning probe or null: [32 workgroups][6 waves][10] = loop cycles, band steps, then per-phase sums: tile wait + barrier,
                             // expand MFMAs, second barrier, E epilogue, depthwise MFMAs, SiLU + D rows, pooled means
