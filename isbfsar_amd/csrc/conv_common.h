@@ -105,6 +105,14 @@ __device__ __forceinline__ float silu_fast(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
 
+// two values at once, the arithmetic of silu_fast bit for bit (the same IEEE multiply / add per half): the three plain operations as packed
+// f32 instructions (one issue slot per pair instead of two), the transcendentals per value
+__device__ __forceinline__ f32x2_t silu_fast2(f32x2_t x) {
+    const f32x2_t t = x * f32x2_t{-1.4426950408889634f, -1.4426950408889634f};
+    const f32x2_t d = f32x2_t{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + f32x2_t{1.0f, 1.0f};
+    return x * f32x2_t{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+}
+
 // the same with the reciprocal refined by one Newton step (r' = r + r (1 - d r): two v_fma more; <= 0.5 ulp of 1 / d instead of 1)
 __device__ __forceinline__ float silu_nr(float x) {
     const float d = 1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x);

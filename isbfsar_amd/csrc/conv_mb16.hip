@@ -115,7 +115,6 @@ __global__ __launch_bounds__(256, 3) void mbfront16_kernel(MbFront16Args p) {
     uint64_t stp[7] = {0, 0, 0, 0, 0, 0, 0}, st_t0 = 0, st_n = 0;       // tuning probe (MbFront16Args.stamps)
     uint64_t st_r0 = 0;
     if (p.stamps) { st_t0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
-    bool first = true;
     for (int smp = q; smp < p.B; smp += Q) {
         // Three workgroups share a CU and a SIMD's issue port goes to the OLDEST wave first: left alone, a CU's first workgroup runs at
         // full speed (4 samples in 71 us), the third crawls (3 samples in 96 us) and the launch ends with CUs a third full (census of
@@ -144,9 +143,11 @@ __global__ __launch_bounds__(256, 3) void mbfront16_kernel(MbFront16Args p) {
                 // ---- the band's tile landed (requested behind the previous band's MFMAs). Younger vector-memory operations of this
                 // wave may keep flying (vmcnt retires in order): the two D-row stores of the previous band's depthwise step, and at a
                 // sample's first band the previous sample's last four D-row stores and its pooled means
-                if (s >= 2 && live) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");        // (a wave without channels has no stores: its tile pieces are its youngest operations)
-                else if (s == 0 && !first && live) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // Round 6: this kernel is no longer the default (mbfront16r_kernel below is; this one stays as form 1, the A/B partner and
+                // the bit-identity test's second witness), so its hand-counted waits -- vmcnt(2) behind a band's two D-row stores, vmcnt(5)
+                // behind a sample's last four and its pooled means: correct only while the compiler emits exactly those stores --
+                // became a plain vmcnt(0): +3 % on a kernel nobody times any more, and nothing left to verify in the disassembly.
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 if (p.stamps) t1 = __builtin_amdgcn_s_memtime();
                 // ---- expand: 32 pixels x the wave's 32 channels; fragment reads two k16 steps ahead (second register set)
@@ -270,7 +271,6 @@ __global__ __launch_bounds__(256, 3) void mbfront16_kernel(MbFront16Args p) {
             for (int s2 = 0; s2 < 32; ++s2) t += rv[s2];
             p.pooled[(size_t)smp * CEXP + c0 + lane] = t / 256.0f;
         }
-        first = false;
         if (p.stamps) stp[6] += __builtin_amdgcn_s_memtime() - tp;
     }
     if (p.stamps && (p.exp & 0x10000) && tid == 0 && blockIdx.x < 1000) {       // census: every workgroup's loop start / end on the 100-MHz clock
@@ -294,32 +294,38 @@ __global__ __launch_bounds__(256, 3) void mbfront16_kernel(MbFront16Args p) {
 //   waves 0-3  PRODUCERS  (one per SIMD): the expand GEMM of a band (32 pixels x the wave's 32 channels, weights stationary in 56
 //              registers, bias in 16), SiLU, one rounding, the two E rows into the channel block's ring in LDS; they also issue the
 //              LDS-DMA of the next band's input tile (two buffers) and have no other vector-memory operation, so their wait for it is a
-//              plain vmcnt(0);
+//              plain vmcnt(0) -- no counted wait anywhere in this kernel;
 //   waves 4-7  CONSUMERS  (one per SIMD): depthwise 3x3 on the matrix pipe from the ring (weight fragments stationary in 48 registers:
 //              the Toeplitz fragments depend on the lane and the tap, not on the data), SiLU, one rounding, pooled sums, the two D rows.
 // Neither role needs the other's registers: 128 suffice and TWO such workgroups share a CU -- four waves per SIMD, two of them in an
 // MFMA + SiLU stream and two in a fragment-read + MFMA + SiLU + store stream, two ticks apart. One workgroup barrier per band ("tick"):
 // at tick T the producers write band T's rows while the consumers compute the output rows of band T - 2 from rows that are complete.
-// The ring has 8 slots per channel block; rows are numbered through the samples of a segment, G = 17 j + 1 + y (sample j, image row y;
-// row 16 of a sample and row -1 of the next are ONE zero row), slot = G & 7: live at tick T are the 7 rows 2T - 5 .. 2T + 1.
+// The ring of a channel block: ten rows -- a zero row, eight slots (image row y lives in slot y & 7; live at a tick are the 7 rows
+// 2t - 5 .. 2t + 1, the next sample's first bands among them), a second zero row (rows -1 and 16 of every sample; never written). A
+// depthwise step stages its two D rows through the two rows its taps read last (the first step of a sample: through the previous
+// sample's last row). The tick bodies are unrolled over the 8 bands of a sample and a lane's row choice (its fragment's pixel pair
+// sits in one of two neighbouring rows) is folded into its base address, so every ring offset is an immediate -- except where the
+// two rows wrap around the ring (slots 7 -> 0: two fragment reads and two staging steps per sample pay one vector add).
 // Arithmetic and orders are the first kernel's (k ascending in one accumulator; tap MFMAs; lane sums over the bands in order, then the
 // 32 slots in order): bit-identical to it and to the two-launch path (tested).
 // Work: units (slice, sample) of an XCD's samples in slice-major order, cut into equal contiguous ranges for the XCD's 64 workgroup
-// slots (a range that crosses a slice boundary drains and reloads: at most one of the 64).
+// slots (a range that crosses a slice boundary drains and reloads: at most one of the 64 per boundary).
 template <int CIN>
 struct Mf16r {
     static constexpr int NK16 = CIN / 16, NKT = CIN / 32;
     static constexpr int XBUF = NKT * 2048;                 // a band's input tile: [NKT][32 rows][64 B], swizzled (gemm1x1's A image)
     static constexpr int ROW = 18 * 64;                     // one padded ring row: [18 pixels][32 ch x 2 B]
-    static constexpr int RING = 8 * ROW;                    // eight slots per channel block
+    static constexpr int RING = 10 * ROW;                   // physical rows: 0 = zeros (image row -1), 1 + (y & 7) = image row y, 9 = zeros (image row 16)
     static constexpr int RING_OFF = 2 * XBUF;
     static constexpr int TBL_OFF = RING_OFF + 4 * RING;
     static constexpr int TBL_BYTES = 1024;                  // per channel block: depthwise bias [32] f32 at 128 | taps [9][32] 16-bit at 256
     static constexpr int LDS = TBL_OFF + 4 * TBL_BYTES;
     static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
+    static constexpr int slot(int y) { return y < 0 ? 0 : (y > 15 ? 9 * ROW : (1 + (y & 7)) * ROW); }
+    static constexpr bool wraps(int y) { return slot(y + 1) - slot(y) != ROW; }       // rows y, y + 1 are not neighbours in the ring
 };
 
-template <int CIN, bool F16>
+template <int CIN, bool F16, bool STAMP = false>
 __global__ __launch_bounds__(512, 4) void mbfront16r_kernel(MbFront16Args p) {
     using S = Mf16r<CIN>;
     constexpr int NK16 = S::NK16, ROW = S::ROW;
@@ -335,10 +341,18 @@ __global__ __launch_bounds__(512, 4) void mbfront16r_kernel(MbFront16Args p) {
     const int Bx = (p.B + 7) / 8, smp0 = xcd * Bx, nx = min(Bx, p.B - smp0);
     if (nx <= 0) return;
     const int U = NSL * nx;
-    int u = (int)((long long)slot_id * U / nslots);
-    const int u1 = (int)((long long)(slot_id + 1) * U / nslots);
+    // ranges differ by one unit (1344 channels at 256 frames: 5.5 units per slot, alternately 5 and 6). The slots of an XCD are dealt to
+    // its 32 CUs in order, so slots k and k + 32 share a CU: give them neighbouring ranges (2 k, 2 k + 1) -- one of 5 and one of 6 units
+    // per CU instead of 5 + 5 on one CU and 6 + 6 on the next (placement is the hardware's business: a speed matter only)
+    const int half = (nslots + 1) >> 1;
+    const int rng = slot_id < half ? 2 * slot_id : 2 * (slot_id - half) + 1;
+    int u = (int)((long long)rng * U / nslots);
+    const int u1 = rng < nslots ? (int)((long long)(rng + 1) * U / nslots) : u;
     if (u >= u1) return;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)lds;
+    // tuning probe (STAMP instantiation only; MbFront16Args.stamps: [32 workgroups][8 waves][4] = cycles in the tick loops, of those waiting
+    // at the tick barrier (arrival -> release), ticks, 100-MHz ticks of the loops)
+    uint64_t st_loop = 0, st_wait = 0, st_n = 0, st_real = 0;
     unsigned char* const ring = lds + S::RING_OFF + cbw * S::RING;
     unsigned char* const tbl = lds + S::TBL_OFF + cbw * S::TBL_BYTES;
 
@@ -351,7 +365,21 @@ __global__ __launch_bounds__(512, 4) void mbfront16r_kernel(MbFront16Args p) {
             dma16_s(src, (uint32_t)(row * CIN * 2 + kt * 64 + logical * 16), lds0 + (uint32_t)(buf * S::XBUF + pc * 1024));
         }
     };
-    // the ring, zero columns included (only interiors are ever written afterwards): once per workgroup, by all eight waves
+    // the tick barrier: a role's LDS writes of the tick are done (the producers: and their pieces of the next input tile have landed)
+    auto tick_barrier = [&](bool prod) __attribute__((always_inline)) {
+        if constexpr (STAMP) {
+            if (prod) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const uint64_t tb = __builtin_amdgcn_s_memtime();
+            asm volatile("s_barrier" ::: "memory");
+            st_wait += __builtin_amdgcn_s_memtime() - tb;
+            ++st_n;
+        } else {
+            if (prod) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+    };
+    // the rings, zero columns and zero rows included (only the interiors of rows 1-8 are ever written afterwards): once per workgroup
     for (int i = tid; i < 4 * S::RING / 16; i += 512) *reinterpret_cast<uint4*>(lds + S::RING_OFF + i * 16) = make_uint4(0, 0, 0, 0);
 
     // a segment: n samples of one slice (the role branch is OUTSIDE the segment loop: inside it the compiler hoists both roles' lane
@@ -361,12 +389,12 @@ __global__ __launch_bounds__(512, 4) void mbfront16r_kernel(MbFront16Args p) {
         u += n;                                                                                                               \
         const int sbase = smp0 + i0;                                                                                          \
         const int cb = min(slice * 4 + cbw, CEXP / 32 - 1), c0 = cb * 32;                                                     \
-        const bool live = (slice * 4 + cbw) * 32 < CEXP;    /* 1344 channels = 10 slices + 64: the last slice's upper waves only keep the barriers (producers: and stage tiles) */ \
-        const int nticks = 8 * n + 2;
+        const bool live = (slice * 4 + cbw) * 32 < CEXP;    /* 1344 channels = 10 slices + 64: the last slice's upper waves only keep the barriers (producers: and stage tiles) */
     if (producer) {
         while (u < u1) {
             ISB_MBF16R_SEGMENT
             // ---------------------------------------------------------------- producer
+            if (p.exp & 0x1) __builtin_amdgcn_s_setprio(2);          // (A/B switch, ISB_EXP bit 0: producers outrank consumers)
             const int r = lane & 31, h = lane >> 5;
             uint4 wreg[NK16];
             {
@@ -378,64 +406,74 @@ __global__ __launch_bounds__(512, 4) void mbfront16r_kernel(MbFront16Args p) {
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) bias[qq] = *reinterpret_cast<const float4*>(p.b1 + c0 + 8 * qq + 4 * h);
             const int a_sw0 = swz(r, h), a_sw1 = swz(r, 2 + h);
-            // E write: lane = pixel r of the band (row r >> 4, column r & 15), 16 channels 4 h + 8 qq + i; chunk slots turned by
-            // f(y, x) = ((x >> 2) & 1) | ((y & 1) << 1) as in the first kernel (the band's first row 2 t is even)
+            // E write: lane = pixel r of the band (row r >> 4, column r & 15), 16 channels 4 h + 8 qq + i; the 16-byte chunk slots of a
+            // pixel are turned by f(x) = (x >> 1) & 3 (x the padded column): the consumers' fragment reads (ds_read_b128, pixels 2 n + j of
+            // two neighbouring rows) stay conflict-free and these 8-byte writes fall 2-way instead of the first kernel's 4-way
+            // (f = ((x >> 2) & 1) | ((y & 1) << 1) there; SQ_LDS_BANK_CONFLICT was 41 % of the LDS cycles)
             const int e_x = (r & 15) + 1, e_rr = r >> 4;
-            const int e_lane = e_x * 64 + h * 8;
-            const int e_f = ((e_x >> 2) & 1) | (e_rr << 1);
+            const int e_f = (e_x >> 1) & 3;
+            unsigned char* const e_cell = ring + e_rr * ROW + e_x * 64 + h * 8;       // + the band's first slot (2 t) & 7: rows 2 t, 2 t + 1 are neighbours
             dma_x(sbase, 0, 0);
-            *reinterpret_cast<uint4*>(ring + 64 + lane * 16) = make_uint4(0, 0, 0, 0);          // Z_0 (slot 0): row -1 of the first sample
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            uint64_t st_t0 = 0, st_r0 = 0;
+            if constexpr (STAMP) { st_t0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
 #pragma unroll 1
-            for (int T = 0; T < nticks; ++T) {
-                if (T < 8 * n) {
-                    const int j = T >> 3, t = T & 7;
-                    if (T + 1 < 8 * n) dma_x(sbase + ((T + 1) >> 3), (T + 1) & 7, (T + 1) & 1);
-                    const int g0 = 17 * j + 1 + 2 * t;              // ring row index of image row 2 t (wave-uniform)
+            for (int j = 0; j < n; ++j) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    if (t < 7) dma_x(sbase + j, t + 1, (t + 1) & 1);
+                    else if (j + 1 < n) dma_x(sbase + j + 1, 0, 0);
                     if (live) {
-                        const unsigned char* const xb = lds + (T & 1) * S::XBUF;
+                        const unsigned char* const xb = lds + (t & 1) * S::XBUF;
                         f32x16 acc;
 #pragma unroll
                         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-                        uint4 fa[2][2];
+                        // fragment reads two k16 pairs (four MFMAs, 128 matrix cycles) ahead of their use, in three register sets: an LDS round
+                        // trip under load is longer than the two MFMAs one set ahead covers
+                        uint4 fa[3][2];
                         auto rd = [&](int pr2, uint4 (&f)[2]) __attribute__((always_inline)) {
                             f[0] = *reinterpret_cast<const uint4*>(xb + pr2 * 2048 + a_sw0);
                             f[1] = *reinterpret_cast<const uint4*>(xb + pr2 * 2048 + a_sw1);
                         };
                         rd(0, fa[0]);
+                        rd(1, fa[1]);
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int pr2 = 0; pr2 < NK16 / 2; ++pr2) {
-                            if (pr2 + 1 < NK16 / 2) rd(pr2 + 1, fa[(pr2 + 1) & 1]);
-                            acc = T16<F16>::mfma32(wreg[2 * pr2], fa[pr2 & 1][0], acc);
-                            acc = T16<F16>::mfma32(wreg[2 * pr2 + 1], fa[pr2 & 1][1], acc);
+                            if (pr2 + 2 < NK16 / 2) rd(pr2 + 2, fa[(pr2 + 2) % 3]);
+                            acc = T16<F16>::mfma32(wreg[2 * pr2], fa[pr2 % 3][0], acc);
+                            acc = T16<F16>::mfma32(wreg[2 * pr2 + 1], fa[pr2 % 3][1], acc);
                             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                             __builtin_amdgcn_sched_barrier(0);
                         }
                         // E = T16(silu(acc + bias)) -> ring rows 2 t, 2 t + 1
-                        unsigned char* const cell = ring + ((g0 + e_rr) & 7) * ROW + e_lane;
+                        unsigned char* const cell = e_cell + S::slot(2 * t);
 #pragma unroll
                         for (int qq = 0; qq < 4; ++qq) {
-                            const float v0 = silu_fast(acc[4 * qq] + bias[qq].x), v1 = silu_fast(acc[4 * qq + 1] + bias[qq].y);
-                            const float v2 = silu_fast(acc[4 * qq + 2] + bias[qq].z), v3 = silu_fast(acc[4 * qq + 3] + bias[qq].w);
+                            const f32x2_t v01 = silu_fast2(f32x2_t{acc[4 * qq], acc[4 * qq + 1]} + f32x2_t{bias[qq].x, bias[qq].y});
+                            const f32x2_t v23 = silu_fast2(f32x2_t{acc[4 * qq + 2], acc[4 * qq + 3]} + f32x2_t{bias[qq].z, bias[qq].w});
                             uint2 pk;
-                            pk.x = T16<F16>::pack2(v0, v1);
-                            pk.y = T16<F16>::pack2(v2, v3);
+                            pk.x = T16<F16>::pack2(v01.x, v01.y);
+                            pk.y = T16<F16>::pack2(v23.x, v23.y);
                             *reinterpret_cast<uint2*>(cell + ((qq ^ e_f) << 4)) = pk;
                         }
-                        // the zero row between this sample and the next (its slot's last tenant, row 8 of this sample, died two ticks ago)
-                        if (t == 7) *reinterpret_cast<uint4*>(ring + ((17 * (j + 1)) & 7) * ROW + 64 + lane * 16) = make_uint4(0, 0, 0, 0);
                     }
+                    // the next band's tile has landed (this wave's pieces; the barrier joins the other producers'), the E rows are written
+                    tick_barrier(true);
                 }
-                // the next band's tile has landed (this wave's pieces; the barrier joins the other producers'), the E rows are written
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
+            tick_barrier(true);                                        // the consumers' last two steps
+            tick_barrier(true);
+            if constexpr (STAMP) { st_loop += __builtin_amdgcn_s_memtime() - st_t0; st_real += __builtin_amdgcn_s_memrealtime() - st_r0; }
         }
     } else {
         while (u < u1) {
             ISB_MBF16R_SEGMENT
             // ---------------------------------------------------------------- consumer
+            // the consumers' tick is the longer one (fragment reads -> 12 MFMAs -> SiLU -> D rows: stamps say the producers wait 31 % of a tick at
+            // the barrier with equal priorities); served first they stop being the pole: 118 -> 115 us per 256 frames (ISB_EXP bit 1: off)
+            if (!(p.exp & 0x2)) __builtin_amdgcn_s_setprio(1);
             // the block's depthwise bias and taps in the channel block's LDS table, then the weight fragments for the whole segment
             if (lane < 8) *reinterpret_cast<float4*>(tbl + 128 + lane * 16) = *reinterpret_cast<const float4*>(p.dwb + c0 + lane * 4);
             else if (lane >= 16 && lane < 16 + 36) {
@@ -456,108 +494,125 @@ __global__ __launch_bounds__(512, 4) void mbfront16r_kernel(MbFront16Args p) {
             else asm volatile("v_mov_b32 %0, 0x3f80\n\tv_lshlrev_b32 %1, 16, %0" : "=v"(one_lo), "=v"(one_hi));
             // B fragment: output row ry of the step's two, pixel pair; input row index ry + ky of the four rows 2s - 3 .. 2s
             const int t_ry = mn >> 3, t_x = 2 * (mn & 7) + mj;         // padded column of the fragment's pixel
-            const int t_lane = t_x * 64;
-            int t_f[2];
-            t_f[0] = ((t_x >> 2) & 1) | (((t_ry + 1) & 1) << 1);       // ky even: image row 2s - 3 + ry + ky is odd iff ry + ky is even
-            t_f[1] = ((t_x >> 2) & 1) | ((t_ry & 1) << 1);             // ky odd
+            // the lane's fragment address for group g, its row choice (t_ry) folded in: + the offset of image row 2s - 3 + ky
+            unsigned char* t_base[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) t_base[g] = ring + t_ry * ROW + t_x * 64 + ((g ^ ((t_x >> 1) & 3)) << 4);
+            const int wrap_fix = -t_ry * 8 * ROW;                       // where rows y, y + 1 wrap around the ring: the second one is 7 rows back, not 1 on
             // D staging: the step's two output rows leave through the interiors of the two ring rows its taps read LAST
             const int d_x = 2 * (mn & 7) + ms;
-            const int d_lane = (d_x + 1) * 64 + (mj & 1) * 8;
-            const int d_f = (d_x >> 1) & 3;
+            // (the second row's pixels sit pairwise swapped, x ^ 1: the 8-byte writes of the two rows then fall into different halves of the
+            // 128-byte bank window, 2-way instead of 4-way; the 16-byte readback stays conflict-free)
+            unsigned char* d_base[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) d_base[g] = ring + t_ry * ROW + ((d_x ^ t_ry) + 1) * 64 + (mj & 1) * 8 + ((g ^ ((d_x >> 1) & 3)) << 4);
+            const int o_sw = ((lane & 3) ^ (((lane >> 2) >> 1) & 3)) << 4;
+            unsigned char* const o_base[2] = {ring + ((lane >> 2) + 1) * 64 + o_sw, ring + (((lane >> 2) ^ 1) + 1) * 64 + o_sw};   // the D rows as 16-byte pieces
+            const float* const dwb_l = reinterpret_cast<const float*>(tbl + 128) + 4 * (mj & 1);
             float psum[4][4];
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            uint64_t st_t0 = 0, st_r0 = 0;
+            if constexpr (STAMP) { st_t0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
+            tick_barrier(false);                                        // the producers' first two bands
+            tick_barrier(false);
 #pragma unroll 1
-            for (int T = 0; T < nticks; ++T) {
-                if (T >= 2 && live) {
-                    const int j = (T - 2) >> 3, s = ((T - 2) & 7) + 1;     // output rows 2s - 2, 2s - 1 of sample j from ring rows 2s - 3 .. 2s
-                    if (s == 1) {
+            for (int j = 0; j < n; ++j) {
+                const int smp = sbase + j;
 #pragma unroll
-                        for (int g = 0; g < 4; ++g)
+                for (int g = 0; g < 4; ++g)
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) psum[g][i] = 0.f;
-                    }
-                    const int g0 = 17 * j + 2 * s - 2;                  // ring row index of image row 2s - 3 (wave-uniform)
-                    int rowoff[3];
+                    for (int i = 0; i < 4; ++i) psum[g][i] = 0.f;
 #pragma unroll
-                    for (int ky = 0; ky < 3; ++ky) {
-                        const int s_a = ((g0 + ky) & 7) * ROW, s_b = ((g0 + 1 + ky) & 7) * ROW;
-                        rowoff[ky] = (t_ry ? s_b : s_a) + t_lane;
-                    }
-                    f32x4 a4[4];
-                    {
-                        uint4 bf[2][3];
-                        auto rdb = [&](int g, uint4 (&f)[3]) __attribute__((always_inline)) {
+                for (int s = 1; s <= 8; ++s) {                          // output rows 2s - 2, 2s - 1 from ring rows 2s - 3 .. 2s
+                    if (live) {
+                        f32x4 a4[4];
+                        {
+                            uint4 bf[2][3];
+                            auto rdb = [&](int g, uint4 (&f)[3]) __attribute__((always_inline)) {
 #pragma unroll
-                            for (int ky = 0; ky < 3; ++ky) f[ky] = *reinterpret_cast<const uint4*>(ring + rowoff[ky] + ((g ^ t_f[ky & 1]) << 4));
-                        };
-                        rdb(0, bf[0]);
+                                for (int ky = 0; ky < 3; ++ky) {
+                                    // the lane's input row 2s - 3 + ry + ky
+                                    const unsigned char* a = t_base[g] + S::slot(2 * s - 3 + ky);
+                                    if (S::wraps(2 * s - 3 + ky)) a += wrap_fix;
+                                    f[ky] = *reinterpret_cast<const uint4*>(a);
+                                }
+                            };
+                            rdb(0, bf[0]);
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                f32x4 c4 = *reinterpret_cast<const f32x4*>(dwb_l + g * 8);       // the bias: the chain's C operand
+                                if (g + 1 < 4) rdb(g + 1, bf[(g + 1) & 1]);
+#pragma unroll
+                                for (int ky = 0; ky < 3; ++ky) c4 = mfma16<F16>(af[g][ky], bf[g & 1][ky], c4);
+                                a4[g] = c4;
+                            }
+                        }
+                        // SiLU, one rounding, pooled sums (the pool sees the stored activations), the two D rows through the dead ring rows
+                        const int d_y0 = s == 1 ? 15 : 2 * s - 3;           // (step 1: through the slot of the previous sample's last row, dead since its step 8)
+                        const int d_r0 = S::slot(d_y0), d_r1 = S::slot(2 * s - 2);       // staging rows of output rows 2s - 2, 2s - 1
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
-                            const float4 db = *reinterpret_cast<const float4*>(tbl + 128 + (g * 8 + 4 * (mj & 1)) * 4);
-                            if (g + 1 < 4) rdb(g + 1, bf[(g + 1) & 1]);
-                            f32x4 c4 = f32x4{db.x, db.y, db.z, db.w};
-#pragma unroll
-                            for (int ky = 0; ky < 3; ++ky) c4 = mfma16<F16>(af[g][ky], bf[g & 1][ky], c4);
-                            a4[g] = c4;
+                            const f32x2_t v01 = silu_fast2(f32x2_t{a4[g][0], a4[g][1]}), v23 = silu_fast2(f32x2_t{a4[g][2], a4[g][3]});
+                            const uint32_t pk0 = T16<F16>::pack2(v01.x, v01.y);
+                            const uint32_t pk1 = T16<F16>::pack2(v23.x, v23.y);
+                            psum[g][0] = T16<F16>::dot2(pk0, one_lo, psum[g][0]);
+                            psum[g][1] = T16<F16>::dot2(pk0, one_hi, psum[g][1]);
+                            psum[g][2] = T16<F16>::dot2(pk1, one_lo, psum[g][2]);
+                            psum[g][3] = T16<F16>::dot2(pk1, one_hi, psum[g][3]);
+                            unsigned char* da = d_base[g] + d_r0;
+                            if (d_r1 - d_r0 != ROW) da += wrap_fix;
+                            *reinterpret_cast<uint2*>(da) = make_uint2(pk0, pk1);
                         }
-                    }
-                    // SiLU, one rounding, pooled sums (the pool sees the stored activations), the two D rows through the dead ring rows
-                    const int d_r0 = (g0 & 7) * ROW, d_r1 = ((g0 + 1) & 7) * ROW;       // slots of image rows 2s - 3, 2s - 2
-                    const int d_row = t_ry ? d_r1 : d_r0;
+                        {
+                            uint16_t* const drow = p.d + ((size_t)smp * 256 + (2 * s - 2) * 16) * CEXP + c0 + (lane & 3) * 8;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const uint32_t pk0 = T16<F16>::pack2(silu_fast(a4[g][0]), silu_fast(a4[g][1]));
-                        const uint32_t pk1 = T16<F16>::pack2(silu_fast(a4[g][2]), silu_fast(a4[g][3]));
-                        psum[g][0] = T16<F16>::dot2(pk0, one_lo, psum[g][0]);
-                        psum[g][1] = T16<F16>::dot2(pk0, one_hi, psum[g][1]);
-                        psum[g][2] = T16<F16>::dot2(pk1, one_lo, psum[g][2]);
-                        psum[g][3] = T16<F16>::dot2(pk1, one_hi, psum[g][3]);
-                        *reinterpret_cast<uint2*>(ring + d_row + d_lane + ((g ^ d_f) << 4)) = make_uint2(pk0, pk1);
-                    }
-                    const int smp = sbase + j;
-                    {
-                        uint16_t* const drow = p.d + ((size_t)smp * 256 + (2 * s - 2) * 16) * CEXP + c0 + (lane & 3) * 8;
-#pragma unroll
-                        for (int i = 0; i < 2; ++i) {
-                            const int px = (lane >> 2) + 16 * i, xx = lane >> 2;
-                            const uint4 v = *reinterpret_cast<const uint4*>(ring + (i ? d_r1 : d_r0) + (xx + 1) * 64 + (((lane & 3) ^ ((xx >> 1) & 3)) << 4));
-                            *reinterpret_cast<uint4*>(drow + (size_t)px * CEXP) = v;
-                        }
-                    }
-                    if (s == 8) {
-                        // pooled means: the lanes' sums over the eight bands -> the 32 (pixel pair, pixel) slots in order, / 256. Scratch: the
-                        // interiors of the two rows the D rows just left through (2 KiB = 16 slots x 32 channels): slots 0-15, then 16-31
-                        auto red_at = [&](int fl) __attribute__((always_inline)) {    // float index -> address
-                            const int o = fl * 4;
-                            return reinterpret_cast<float*>(ring + ((o >> 10) ? d_r1 : d_r0) + 64 + (o & 1023));
-                        };
-                        float tsum = 0.f;
-#pragma unroll
-                        for (int half = 0; half < 2; ++half) {
-                            if ((mn >> 3) == half) {
-#pragma unroll
-                                for (int g = 0; g < 4; ++g)
-                                    *reinterpret_cast<float4*>(red_at((2 * (mn & 7) + ms) * 32 + g * 8 + 4 * (mj & 1))) =
-                                        make_float4(psum[g][0], psum[g][1], psum[g][2], psum[g][3]);
-                            }
-                            if (lane < 32) {
-                                float rv[16];
-#pragma unroll
-                                for (int s2 = 0; s2 < 16; ++s2) rv[s2] = *red_at(s2 * 32 + lane);
-#pragma unroll
-                                for (int s2 = 0; s2 < 16; ++s2) tsum += rv[s2];
+                            for (int i = 0; i < 2; ++i) {
+                                const int px = (lane >> 2) + 16 * i;
+                                const uint4 v = *reinterpret_cast<const uint4*>(o_base[i] + (i ? d_r1 : d_r0));
+                                *reinterpret_cast<uint4*>(drow + (size_t)px * CEXP) = v;
                             }
                         }
-                        if (lane < 32) p.pooled[(size_t)smp * CEXP + c0 + lane] = tsum / 256.0f;
+                        if (s == 8) {
+                            // pooled means: the lanes' sums over the eight bands -> the 32 (pixel pair, pixel) slots in order, / 256. Scratch: the
+                            // interiors of the two rows the D rows just left through (2 KiB = 16 slots x 32 channels): slots 0-15, then 16-31
+                            auto red_at = [&](int fl) __attribute__((always_inline)) {    // float index -> address
+                                const int o = fl * 4;
+                                return reinterpret_cast<float*>(ring + ((o >> 10) ? d_r1 : d_r0) + 64 + (o & 1023));
+                            };
+                            float tsum = 0.f;
+#pragma unroll
+                            for (int half = 0; half < 2; ++half) {
+                                if ((mn >> 3) == half) {
+#pragma unroll
+                                    for (int g = 0; g < 4; ++g)
+                                        *reinterpret_cast<float4*>(red_at((2 * (mn & 7) + ms) * 32 + g * 8 + 4 * (mj & 1))) =
+                                            make_float4(psum[g][0], psum[g][1], psum[g][2], psum[g][3]);
+                                }
+                                if (lane < 32) {
+                                    float rv[16];
+#pragma unroll
+                                    for (int s2 = 0; s2 < 16; ++s2) rv[s2] = *red_at(s2 * 32 + lane);
+#pragma unroll
+                                    for (int s2 = 0; s2 < 16; ++s2) tsum += rv[s2];
+                                }
+                            }
+                            if (lane < 32) p.pooled[(size_t)smp * CEXP + c0 + lane] = tsum / 256.0f;
+                        }
                     }
+                    tick_barrier(false);
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
+            if constexpr (STAMP) { st_loop += __builtin_amdgcn_s_memtime() - st_t0; st_real += __builtin_amdgcn_s_memrealtime() - st_r0; }
         }
     }
 #undef ISB_MBF16R_SEGMENT
+    if constexpr (STAMP) {
+        if (p.stamps && blockIdx.x < 32 && lane == 0) {
+            uint64_t* o = p.stamps + ((size_t)blockIdx.x * 8 + wave) * 4;
+            o[0] = st_loop; o[1] = st_wait; o[2] = st_n; o[3] = st_real;
+        }
+    }
 }
-
 
 int launch_mbfront16(const MbFront16Args& a, hipStream_t st) {
     if (a.B < 1 || !a.x || !a.w1p || !a.b1 || !a.dww || !a.dwb || !a.d || !a.pooled || (a.cin != 192 && a.cin != 224) || a.cexp % 32 != 0 ||
@@ -573,7 +628,19 @@ int launch_mbfront16(const MbFront16Args& a, hipStream_t st) {
     // kernel (every wave does everything, three waves per SIMD), 2 = roles. ISB_MBF16_FORM overrides the choice (A/B runs, tests).
     static const int env_form = [] { const char* e = getenv("ISB_MBF16_FORM"); return e ? atoi(e) : 0; }();
     const int form = a.form ? a.form : (env_form ? env_form : 2);
-    if (form == 2 && !a.stamps) {
+    if (form == 2 && a.stamps) {
+        if (!(a.cin == 224 && a.f16)) { set_error("mbfront16r: the stamped instantiation is <224, fp16>"); return ISB_ERR_INVALID; }
+        const int nslots = std::min(64, nsl * cdiv(a.B, 8));
+        static DevOnce attr_set;
+        if (attr_set.need()) {
+            ISB_HIP(hipFuncSetAttribute((const void*)mbfront16r_kernel<224, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Mf16r<224>::LDS));
+            attr_set.mark();
+        }
+        hipLaunchKernelGGL((mbfront16r_kernel<224, true, true>), dim3(8 * nslots), dim3(512), Mf16r<224>::LDS, st, aa);
+        ISB_LAUNCHED("mbfront16r (stamped)", st);
+        return ISB_OK;
+    }
+    if (form == 2) {
         const int nslots = std::min(64, nsl * cdiv(a.B, 8));
 #define ISB_MBF16R(CIN_, F16_)                                                                                               \
     do {                                                                                                                     \

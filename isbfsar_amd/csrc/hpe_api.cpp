@@ -397,6 +397,7 @@ int backbone_blocks(isb_hpe* h, Lane& L, hipStream_t st, int B, size_t i0, size_
                 a.dww = b.dw_w16.as<uint16_t>(); a.dwb = b.dw_b.as<float>(); a.d = L.bufD.as<uint16_t>(); a.pooled = L.pooled.as<float>();
                 a.B = B; a.cin = b.cin; a.cexp = b.cexp; a.f16 = b.f16 ? 1 : 0;
                 a.stamps = (h->mb8_stamps.p && h->stamp16 && b.cin == 224) ? h->mb8_stamps.as<uint64_t>() : nullptr;
+                if (a.stamps) a.form = 1;      // (tools/exp_mbf16.py reads the first kernel's phase clocks; the role kernel's: isb_debug_mbfront16)
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (h->prof) {
                     ISB_HIP(hipEventCreate(&e0));
@@ -1602,6 +1603,8 @@ extern "C" int isb_debug_mbfront16(int32_t device, const uint16_t* x, const floa
                                    int32_t f16, int32_t form, int32_t iters, uint16_t* d_out, float* pooled, float* ms_per_iter) {
     return isb::guard([&]() -> int {
         ISB_REQUIRE(x && w1 && scale1 && shift1 && dww && dwscale && dwshift && d_out && pooled && ms_per_iter, ISB_ERR_INVALID, "null argument");
+        const bool stamps = (form & 0x100) != 0;           // tuning probe (form 2, cin 224, fp16): the tick loops' clocks to stderr
+        form &= 0xff;
         ISB_REQUIRE(B >= 1 && (cin == 192 || cin == 224) && cexp % 32 == 0 && cexp >= 128 && iters >= 1 && form >= 0 && form <= 2, ISB_ERR_INVALID,
                     "bad parameters (cin 192 / 224, cexp a multiple of 32, form 0..2)");
         ISB_HIP(hipSetDevice(device));
@@ -1635,6 +1638,12 @@ extern "C" int isb_debug_mbfront16(int32_t device, const uint16_t* x, const floa
         ISB_TRY(launch_f32_to_bf16_rows(dw1f.as<float>(), ds1.as<float>(), dw1.as<uint16_t>(), cexp, (size_t)cin, nullptr, f16));
         ISB_TRY(launch_mb8_pack_frag(dw1.as<uint16_t>(), dw1p.p, cexp, cin, 1, nullptr));
         if (form == 0) ISB_TRY(dE.alloc(nout * 2));
+        DevBuf dstamps;
+        if (stamps) {
+            ISB_REQUIRE(form == 2, ISB_ERR_INVALID, "stamps: form 2");
+            ISB_TRY(dstamps.alloc(32 * 8 * 4 * 8));
+            ISB_HIP(hipMemset(dstamps.p, 0, 32 * 8 * 4 * 8));
+        }
         auto run = [&]() -> int {
             if (form == 0) {
                 ConvArgs a{};
@@ -1652,6 +1661,7 @@ extern "C" int isb_debug_mbfront16(int32_t device, const uint16_t* x, const floa
             MbFront16Args a{};
             a.x = dx.as<uint16_t>(); a.w1p = (const uint4*)dw1p.p; a.b1 = db1.as<float>(); a.dww = ddw.as<uint16_t>(); a.dwb = ddb.as<float>();
             a.d = dD.as<uint16_t>(); a.pooled = dpool.as<float>(); a.B = B; a.cin = cin; a.cexp = cexp; a.f16 = f16; a.form = form;
+            a.stamps = stamps ? dstamps.as<uint64_t>() : nullptr;
             return launch_mbfront16(a, nullptr);
         };
         ISB_TRY(run());
@@ -1670,6 +1680,24 @@ extern "C" int isb_debug_mbfront16(int32_t device, const uint16_t* x, const floa
         *ms_per_iter = ms / iters;
         ISB_HIP(hipMemcpy(d_out, dD.p, nout * 2, hipMemcpyDeviceToHost));
         ISB_HIP(hipMemcpy(pooled, dpool.p, (size_t)B * cexp * 4, hipMemcpyDeviceToHost));
+        if (stamps) {
+            std::vector<uint64_t> st(32 * 8 * 4);
+            ISB_HIP(hipMemcpy(st.data(), dstamps.p, st.size() * 8, hipMemcpyDeviceToHost));
+            for (int role = 0; role < 2; ++role) {
+                double loop = 0, wait = 0, ticks = 0, real = 0;
+                int n = 0;
+                for (int g = 0; g < 32; ++g)
+                    for (int w = role * 4; w < role * 4 + 4; ++w) {
+                        const uint64_t* o = &st[((size_t)g * 8 + w) * 4];
+                        if (!o[2]) continue;
+                        loop += (double)o[0]; wait += (double)o[1]; ticks += (double)o[2]; real += (double)o[3];
+                        ++n;
+                    }
+                if (n)
+                    fprintf(stderr, "mbfront16r %s waves (%d): %.0f ticks, %.0f cycles per tick, of those %.0f at the barrier (%.0f %%); clock %.0f MHz\n",
+                            role ? "consumer" : "producer", n, ticks / n, loop / ticks, wait / ticks, 100.0 * wait / loop, loop / real * 100.0);
+            }
+        }
         return ISB_OK;
     });
 }

@@ -7,9 +7,10 @@ import numpy as np
 
 from isbfsar_amd.hpe_engine import f32_to_f16, mbfront16_debug
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-iters = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+B = int(args[0]) if len(args) > 0 else 256
+iters = int(args[1]) if len(args) > 1 else 200
+rounds = int(args[2]) if len(args) > 2 else 3
 for cin, cexp in ((224, 1344), (192, 1152), (192, 768)):
     rng = np.random.default_rng(cin + cexp)
     x16 = f32_to_f16(rng.normal(0, 1, (B, 16, 16, cin)).astype(np.float32))
@@ -29,3 +30,5 @@ for cin, cexp in ((224, 1344), (192, 1152), (192, 768)):
             same = bool(np.array_equal(d, ref[0]) and np.array_equal(pl, ref[1]))
             row.append(f"form {form}: {ms * 1e3:7.1f} us{'' if same else ' (BITS DIFFER)'}")
         print(f"{cin:3d} -> {cexp:4d}, {B} frames, {iters} launches: " + " | ".join(row), flush=True)
+    if cin == 224 and "--stamps" in sys.argv:
+        mbfront16_debug(x16, w1, s1, b1, dww, s2, b2, f16=True, form=2 | 0x100, iters=20)
