@@ -362,14 +362,16 @@ int isb_debug_dwconv_fc1(int32_t device, const uint16_t* h_x, const float* h_w, 
                          int32_t B, int32_t H, int32_t C, int32_t stride, int32_t iters, uint16_t* h_out, float* h_pooled,
                          float* ms_per_iter, const float* h_se_w1, int32_t cse, float* h_se_part, int32_t* n_parts);
 
-/* test / tuning hook: the FRONT half of a stride-1 MBConv block on 16 x 16 maps -- 1x1 expand + folded BN + SiLU -> depthwise 3x3 + folded
- * BN + SiLU -> D [B,16,16,cexp] (what the gated projection reads) + the squeeze-excite pool [B,cexp] -- on host tensors, three ways that
- * must give the same bits: form 0 = two launches (expand GEMM, matrix-pipe depthwise kernel), 1 = the fused front of round 5 (every
- * wave does everything, three waves per SIMD), 2 = the fused front with producer / consumer waves (round 6, four waves per SIMD).
- *   h_x 16-bit [B,16,16,cin] (cin 192 / 224), h_w1 f32 [cexp,cin], h_dww f32 [cexp,3,3]; f16: the 16-bit type is IEEE fp16, else bf16 */
-int isb_debug_mbfront16(int32_t device, const uint16_t* h_x, const float* h_w1, const float* h_scale1, const float* h_shift1,
-                        const float* h_dww, const float* h_dwscale, const float* h_dwshift, int32_t B, int32_t cin, int32_t cexp,
-                        int32_t f16, int32_t form, int32_t iters, uint16_t* h_d, float* h_pooled, float* ms_per_iter);
+/* test / tuning hook: the FRONT half of a stride-1 MBConv block -- 1x1 expand + folded BN + SiLU -> depthwise 3x3 + folded BN + SiLU ->
+ * D [B,hw,hw,cexp] (what the gated projection reads) + the squeeze-excite pool [B,cexp] -- on host tensors, three ways that must give the
+ * same bits: form 0 = two launches (expand GEMM, matrix-pipe depthwise kernel), 1 = the fused fronts of rounds 4 / 5 (every wave does
+ * everything: two / three waves per SIMD), 2 = the fused fronts with producer / consumer waves (round 6: three / four waves per SIMD).
+ *   hw = 16: h_x 16-bit [B,16,16,cin] with cin 192 / 224, cexp a multiple of 32; hw = 8: cin 384, cexp 2304.
+ *   h_w1 f32 [cexp,cin], h_dww f32 [cexp,3,3]; f16: the 16-bit type is IEEE fp16, else bf16.
+ *   form | 0x100 (hw 16, form 2, cin 224, fp16): in-kernel clocks of the tick loops to stderr. */
+int isb_debug_mbfront(int32_t device, int32_t hw, const uint16_t* h_x, const float* h_w1, const float* h_scale1, const float* h_shift1,
+                      const float* h_dww, const float* h_dwscale, const float* h_dwshift, int32_t B, int32_t cin, int32_t cexp,
+                      int32_t f16, int32_t form, int32_t iters, uint16_t* h_d, float* h_pooled, float* ms_per_iter);
 
 /* ------------------------------------------------------------------------------------------
  * Glue between the two stages (main.py:102-105 + ar.py:42-50): root-centre every pose on joint 0,

@@ -722,6 +722,262 @@ __global__ __launch_bounds__(256, 2) void mbfront8_kernel(MbFront8Args p) {
     }
 }
 
+// =====================================================================================
+// Round 6: the same front half with the waves of a workgroup in DIFFERENT ROLES (the form of mbfront16r_kernel, conv_mb16.hip).
+// mbfront8_kernel above runs two waves per SIMD (96 stationary weight registers + the depthwise stage in the same wave) and each of its
+// phases takes 3-4x its issue cost (EXPERIMENTS.md round 5: the SIMD issues 55 % of its cycles, the matrix pipe is busy 33 %). Here ONE
+// workgroup of TWELVE waves per CU owns a 128-channel slice:
+//   waves 0-3   PRODUCERS (one per SIMD): the expand GEMM of a sample (64 pixels x the wave's 32 channels: 48 MFMAs on 96 stationary weight
+//               registers), bias, SiLU, one rounding, the E tile into the channel block's padded 10 x 10 tile in LDS (two tile buffers);
+//   waves 4-11  CONSUMERS (two per SIMD, 16 channels each): depthwise 3x3 on the matrix pipe from the tile the producers finished a tick
+//               earlier (weight fragments stationary), SiLU, one rounding, pooled sums, the D rows in place through the tile; they also
+//               issue the LDS-DMA of the next sample's input tile (two buffers) -- the producers' instruction stream is the pole of a tick
+//               (48 MFMAs = 1 536 matrix cycles, then 32 SiLUs per lane), the consumers' vector work fits into the issue slots the
+//               producers' MFMAs leave free (an MFMA holds the issue port 8 of its 32 cycles).
+// One workgroup barrier per sample. No counted vmcnt wait: a consumer waits for its input-tile pieces (issued a tick earlier) with
+// vmcnt(0) BEFORE it issues the tick's stores. Arithmetic and orders are mbfront8_kernel's: bit-identical to it and to the two launches.
+// Work: units (slice, sample) of an XCD's samples in slice-major order, cut into equal contiguous ranges for the XCD's 32 workgroups.
+template <int CIN>
+struct Mf8r {
+    static constexpr int NK16 = CIN / 16, NKT = CIN / 32, CEXP = 6 * CIN, NSL = CEXP / 128;
+    static constexpr int XBUF = NKT * 4096;                 // a sample's input tile: [NKT][64 rows][64 B], swizzled
+    static constexpr int ET = MB8_ET_BYTES;                 // a channel block's padded tile: [100 pixels][32 ch x 2 B]
+    static constexpr int ET_OFF = 2 * XBUF;                 // [4 blocks][2 buffers]
+    static constexpr int TBL_OFF = ET_OFF + 8 * ET;
+    static constexpr int TBL_BYTES = 1024;                  // per channel block: bias [32] f32 | depthwise bias [32] f32 at 128 | taps [9][32] 16-bit at 256
+    static constexpr int LDS = TBL_OFF + 4 * TBL_BYTES;
+    static_assert(LDS <= 160 * 1024, "one workgroup per CU");
+};
+
+template <int CIN, bool F16>
+__global__ __launch_bounds__(768, 3) void mbfront8r_kernel(MbFront8Args p) {
+    using S = Mf8r<CIN>;
+    constexpr int NK16 = S::NK16, CEXP = S::CEXP, NSL = S::NSL, ET = S::ET;
+    T16<F16>::enter();
+    unsigned char* const lds = conv_lds_dyn;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wave < 4;
+    // this workgroup's units: XCD x (ids 8 apart share one) owns samples [x Bx, x Bx + nx); its slots cut NSL * nx units evenly
+    const int xcd = blockIdx.x & 7, slot_id = blockIdx.x >> 3, nslots = (int)(gridDim.x >> 3);
+    const int Bx = (p.B + 7) / 8, smp0 = xcd * Bx, nx = min(Bx, p.B - smp0);
+    if (nx <= 0) return;
+    const int U = NSL * nx;
+    int u = (int)((long long)slot_id * U / nslots);
+    const int u1 = (int)((long long)(slot_id + 1) * U / nslots);
+    if (u >= u1) return;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)lds;
+    // the padded tiles, zero rings included (only interiors are ever written afterwards): once per workgroup
+    for (int i = tid; i < 8 * ET / 16; i += 768) *reinterpret_cast<uint4*>(lds + S::ET_OFF + i * 16) = make_uint4(0, 0, 0, 0);
+
+#define ISB_MBF8R_SEGMENT                                                                                                   \
+        const int slice = u / nx, i0 = u % nx, n = min(nx - i0, u1 - u);                                                      \
+        u += n;                                                                                                               \
+        const int sbase = smp0 + i0;
+    if (producer) {
+        const int r = lane & 31, h = lane >> 5;
+        const int a_sw0 = swz(r, h), a_sw1 = swz(r, 2 + h);
+        unsigned char* const et0 = lds + S::ET_OFF + wave * 2 * ET;
+        unsigned char* const tbl = lds + S::TBL_OFF + wave * S::TBL_BYTES;
+        const int e_f = ((((r & 7) + 1) >> 2) & 1) | ((((r >> 3) + 1) & 1) << 1);      // E write: padded pixel ((r >> 3) + 1 + 4 rb, (r & 7) + 1)
+        const int e_cell = et_pix(r) * 64 + h * 8;                                       // row block rb: + rb * 4 * 10 * 64
+        while (u < u1) {
+            ISB_MBF8R_SEGMENT
+            (void)sbase;
+            const int cb = slice * 4 + wave, c0 = cb * 32;
+            uint4 wreg[NK16];
+            {
+                const uint4* src = p.w1p + (size_t)cb * NK16 * 64 + lane;
+#pragma unroll
+                for (int s = 0; s < NK16; ++s) wreg[s] = src[s * 64];
+            }
+            if (lane < 8) *reinterpret_cast<float4*>(tbl + lane * 16) = *reinterpret_cast<const float4*>(p.b1 + c0 + lane * 4);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");       // (the consumers: the first sample's input tile has landed)
+#pragma unroll 1
+            for (int T = 0; T <= n; ++T) {
+                if (T < n) {
+                    const unsigned char* const xb = lds + (T & 1) * S::XBUF;
+                    unsigned char* const et = et0 + (T & 1) * ET;
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb) {
+                        f32x16 acc;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+                        // fragment reads two k16 pairs ahead of their use (three register sets)
+                        uint4 fa[3][2];
+                        auto rd = [&](int pr, uint4 (&f)[2]) __attribute__((always_inline)) {
+                            f[0] = *reinterpret_cast<const uint4*>(xb + pr * 4096 + rb * 2048 + a_sw0);
+                            f[1] = *reinterpret_cast<const uint4*>(xb + pr * 4096 + rb * 2048 + a_sw1);
+                        };
+                        rd(0, fa[0]);
+                        rd(1, fa[1]);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int pr = 0; pr < NK16 / 2; ++pr) {
+                            if (pr + 2 < NK16 / 2) rd(pr + 2, fa[(pr + 2) % 3]);
+                            acc = T16<F16>::mfma32(wreg[2 * pr], fa[pr % 3][0], acc);
+                            acc = T16<F16>::mfma32(wreg[2 * pr + 1], fa[pr % 3][1], acc);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        // E = T16(silu(acc + bias)) -> the block's padded tile (16-byte chunk slot = chunk ^ f(y, x))
+                        unsigned char* const cell = et + e_cell + rb * (4 * 10 * 64);
+#pragma unroll
+                        for (int qq = 0; qq < 4; ++qq) {
+                            const float4 bs = *reinterpret_cast<const float4*>(tbl + (8 * qq + 4 * h) * 4);
+                            const f32x2_t v01 = silu_fast2(f32x2_t{acc[4 * qq], acc[4 * qq + 1]} + f32x2_t{bs.x, bs.y});
+                            const f32x2_t v23 = silu_fast2(f32x2_t{acc[4 * qq + 2], acc[4 * qq + 3]} + f32x2_t{bs.z, bs.w});
+                            uint2 pk;
+                            pk.x = T16<F16>::pack2(v01.x, v01.y);
+                            pk.y = T16<F16>::pack2(v23.x, v23.y);
+                            *reinterpret_cast<uint2*>(cell + ((qq ^ e_f) << 4)) = pk;
+                        }
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+        }
+    } else {
+        const int cw = wave - 4, blk = cw & 3, half = cw >> 2;      // the channel block and which 16 of its channels
+        unsigned char* const et0 = lds + S::ET_OFF + blk * 2 * ET;
+        unsigned char* const tbl = lds + S::TBL_OFF + blk * S::TBL_BYTES;
+        // the next sample's input tile: 4 NKT pieces of 1 KiB over the eight consumer waves
+        auto dma_x = [&](int smp, int buf) {
+            const unsigned char* src = reinterpret_cast<const unsigned char*>(p.x) + (size_t)smp * 64 * CIN * 2;
+            for (int pc = cw; pc < S::NKT * 4; pc += 8) {
+                const int kt = pc >> 2, row = 16 * (pc & 3) + (lane >> 2);
+                const int logical = (lane & 3) ^ ((row >> 2) & 3);
+                dma16_s(src, (uint32_t)(row * CIN * 2 + kt * 64 + logical * 16), lds0 + (uint32_t)(buf * S::XBUF + pc * 1024));
+            }
+        };
+        const DwmmLane wl(lane);
+        const int w_d = min(max(wl.d, 0), 2);
+        const int mn = lane & 15, mj = lane >> 4, ms = mj >> 1;        // pixel pair, input column / output rows, pixel of the pair
+        int b_pix[3], b_f[2];
+        {
+            const int ry = mn >> 2, xx = 2 * (mn & 3) + mj;             // B fragment: padded pixel (4 t + ry + ky, xx)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) b_pix[ky] = ((ry + ky) * 10 + xx) * 64;
+            b_f[0] = ((xx >> 2) & 1) | ((ry & 1) << 1);                 // ky even
+            b_f[1] = ((xx >> 2) & 1) | (((ry + 1) & 1) << 1);           // ky odd
+        }
+        int d_pix, d_f;
+        {
+            const int yy = (mn >> 2) + 1, xx = 2 * (mn & 3) + ms + 1;   // the lane's output pixel (tile 0), padded coordinates
+            d_pix = (yy * 10 + xx) * 64 + (mj & 1) * 8;
+            d_f = ((xx >> 2) & 1) | ((yy & 1) << 1);
+        }
+        // readback / scratch: lane = pixel (yy, xx) of the map; the wave's two 16-byte chunks of it (its 16 channels) sit at slots (2 half + i) ^ f
+        const int o_pix = et_pix(lane) * 64;
+        const int o_f = (((((lane & 7) + 1) >> 2) & 1) | ((((lane >> 3) + 1) & 1) << 1));
+        uint32_t one_lo, one_hi;                                        // (1, 0) / (0, 1) pairs in the storage type
+        if constexpr (F16) asm volatile("v_mov_b32 %0, 0x3c00\n\tv_lshlrev_b32 %1, 16, %0" : "=v"(one_lo), "=v"(one_hi));
+        else asm volatile("v_mov_b32 %0, 0x3f80\n\tv_lshlrev_b32 %1, 16, %0" : "=v"(one_lo), "=v"(one_hi));
+        while (u < u1) {
+            ISB_MBF8R_SEGMENT
+            const int cb = slice * 4 + blk, c0 = cb * 32;
+            // the block's depthwise bias and taps in the block's table (both halves write the same values), then this wave's weight fragments
+            if (lane < 8) *reinterpret_cast<float4*>(tbl + 128 + lane * 16) = *reinterpret_cast<const float4*>(p.dwb + c0 + lane * 4);
+            else if (lane >= 16 && lane < 16 + 36) {
+                const int t = (lane - 16) >> 2, c4 = (lane - 16) & 3;
+                *reinterpret_cast<uint4*>(tbl + 256 + t * 64 + c4 * 16) = *reinterpret_cast<const uint4*>(p.dww + (size_t)t * CEXP + c0 + c4 * 8);
+            }
+            uint4 af[2][3];
+#pragma unroll
+            for (int gl = 0; gl < 2; ++gl)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+                    af[gl][ky] = wl.place((uint32_t)*reinterpret_cast<const uint16_t*>(tbl + 256 + (ky * 3 + w_d) * 64 + ((2 * half + gl) * 8 + wl.c) * 2));
+            dma_x(sbase, 0);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll 1
+            for (int T = 0; T <= n; ++T) {
+                if (T + 1 < n) dma_x(sbase + T + 1, (T + 1) & 1);
+                if (T >= 1) {
+                    const int smp = sbase + T - 1;
+                    unsigned char* const et = et0 + ((T - 1) & 1) * ET;
+                    // ---- depthwise 3x3 + bias on the matrix pipe: two tiles of 32 pixels x this wave's two 8-channel groups
+                    f32x4 a4[2][2];
+                    {
+                        uint4 bf[2][6];
+                        auto rdb = [&](int t, uint4 (&f)[6]) __attribute__((always_inline)) {
+#pragma unroll
+                            for (int gl = 0; gl < 2; ++gl)
+#pragma unroll
+                                for (int ky = 0; ky < 3; ++ky)
+                                    f[gl * 3 + ky] = *reinterpret_cast<const uint4*>(et + b_pix[ky] + (((2 * half + gl) ^ b_f[ky & 1]) << 4) + t * (4 * 10 * 64));
+                        };
+                        rdb(0, bf[0]);
+                        rdb(1, bf[1]);
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+#pragma unroll
+                            for (int gl = 0; gl < 2; ++gl) {
+                                f32x4 c4 = *reinterpret_cast<const f32x4*>(tbl + 128 + ((2 * half + gl) * 8 + 4 * (mj & 1)) * 4);
+#pragma unroll
+                                for (int ky = 0; ky < 3; ++ky) c4 = mfma16<F16>(af[gl][ky], bf[t][gl * 3 + ky], c4);
+                                a4[gl][t] = c4;
+                            }
+                    }
+                    // SiLU, one rounding, pooled sums (the pool sees the stored activations), D into the tile's interior in place
+                    float psum[2][4];
+#pragma unroll
+                    for (int gl = 0; gl < 2; ++gl) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) psum[gl][i] = 0.f;
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            const f32x2_t v01 = silu_fast2(f32x2_t{a4[gl][t][0], a4[gl][t][1]}), v23 = silu_fast2(f32x2_t{a4[gl][t][2], a4[gl][t][3]});
+                            const uint32_t pk0 = T16<F16>::pack2(v01.x, v01.y);
+                            const uint32_t pk1 = T16<F16>::pack2(v23.x, v23.y);
+                            psum[gl][0] = T16<F16>::dot2(pk0, one_lo, psum[gl][0]);
+                            psum[gl][1] = T16<F16>::dot2(pk0, one_hi, psum[gl][1]);
+                            psum[gl][2] = T16<F16>::dot2(pk1, one_lo, psum[gl][2]);
+                            psum[gl][3] = T16<F16>::dot2(pk1, one_hi, psum[gl][3]);
+                            *reinterpret_cast<uint2*>(et + d_pix + (((2 * half + gl) ^ d_f) << 4) + t * (4 * 10 * 64)) = make_uint2(pk0, pk1);
+                        }
+                    }
+                    uint4 dv[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) dv[i] = *reinterpret_cast<const uint4*>(et + o_pix + (((2 * half + i) ^ o_f) << 4));
+                    // the input-tile pieces this wave requested at the top of the tick have landed long ago; waiting for them HERE, before the
+                    // tick's stores are issued, needs no count (the stores then fly across the barrier)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    {
+                        uint16_t* const drow = p.d + ((size_t)smp * 64 + lane) * CEXP + c0 + half * 16;
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4*>(drow + i * 8) = dv[i];
+                    }
+                    // pooled means: the lanes' sums over their two tiles -> the 32 (pixel pair, pixel) slots in order, / 64. Scratch: the wave's
+                    // own 128 cells of 16 bytes in the tile's interior (cell k = pixel k >> 1, chunk 2 half + (k & 1)), as [slot][16 channels] f32
+                    auto cell_at = [&](int pix, int which) __attribute__((always_inline)) {
+                        const int yy = (pix >> 3) + 1, xx = (pix & 7) + 1;
+                        return et + (yy * 10 + xx) * 64 + (((2 * half + which) ^ (((xx >> 2) & 1) | ((yy & 1) << 1))) << 4);
+                    };
+#pragma unroll
+                    for (int gl = 0; gl < 2; ++gl)
+                        *reinterpret_cast<float4*>(cell_at((2 * mn + ms) * 2 + gl, mj & 1)) = make_float4(psum[gl][0], psum[gl][1], psum[gl][2], psum[gl][3]);
+                    if (lane < 16) {
+                        float rv[32];
+#pragma unroll
+                        for (int s2 = 0; s2 < 32; ++s2)
+                            rv[s2] = *(reinterpret_cast<const float*>(cell_at(s2 * 2 + (lane >> 3), (lane >> 2) & 1)) + (lane & 3));
+                        float tsum = 0.f;
+#pragma unroll
+                        for (int s2 = 0; s2 < 32; ++s2) tsum += rv[s2];
+                        p.pooled[(size_t)smp * CEXP + c0 + half * 16 + lane] = tsum / 64.0f;
+                    }
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (first tick: nothing to store, the second sample's pieces land)
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+        }
+    }
+#undef ISB_MBF8R_SEGMENT
+}
+
 // 16-bit weights [N][K] row-major -> MFMA fragment order for register streaming: groups of G 32-channel blocks, k16-major inside
 // a group: dst[((grp * K/16 + s) * G + g) * 64 + lane] (16 bytes) = W[(grp G + g) 32 + (lane & 31)][16 s + 8 (lane >> 5) .. + 8]
 __global__ void mb8_pack_frag_kernel(const uint16_t* w, uint4* dst, int N, int K, int G) {
@@ -789,6 +1045,23 @@ int launch_mbfront8(const MbFront8Args& a, hipStream_t st) {
     const int Q = std::max(1, std::min(a.B, 512 / NSL));              // sample sequences: two workgroups per CU
     MbFront8Args aa = a;
     aa.exp = exp_flags();
+    // round 6: producer / consumer waves, twelve per workgroup, one workgroup per CU (mbfront8r_kernel). a.form: 0 = the library's choice,
+    // 1 = the first kernel, 2 = roles. ISB_MBF8_FORM overrides the choice (A/B runs, tests).
+    static const int env_form = [] { const char* e = getenv("ISB_MBF8_FORM"); return e ? atoi(e) : 0; }();
+    const int form = a.form ? a.form : (env_form ? env_form : 2);
+    if (form == 2 && !a.stamps) {
+        static DevOnce attr_r;
+        if (attr_r.need()) {
+            ISB_HIP(hipFuncSetAttribute((const void*)mbfront8r_kernel<384, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Mf8r<384>::LDS));
+            ISB_HIP(hipFuncSetAttribute((const void*)mbfront8r_kernel<384, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Mf8r<384>::LDS));
+            attr_r.mark();
+        }
+        const int nslots = std::min(32, NSL * cdiv(a.B, 8));
+        if (a.f16) hipLaunchKernelGGL((mbfront8r_kernel<384, true>), dim3(8 * nslots), dim3(768), Mf8r<384>::LDS, st, aa);
+        else hipLaunchKernelGGL((mbfront8r_kernel<384, false>), dim3(8 * nslots), dim3(768), Mf8r<384>::LDS, st, aa);
+        ISB_LAUNCHED("mbfront8r", st);
+        return ISB_OK;
+    }
     if (a.f16) hipLaunchKernelGGL((mbfront8_kernel<384, true>), dim3(NSL * Q), dim3(256), LDSB, st, aa);
     else hipLaunchKernelGGL((mbfront8_kernel<384, false>), dim3(NSL * Q), dim3(256), LDSB, st, aa);
     ISB_LAUNCHED("mbfront8", st);

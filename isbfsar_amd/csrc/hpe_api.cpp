@@ -379,6 +379,7 @@ int backbone_blocks(isb_hpe* h, Lane& L, hipStream_t st, int B, size_t i0, size_
                 a.dww = b.dw_w16.as<uint16_t>(); a.dwb = b.dw_b.as<float>(); a.d = L.bufD.as<uint16_t>(); a.pooled = L.pooled.as<float>();
                 a.B = B; a.cin = b.cin; a.f16 = b.f16 ? 1 : 0;
                 a.stamps = (h->mb8_stamps.p && !h->stamp16) ? h->mb8_stamps.as<uint64_t>() : nullptr;
+                if (a.stamps) a.form = 1;      // (tools/exp_mbf8.py reads the first kernel's phase clocks)
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (h->prof) {
                     ISB_HIP(hipEventCreate(&e0));
@@ -397,7 +398,7 @@ int backbone_blocks(isb_hpe* h, Lane& L, hipStream_t st, int B, size_t i0, size_
                 a.dww = b.dw_w16.as<uint16_t>(); a.dwb = b.dw_b.as<float>(); a.d = L.bufD.as<uint16_t>(); a.pooled = L.pooled.as<float>();
                 a.B = B; a.cin = b.cin; a.cexp = b.cexp; a.f16 = b.f16 ? 1 : 0;
                 a.stamps = (h->mb8_stamps.p && h->stamp16 && b.cin == 224) ? h->mb8_stamps.as<uint64_t>() : nullptr;
-                if (a.stamps) a.form = 1;      // (tools/exp_mbf16.py reads the first kernel's phase clocks; the role kernel's: isb_debug_mbfront16)
+                if (a.stamps) a.form = 1;      // (tools/exp_mbf16.py reads the first kernel's phase clocks; the role kernel's: isb_debug_mbfront)
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (h->prof) {
                     ISB_HIP(hipEventCreate(&e0));
@@ -1595,20 +1596,22 @@ extern "C" int isb_debug_fused_mb(int32_t device, const uint16_t* x, const float
     });
 }
 
-// test / tuning hook: the FRONT half of a stride-1 MBConv block on 16 x 16 maps (1x1 expand + BN + SiLU -> depthwise 3x3 + BN + SiLU ->
-// D + squeeze-excite pool) on host tensors, three ways that must give the same bits: form 0 = the two launches (expand GEMM, then
-// dwconv3x3_mm_kernel<16>), 1 = mbfront16_kernel, 2 = mbfront16r_kernel (conv_mb16.hip)
-extern "C" int isb_debug_mbfront16(int32_t device, const uint16_t* x, const float* w1, const float* scale1, const float* shift1,
-                                   const float* dww, const float* dwscale, const float* dwshift, int32_t B, int32_t cin, int32_t cexp,
-                                   int32_t f16, int32_t form, int32_t iters, uint16_t* d_out, float* pooled, float* ms_per_iter) {
+// test / tuning hook: the FRONT half of a stride-1 MBConv block on 16 x 16 or 8 x 8 maps (1x1 expand + BN + SiLU -> depthwise 3x3 + BN +
+// SiLU -> D + squeeze-excite pool) on host tensors, three ways that must give the same bits: form 0 = the two launches (expand GEMM, then
+// dwconv3x3_mm_kernel), 1 = mbfront16_kernel / mbfront8_kernel, 2 = mbfront16r_kernel / mbfront8r_kernel (conv_mb16.hip, conv_mb8.hip)
+extern "C" int isb_debug_mbfront(int32_t device, int32_t hw, const uint16_t* x, const float* w1, const float* scale1, const float* shift1,
+                                 const float* dww, const float* dwscale, const float* dwshift, int32_t B, int32_t cin, int32_t cexp,
+                                 int32_t f16, int32_t form, int32_t iters, uint16_t* d_out, float* pooled, float* ms_per_iter) {
     return isb::guard([&]() -> int {
         ISB_REQUIRE(x && w1 && scale1 && shift1 && dww && dwscale && dwshift && d_out && pooled && ms_per_iter, ISB_ERR_INVALID, "null argument");
         const bool stamps = (form & 0x100) != 0;           // tuning probe (form 2, cin 224, fp16): the tick loops' clocks to stderr
         form &= 0xff;
-        ISB_REQUIRE(B >= 1 && (cin == 192 || cin == 224) && cexp % 32 == 0 && cexp >= 128 && iters >= 1 && form >= 0 && form <= 2, ISB_ERR_INVALID,
-                    "bad parameters (cin 192 / 224, cexp a multiple of 32, form 0..2)");
+        ISB_REQUIRE(B >= 1 && iters >= 1 && form >= 0 && form <= 2 &&
+                        ((hw == 16 && (cin == 192 || cin == 224) && cexp % 32 == 0 && cexp >= 128) || (hw == 8 && cin == 384 && cexp == 2304)),
+                    ISB_ERR_INVALID, "bad parameters (16 x 16 maps: cin 192 / 224, cexp a multiple of 32; 8 x 8 maps: 384 -> 2304; form 0..2)");
+        const int npx = hw * hw;
         ISB_HIP(hipSetDevice(device));
-        const size_t nin = (size_t)B * 256 * cin, nout = (size_t)B * 256 * cexp;
+        const size_t nin = (size_t)B * npx * cin, nout = (size_t)B * npx * cexp;
         std::vector<uint16_t> wt16((size_t)9 * cexp);
         for (int c = 0; c < cexp; ++c)
             for (int t = 0; t < 9; ++t) {
@@ -1640,7 +1643,7 @@ extern "C" int isb_debug_mbfront16(int32_t device, const uint16_t* x, const floa
         if (form == 0) ISB_TRY(dE.alloc(nout * 2));
         DevBuf dstamps;
         if (stamps) {
-            ISB_REQUIRE(form == 2, ISB_ERR_INVALID, "stamps: form 2");
+            ISB_REQUIRE(form == 2 && hw == 16, ISB_ERR_INVALID, "stamps: form 2 of the 16 x 16 front");
             ISB_TRY(dstamps.alloc(32 * 8 * 4 * 8));
             ISB_HIP(hipMemset(dstamps.p, 0, 32 * 8 * 4 * 8));
         }
@@ -1649,14 +1652,20 @@ extern "C" int isb_debug_mbfront16(int32_t device, const uint16_t* x, const floa
                 ConvArgs a{};
                 a.f16 = f16;
                 a.in = dx.as<uint16_t>(); a.w = dw1.as<uint16_t>(); a.bias = db1.as<float>(); a.out = dE.p;
-                a.B = B; a.H = 16; a.W = 16; a.Cin = cin; a.Cout = cexp; a.KH = 1; a.KW = 1; a.stride = 1; a.OH = 16; a.OW = 16;
-                a.pad = 0; a.M = B * 256; a.K = cin; a.act = 1; a.zeros = dzero.as<uint16_t>();
+                a.B = B; a.H = hw; a.W = hw; a.Cin = cin; a.Cout = cexp; a.KH = 1; a.KW = 1; a.stride = 1; a.OH = hw; a.OW = hw;
+                a.pad = 0; a.M = B * npx; a.K = cin; a.act = 1; a.zeros = dzero.as<uint16_t>();
                 ISB_TRY(launch_conv_igemm(a, nullptr));
                 DwArgs d{};
                 d.in = dE.as<uint16_t>(); d.w = ddw.as<uint16_t>(); d.bias = ddb.as<float>(); d.out = dD.as<uint16_t>();
-                d.pooled = dpool.as<float>(); d.B = B; d.H = 16; d.W = 16; d.C = cexp; d.OH = 16; d.OW = 16; d.stride = 1; d.pad = 1;
+                d.pooled = dpool.as<float>(); d.B = B; d.H = hw; d.W = hw; d.C = cexp; d.OH = hw; d.OW = hw; d.stride = 1; d.pad = 1;
                 d.in_f16 = f16; d.out_f16 = f16; d.general = 3;
                 return launch_dwconv3x3(d, nullptr);
+            }
+            if (hw == 8) {
+                MbFront8Args a{};
+                a.x = dx.as<uint16_t>(); a.w1p = (const uint4*)dw1p.p; a.b1 = db1.as<float>(); a.dww = ddw.as<uint16_t>(); a.dwb = ddb.as<float>();
+                a.d = dD.as<uint16_t>(); a.pooled = dpool.as<float>(); a.B = B; a.cin = cin; a.f16 = f16; a.form = form;
+                return launch_mbfront8(a, nullptr);
             }
             MbFront16Args a{};
             a.x = dx.as<uint16_t>(); a.w1p = (const uint4*)dw1p.p; a.b1 = db1.as<float>(); a.dww = ddw.as<uint16_t>(); a.dwb = ddb.as<float>();

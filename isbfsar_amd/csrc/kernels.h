@@ -217,6 +217,7 @@ struct MbFront8Args {
     uint16_t* d;            // out [B][64][cexp] 16-bit: the depthwise output the gated projection reads
     float* pooled;          // out [B][cexp] f32 spatial means
     int B, cin, f16;
+    int form;               // 0 = the library's choice; 1 = mbfront8_kernel; 2 = mbfront8r_kernel (producer / consumer waves, round 6). Same bits.
     int exp;                // open experiments (isb::exp_flags(), set by the launcher)
     uint64_t* stamps;       // tuning probe or null: [32 workgroups][4 waves][16] = loop cycles, waiting at the loop top, bodies, iterations,
                             // then the bodies' phases: expand MFMAs, second barrier, E epilogue, depthwise + stores + pool, and the last

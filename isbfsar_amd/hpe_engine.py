@@ -318,22 +318,25 @@ def gemm_f32_debug(A, W, bias=None, a_bias=None, a_add=None, act=0, a_act=0, spl
     return out, ms.value
 
 
-def mbfront16_debug(x16, w1, scale1, shift1, dww, dwscale, dwshift, f16=False, form=2, iters=1, device=0):
-    """The front half of a stride-1 MBConv block on 16 x 16 maps through isb_debug_mbfront16: x16 uint16 [B,16,16,cin] (cin 192 / 224),
-    w1 f32 [cexp,cin], dww f32 [cexp,3,3]. form 0 = two launches, 1 = the round-5 fused kernel, 2 = producer / consumer waves.
-    Returns (D uint16 [B,16,16,cexp], pooled f32 [B,cexp], ms_per_launch)."""
+def mbfront_debug(x16, w1, scale1, shift1, dww, dwscale, dwshift, f16=False, form=2, iters=1, device=0):
+    """The front half of a stride-1 MBConv block through isb_debug_mbfront: x16 uint16 [B,hw,hw,cin] (hw 16: cin 192 / 224; hw 8: cin 384,
+    2304 expanded channels), w1 f32 [cexp,cin], dww f32 [cexp,3,3]. form 0 = two launches, 1 = the fused kernel of rounds 4 / 5, 2 =
+    producer / consumer waves. Returns (D uint16 [B,hw,hw,cexp], pooled f32 [B,cexp], ms_per_launch)."""
     x = np.ascontiguousarray(x16, dtype=np.uint16)
-    B, cin = x.shape[0], x.shape[3]
+    B, hw, cin = x.shape[0], x.shape[1], x.shape[3]
     w1 = np.ascontiguousarray(w1, dtype=np.float32)
     cexp = w1.shape[0]
     arrs = [np.ascontiguousarray(a, dtype=np.float32) for a in (scale1, shift1, dww, dwscale, dwshift)]
-    d = np.empty((B, 16, 16, cexp), np.uint16)
+    d = np.empty((B, hw, hw, cexp), np.uint16)
     pooled = np.empty((B, cexp), np.float32)
     ms = C.c_float()
-    _lib.check(_lib.lib().isb_debug_mbfront16(device, _ptr(x), _ptr(w1), _ptr(arrs[0]), _ptr(arrs[1]), _ptr(arrs[2]), _ptr(arrs[3]), _ptr(arrs[4]),
-                                              B, cin, cexp, int(bool(f16)), int(form), int(iters), _ptr(d), _ptr(pooled), C.byref(ms)),
-               "isb_debug_mbfront16")
+    _lib.check(_lib.lib().isb_debug_mbfront(device, hw, _ptr(x), _ptr(w1), _ptr(arrs[0]), _ptr(arrs[1]), _ptr(arrs[2]), _ptr(arrs[3]), _ptr(arrs[4]),
+                                            B, cin, cexp, int(bool(f16)), int(form), int(iters), _ptr(d), _ptr(pooled), C.byref(ms)),
+               "isb_debug_mbfront")
     return d, pooled, float(ms.value)
+
+
+mbfront16_debug = mbfront_debug
 
 
 def dwconv_debug(x_bf16, w, scale, shift, stride=1, iters=1, device=0, in_f16=False, out_f16=False, general=False):

@@ -747,3 +747,28 @@ def test_fused_front_16x16_forms_are_bit_identical(B, cin, cexp, f16):
         d, pl, _ = mbfront16_debug(x16, w1, s1, b1, dww, s2, b2, f16=f16, form=form, iters=2)
         assert np.array_equal(d, d0), (form, float(np.mean(d != d0)))
         assert np.array_equal(pl, p0), (form, float(np.abs(pl - p0).max()))
+
+
+@pytest.mark.parametrize("f16", [False, True])
+@pytest.mark.parametrize("B", [3, 32, 45, 130])
+def test_fused_front_8x8_forms_are_bit_identical(B, f16):
+    """The same for the 384 -> 2304 blocks of the 8 x 8 stage: two launches, mbfront8_kernel (round 4 / 5) and mbfront8r_kernel (round 6:
+    four producer and eight consumer waves per workgroup, one workgroup per CU; ranges of 2304 / 128 = 18 slices x an XCD's samples that
+    cross slice boundaries): D and the pooled means bit for bit."""
+    from isbfsar_amd.hpe_engine import f32_to_f16, mbfront_debug
+    cin, cexp = 384, 2304
+    rng = np.random.default_rng(B * 11 + int(f16))
+    x = rng.normal(0, 1, (B, 8, 8, cin)).astype(np.float32)
+    w1 = (rng.normal(0, 1, (cexp, cin)) / np.sqrt(cin)).astype(np.float32)
+    s1 = rng.uniform(0.8, 1.2, cexp).astype(np.float32)
+    b1 = rng.uniform(-0.2, 0.2, cexp).astype(np.float32)
+    dww = (rng.normal(0, 1, (cexp, 3, 3)) / 3.0).astype(np.float32)
+    s2 = rng.uniform(0.8, 1.2, cexp).astype(np.float32)
+    b2 = rng.uniform(-0.1, 0.1, cexp).astype(np.float32)
+    x16 = f32_to_f16(x) if f16 else f32_to_bf16(x)
+    d0, p0, _ = mbfront_debug(x16, w1, s1, b1, dww, s2, b2, f16=f16, form=0)
+    assert np.abs(p0).max() > 0 and np.isfinite(p0).all()
+    for form in (1, 2):
+        d, pl, _ = mbfront_debug(x16, w1, s1, b1, dww, s2, b2, f16=f16, form=form, iters=2)
+        assert np.array_equal(d, d0), (form, float(np.mean(d != d0)))
+        assert np.array_equal(pl, p0), (form, float(np.abs(pl - p0).max()))
