@@ -745,11 +745,12 @@ struct Mf8r {
     static constexpr int ET_OFF = 2 * XBUF;                 // [4 blocks][2 buffers]
     static constexpr int TBL_OFF = ET_OFF + 8 * ET;
     static constexpr int TBL_BYTES = 1024;                  // per channel block: bias [32] f32 | depthwise bias [32] f32 at 128 | taps [9][32] 16-bit at 256
-    static constexpr int LDS = TBL_OFF + 4 * TBL_BYTES;
+    static constexpr int RED_OFF = TBL_OFF + 4 * TBL_BYTES; // per consumer wave 1 KiB: the pool's scratch, [16 slots][16 channels] f32
+    static constexpr int LDS = RED_OFF + 8 * 1024;
     static_assert(LDS <= 160 * 1024, "one workgroup per CU");
 };
 
-template <int CIN, bool F16>
+template <int CIN, bool F16, bool STAMP = false>
 __global__ __launch_bounds__(768, 3) void mbfront8r_kernel(MbFront8Args p) {
     using S = Mf8r<CIN>;
     constexpr int NK16 = S::NK16, CEXP = S::CEXP, NSL = S::NSL, ET = S::ET;
@@ -767,6 +768,11 @@ __global__ __launch_bounds__(768, 3) void mbfront8r_kernel(MbFront8Args p) {
     const int u1 = (int)((long long)(slot_id + 1) * U / nslots);
     if (u >= u1) return;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)lds;
+    // tuning probe (STAMP instantiation; MbFront8Args.stamps: [32 workgroups][12 waves][8]): ticks, then cycles summed over the ticks --
+    // producers: MFMAs of row block 0, its epilogue, MFMAs of row block 1, its epilogue, barrier; consumers: input requests, fragment
+    // reads + MFMAs, SiLU + D + readback + stores, pool, barrier
+    uint64_t stv[6] = {0, 0, 0, 0, 0, 0};
+    auto now = [&]() __attribute__((always_inline)) -> uint64_t { if constexpr (STAMP) return __builtin_amdgcn_s_memtime(); else return 0; };
     // the padded tiles, zero rings included (only interiors are ever written afterwards): once per workgroup
     for (int i = tid; i < 8 * ET / 16; i += 768) *reinterpret_cast<uint4*>(lds + S::ET_OFF + i * 16) = make_uint4(0, 0, 0, 0);
 
@@ -795,9 +801,11 @@ __global__ __launch_bounds__(768, 3) void mbfront8r_kernel(MbFront8Args p) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");       // (the consumers: the first sample's input tile has landed)
 #pragma unroll 1
             for (int T = 0; T <= n; ++T) {
+                uint64_t tq = now();
                 if (T < n) {
                     const unsigned char* const xb = lds + (T & 1) * S::XBUF;
                     unsigned char* const et = et0 + (T & 1) * ET;
+                    if constexpr (STAMP) ++stv[0];
 #pragma unroll
                     for (int rb = 0; rb < 2; ++rb) {
                         f32x16 acc;
@@ -821,6 +829,7 @@ __global__ __launch_bounds__(768, 3) void mbfront8r_kernel(MbFront8Args p) {
                             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                             __builtin_amdgcn_sched_barrier(0);
                         }
+                        if constexpr (STAMP) { asm volatile("s_nop 0" ::: "memory"); const uint64_t t2 = now(); stv[1 + 2 * rb] += t2 - tq; tq = t2; }
                         // E = T16(silu(acc + bias)) -> the block's padded tile (16-byte chunk slot = chunk ^ f(y, x))
                         unsigned char* const cell = et + e_cell + rb * (4 * 10 * 64);
 #pragma unroll
@@ -833,15 +842,18 @@ __global__ __launch_bounds__(768, 3) void mbfront8r_kernel(MbFront8Args p) {
                             pk.y = T16<F16>::pack2(v23.x, v23.y);
                             *reinterpret_cast<uint2*>(cell + ((qq ^ e_f) << 4)) = pk;
                         }
+                        if constexpr (STAMP) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const uint64_t t2 = now(); stv[2 + 2 * rb] += t2 - tq; tq = t2; }
                     }
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if constexpr (STAMP) { if (T < n) stv[5] += now() - tq; }
             }
         }
     } else {
         const int cw = wave - 4, blk = cw & 3, half = cw >> 2;      // the channel block and which 16 of its channels
         unsigned char* const et0 = lds + S::ET_OFF + blk * 2 * ET;
         unsigned char* const tbl = lds + S::TBL_OFF + blk * S::TBL_BYTES;
+        float* const red = reinterpret_cast<float*>(lds + S::RED_OFF + cw * 1024);
         // the next sample's input tile: 4 NKT pieces of 1 KiB over the eight consumer waves
         auto dma_x = [&](int smp, int buf) {
             const unsigned char* src = reinterpret_cast<const unsigned char*>(p.x) + (size_t)smp * 64 * CIN * 2;
@@ -868,9 +880,14 @@ __global__ __launch_bounds__(768, 3) void mbfront8r_kernel(MbFront8Args p) {
             d_pix = (yy * 10 + xx) * 64 + (mj & 1) * 8;
             d_f = ((xx >> 2) & 1) | ((yy & 1) << 1);
         }
-        // readback / scratch: lane = pixel (yy, xx) of the map; the wave's two 16-byte chunks of it (its 16 channels) sit at slots (2 half + i) ^ f
-        const int o_pix = et_pix(lane) * 64;
-        const int o_f = (((((lane & 7) + 1) >> 2) & 1) | ((((lane >> 3) + 1) & 1) << 1));
+        // readback: piece i of lane = pixel (lane >> 1) + 32 i, the wave's 16-byte chunk lane & 1 of it (its 16 channels sit at slots
+        // (2 half + chunk) ^ f): a store instruction then writes 32 bytes of 32 pixels (one pixel per lane made it 16 bytes of 64 rows)
+        int o_off[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int px = (lane >> 1) + 32 * i, yy = (px >> 3) + 1, xx = (px & 7) + 1;
+            o_off[i] = (yy * 10 + xx) * 64 + (((2 * half + (lane & 1)) ^ (((xx >> 2) & 1) | ((yy & 1) << 1))) << 4);
+        }
         uint32_t one_lo, one_hi;                                        // (1, 0) / (0, 1) pairs in the storage type
         if constexpr (F16) asm volatile("v_mov_b32 %0, 0x3c00\n\tv_lshlrev_b32 %1, 16, %0" : "=v"(one_lo), "=v"(one_hi));
         else asm volatile("v_mov_b32 %0, 0x3f80\n\tv_lshlrev_b32 %1, 16, %0" : "=v"(one_lo), "=v"(one_hi));
@@ -891,11 +908,24 @@ __global__ __launch_bounds__(768, 3) void mbfront8r_kernel(MbFront8Args p) {
                     af[gl][ky] = wl.place((uint32_t)*reinterpret_cast<const uint16_t*>(tbl + 256 + (ky * 3 + w_d) * 64 + ((2 * half + gl) * 8 + wl.c) * 2));
             dma_x(sbase, 0);
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            // a sample's results leave at the TOP of the next tick, ahead of that tick's input requests: the wait at the bottom of a tick is
+            // then a plain vmcnt(0) with a whole tick between every request and it (stamps: waiting for the pieces in mid-tick, before the
+            // stores, cost the consumers 1 900 cycles of a 6 800-cycle tick -- an input piece lands about 2 000 cycles after its request)
+            uint4 dv[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+            float pool_v = 0.f;
+            auto flush = [&](int smp) __attribute__((always_inline)) {
+                uint16_t* const drow = p.d + ((size_t)smp * 64 + (lane >> 1)) * CEXP + c0 + half * 16 + (lane & 1) * 8;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4*>(drow + (size_t)(32 * i) * CEXP) = dv[i];
+                if (lane < 16) p.pooled[(size_t)smp * CEXP + c0 + half * 16 + lane] = pool_v;
+            };
 #pragma unroll 1
             for (int T = 0; T <= n; ++T) {
+                uint64_t tq = now();
+                if (T >= 2) flush(sbase + T - 2);
                 if (T + 1 < n) dma_x(sbase + T + 1, (T + 1) & 1);
+                if constexpr (STAMP) { if (T >= 1) { ++stv[0]; const uint64_t t2 = now(); stv[1] += t2 - tq; tq = t2; } }
                 if (T >= 1) {
-                    const int smp = sbase + T - 1;
                     unsigned char* const et = et0 + ((T - 1) & 1) * ET;
                     // ---- depthwise 3x3 + bias on the matrix pipe: two tiles of 32 pixels x this wave's two 8-channel groups
                     f32x4 a4[2][2];
@@ -920,6 +950,7 @@ __global__ __launch_bounds__(768, 3) void mbfront8r_kernel(MbFront8Args p) {
                                 a4[gl][t] = c4;
                             }
                     }
+                    if constexpr (STAMP) { asm volatile("s_nop 0" ::: "memory"); const uint64_t t2 = now(); stv[2] += t2 - tq; tq = t2; }
                     // SiLU, one rounding, pooled sums (the pool sees the stored activations), D into the tile's interior in place
                     float psum[2][4];
 #pragma unroll
@@ -938,44 +969,45 @@ __global__ __launch_bounds__(768, 3) void mbfront8r_kernel(MbFront8Args p) {
                             *reinterpret_cast<uint2*>(et + d_pix + (((2 * half + gl) ^ d_f) << 4) + t * (4 * 10 * 64)) = make_uint2(pk0, pk1);
                         }
                     }
-                    uint4 dv[2];
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) dv[i] = *reinterpret_cast<const uint4*>(et + o_pix + (((2 * half + i) ^ o_f) << 4));
-                    // the input-tile pieces this wave requested at the top of the tick have landed long ago; waiting for them HERE, before the
-                    // tick's stores are issued, needs no count (the stores then fly across the barrier)
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    {
-                        uint16_t* const drow = p.d + ((size_t)smp * 64 + lane) * CEXP + c0 + half * 16;
+                    for (int i = 0; i < 2; ++i) dv[i] = *reinterpret_cast<const uint4*>(et + o_off[i]);
+                    if constexpr (STAMP) { const uint64_t t2 = now(); stv[3] += t2 - tq; tq = t2; }
+                    // pooled means: the lanes' sums over their two tiles -> the 32 (pixel pair, pixel) slots in order, / 64, through the wave's
+                    // 1-KiB scratch: slots 0-15, then 16-31 (the order of mbfront8_kernel's walk over all 32)
+                    float tsum = 0.f;
 #pragma unroll
-                        for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4*>(drow + i * 8) = dv[i];
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        if ((mn >> 3) == h2) {
+#pragma unroll
+                            for (int gl = 0; gl < 2; ++gl)
+                                *reinterpret_cast<float4*>(red + (2 * (mn & 7) + ms) * 16 + gl * 8 + 4 * (mj & 1)) = make_float4(psum[gl][0], psum[gl][1], psum[gl][2], psum[gl][3]);
+                        }
+                        if (lane < 16) {
+                            float rv[16];
+#pragma unroll
+                            for (int s2 = 0; s2 < 16; ++s2) rv[s2] = red[s2 * 16 + lane];
+#pragma unroll
+                            for (int s2 = 0; s2 < 16; ++s2) tsum += rv[s2];
+                        }
                     }
-                    // pooled means: the lanes' sums over their two tiles -> the 32 (pixel pair, pixel) slots in order, / 64. Scratch: the wave's
-                    // own 128 cells of 16 bytes in the tile's interior (cell k = pixel k >> 1, chunk 2 half + (k & 1)), as [slot][16 channels] f32
-                    auto cell_at = [&](int pix, int which) __attribute__((always_inline)) {
-                        const int yy = (pix >> 3) + 1, xx = (pix & 7) + 1;
-                        return et + (yy * 10 + xx) * 64 + (((2 * half + which) ^ (((xx >> 2) & 1) | ((yy & 1) << 1))) << 4);
-                    };
-#pragma unroll
-                    for (int gl = 0; gl < 2; ++gl)
-                        *reinterpret_cast<float4*>(cell_at((2 * mn + ms) * 2 + gl, mj & 1)) = make_float4(psum[gl][0], psum[gl][1], psum[gl][2], psum[gl][3]);
-                    if (lane < 16) {
-                        float rv[32];
-#pragma unroll
-                        for (int s2 = 0; s2 < 32; ++s2)
-                            rv[s2] = *(reinterpret_cast<const float*>(cell_at(s2 * 2 + (lane >> 3), (lane >> 2) & 1)) + (lane & 3));
-                        float tsum = 0.f;
-#pragma unroll
-                        for (int s2 = 0; s2 < 32; ++s2) tsum += rv[s2];
-                        p.pooled[(size_t)smp * CEXP + c0 + half * 16 + lane] = tsum / 64.0f;
-                    }
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (first tick: nothing to store, the second sample's pieces land)
+                    pool_v = tsum / 64.0f;
+                    if constexpr (STAMP) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const uint64_t t2 = now(); stv[4] += t2 - tq; tq = t2; }
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                // the pieces requested at the top of the tick have landed (and the previous sample's stores are done)
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if constexpr (STAMP) { if (T >= 1) stv[5] += now() - tq; }
             }
+            flush(sbase + n - 1);
         }
     }
 #undef ISB_MBF8R_SEGMENT
+    if constexpr (STAMP) {
+        if (p.stamps && blockIdx.x < 32 && lane == 0) {
+            uint64_t* o = p.stamps + ((size_t)blockIdx.x * 12 + wave) * 8;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) o[k] = stv[k];
+        }
+    }
 }
 
 // 16-bit weights [N][K] row-major -> MFMA fragment order for register streaming: groups of G 32-channel blocks, k16-major inside
@@ -1049,7 +1081,19 @@ int launch_mbfront8(const MbFront8Args& a, hipStream_t st) {
     // 1 = the first kernel, 2 = roles. ISB_MBF8_FORM overrides the choice (A/B runs, tests).
     static const int env_form = [] { const char* e = getenv("ISB_MBF8_FORM"); return e ? atoi(e) : 0; }();
     const int form = a.form ? a.form : (env_form ? env_form : 2);
-    if (form == 2 && !a.stamps) {
+    if (form == 2 && a.stamps) {
+        if (!a.f16) { set_error("mbfront8r: the stamped instantiation is fp16"); return ISB_ERR_INVALID; }
+        static DevOnce attr_s;
+        if (attr_s.need()) {
+            ISB_HIP(hipFuncSetAttribute((const void*)mbfront8r_kernel<384, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Mf8r<384>::LDS));
+            attr_s.mark();
+        }
+        const int nslots = std::min(32, NSL * cdiv(a.B, 8));
+        hipLaunchKernelGGL((mbfront8r_kernel<384, true, true>), dim3(8 * nslots), dim3(768), Mf8r<384>::LDS, st, aa);
+        ISB_LAUNCHED("mbfront8r (stamped)", st);
+        return ISB_OK;
+    }
+    if (form == 2) {
         static DevOnce attr_r;
         if (attr_r.need()) {
             ISB_HIP(hipFuncSetAttribute((const void*)mbfront8r_kernel<384, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Mf8r<384>::LDS));

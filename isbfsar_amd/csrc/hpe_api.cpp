@@ -1643,9 +1643,9 @@ extern "C" int isb_debug_mbfront(int32_t device, int32_t hw, const uint16_t* x, 
         if (form == 0) ISB_TRY(dE.alloc(nout * 2));
         DevBuf dstamps;
         if (stamps) {
-            ISB_REQUIRE(form == 2 && hw == 16, ISB_ERR_INVALID, "stamps: form 2 of the 16 x 16 front");
-            ISB_TRY(dstamps.alloc(32 * 8 * 4 * 8));
-            ISB_HIP(hipMemset(dstamps.p, 0, 32 * 8 * 4 * 8));
+            ISB_REQUIRE(form == 2, ISB_ERR_INVALID, "stamps: form 2");
+            ISB_TRY(dstamps.alloc(32 * 12 * 8 * 8));
+            ISB_HIP(hipMemset(dstamps.p, 0, 32 * 12 * 8 * 8));
         }
         auto run = [&]() -> int {
             if (form == 0) {
@@ -1665,6 +1665,7 @@ extern "C" int isb_debug_mbfront(int32_t device, int32_t hw, const uint16_t* x, 
                 MbFront8Args a{};
                 a.x = dx.as<uint16_t>(); a.w1p = (const uint4*)dw1p.p; a.b1 = db1.as<float>(); a.dww = ddw.as<uint16_t>(); a.dwb = ddb.as<float>();
                 a.d = dD.as<uint16_t>(); a.pooled = dpool.as<float>(); a.B = B; a.cin = cin; a.f16 = f16; a.form = form;
+                a.stamps = stamps ? dstamps.as<uint64_t>() : nullptr;
                 return launch_mbfront8(a, nullptr);
             }
             MbFront16Args a{};
@@ -1689,7 +1690,28 @@ extern "C" int isb_debug_mbfront(int32_t device, int32_t hw, const uint16_t* x, 
         *ms_per_iter = ms / iters;
         ISB_HIP(hipMemcpy(d_out, dD.p, nout * 2, hipMemcpyDeviceToHost));
         ISB_HIP(hipMemcpy(pooled, dpool.p, (size_t)B * cexp * 4, hipMemcpyDeviceToHost));
-        if (stamps) {
+        if (stamps && hw == 8) {
+            std::vector<uint64_t> st(32 * 12 * 8);
+            ISB_HIP(hipMemcpy(st.data(), dstamps.p, st.size() * 8, hipMemcpyDeviceToHost));
+            const char* names[2][5] = {{"MFMAs of row block 0", "its epilogue", "MFMAs of row block 1", "its epilogue", "barrier"},
+                                       {"input requests", "fragment reads + MFMAs", "SiLU + D + readback + stores", "pool", "barrier"}};
+            for (int role = 0; role < 2; ++role) {
+                double sum[6] = {0, 0, 0, 0, 0, 0};
+                int n = 0;
+                for (int g = 0; g < 32; ++g)
+                    for (int w = role ? 4 : 0; w < (role ? 12 : 4); ++w) {
+                        const uint64_t* o = &st[((size_t)g * 12 + w) * 8];
+                        if (!o[0]) continue;
+                        for (int k = 0; k < 6; ++k) sum[k] += (double)o[k];
+                        ++n;
+                    }
+                if (!n) continue;
+                fprintf(stderr, "mbfront8r %s waves (%d), cycles per tick:", role ? "consumer" : "producer", n);
+                double tot = 0;
+                for (int k = 0; k < 5; ++k) { fprintf(stderr, " %s %.0f |", names[role][k], sum[1 + k] / sum[0]); tot += sum[1 + k] / sum[0]; }
+                fprintf(stderr, " tick %.0f (%.1f ticks per wave)\n", tot, sum[0] / n);
+            }
+        } else if (stamps) {
             std::vector<uint64_t> st(32 * 8 * 4);
             ISB_HIP(hipMemcpy(st.data(), dstamps.p, st.size() * 8, hipMemcpyDeviceToHost));
             for (int role = 0; role < 2; ++role) {

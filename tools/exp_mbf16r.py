@@ -30,5 +30,5 @@ for hw, cin, cexp in ((8, 384, 2304), (16, 224, 1344), (16, 192, 1152), (16, 192
             same = bool(np.array_equal(d, ref[0]) and np.array_equal(pl, ref[1]))
             row.append(f"form {form}: {ms * 1e3:7.1f} us{'' if same else ' (BITS DIFFER)'}")
         print(f"{hw:2d}x{hw:<2d} {cin:3d} -> {cexp:4d}, {B} frames, {iters} launches: " + " | ".join(row), flush=True)
-    if cin == 224 and "--stamps" in sys.argv:
+    if (cin == 224 or hw == 8) and "--stamps" in sys.argv:
         mbfront16_debug(x16, w1, s1, b1, dww, s2, b2, f16=True, form=2 | 0x100, iters=20)
