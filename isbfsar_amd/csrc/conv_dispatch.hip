@@ -62,6 +62,9 @@ static int choose_variant(const ConvArgs& a) {
             2 * a.Cin * 4 + (a.Cout % 192 == 0 || a.M < 16384 ? 6 * 320 : 4 * 448) * 64 + 2048 <= 160 * 1024) {
             // the 8 x 8 stages: 128-row tiles with loader waves, one workgroup per CU (gemm1x1_lw_kernel; bit-identical).
             // 2304 -> 384: 53.7 vs 60.3 us at 256 frames, 39.6 vs 46.7 at 128; 3840 -> 640: 113.7 vs 123.0 / 76.0 vs 84.1
+            // (round 6 sweep, tools/exp_sweep_b1024.py: at 1024 frames -- M = 65 536 -- the A operand no longer stays in the L2 / Infinity
+            // Cache between the N tiles and two plain 128 x 192 workgroups per CU beat the loader-wave form, 214 vs 222-232 us on 2304 -> 384)
+            if (a.Cout % 192 == 0 && a.M >= 65536) return 141;
             return (a.Cout % 192 == 0 || a.M < 16384) ? 155 : 156;
         }
         if (ohw % 64 == 0 && a.Cout % 64 == 0 && ((a.Cout % 192 == 0 && wgs128 <= 256) || (a.Cout % 320 == 0 && wgs128 < 256))) return 146;

@@ -6,6 +6,14 @@ tag=$1; shift
 match=$1; shift
 mkdir -p gpurun_out/pmc_$tag
 i=0
+# PMC_SETS="set one;set two;..." replaces the default SQ / LDS sets (e.g. the L2-side sets of tools/pmc_l2.sh)
+if [ -n "$PMC_SETS" ]; then
+  IFS=';' read -ra SETS <<< "$PMC_SETS"
+  for set in "${SETS[@]}"; do
+    i=$((i+1))
+    timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmc_$tag -o set$i -- python3 "$@" > gpurun_out/pmc_$tag/set$i.log 2>&1 || { tail -3 gpurun_out/pmc_$tag/set$i.log; }
+  done
+else
 for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
            "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS" \
@@ -14,6 +22,7 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_I
   i=$((i+1))
   timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmc_$tag -o set$i -- python3 "$@" > gpurun_out/pmc_$tag/set$i.log 2>&1 || { tail -3 gpurun_out/pmc_$tag/set$i.log; }
 done
+fi
 python3 - <<PY
 import csv, glob, collections
 agg=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.Counter()
