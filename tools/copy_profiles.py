@@ -34,4 +34,9 @@ for src, dst in (("pmc_fetch", "hpe_b256_fetch_size"), ("pmc_write", "hpe_b256_w
         for r in csv.DictReader(f):
             w.writerow([r["Dispatch_Id"], r["Kernel_Name"][:80], r["Grid_Size"], r["Workgroup_Size"], r["Counter_Name"],
                         r["Counter_Value"]])
+for src, dst in (("pmc_l2/l2_table.txt", "l2_counters_hpe_b256_onelane.txt"), ("pmc_l2/summary.txt", "l2_counters_hpe_b256_onelane_raw.txt"),
+                 ("fronts_three_forms.txt", "fused_fronts_three_forms.txt"), ("pmc_fronts/summary.txt", "fused_fronts_sq_lds_counters.txt"),
+                 ("ab_mbf16_forms.txt", "ab_kernels_mbfront16_form1_vs_form2.txt"), ("ab_mbf8_forms.txt", "ab_kernels_mbfront8_form1_vs_form2.txt")):
+    if os.path.exists(f"{G}/{src}"):
+        shutil.copy(f"{G}/{src}", f"{P}/{tag}_{dst}")
 print("copied to", P)

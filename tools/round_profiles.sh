@@ -49,4 +49,11 @@ python3 tools/collect_mfma.py gpurun_out/mfma_ar.json gpurun_out/pmc_mfma_ar/run
 echo "== SQ counters of the three MFMA-bound early-stage kernels (VERDICT r3 item 5), own pass"
 ISB_BENCH_INFLIGHT=1 ISB_HPE_LANES=1 timeout -k 10 300 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d gpurun_out/pmc_lds_hpe -o run -- python3 bench.py --workload hpe --steps 1 --warmup 1 --no-cpu-baseline --no-extras --min-gpu-seconds 0 > gpurun_out/pmc_lds_hpe.log 2>&1 || true
 python3 tools/collect_lds.py gpurun_out/lds_hpe.json gpurun_out/pmc_lds_hpe/run_counter_collection.csv || true
+echo "== round 6: L2-side counters of a one-lane pose pass (VERDICT r5 item 4), the fused fronts alone (three forms, stamps, SQ / LDS counters)"
+bash tools/pmc_l2.sh > gpurun_out/pmc_l2_run.log 2>&1 || true
+PYTHONPATH=. timeout -k 10 300 python3 tools/exp_mbf16r.py 256 200 3 --stamps > gpurun_out/fronts_three_forms.txt 2>&1 || true
+PYTHONPATH=. bash tools/pmc_any.sh fronts mbfront tools/exp_mbf16r.py 256 5 1 > gpurun_out/pmc_fronts_run.log 2>&1 || true
+echo "== per-kernel A/B of the fused fronts' forms in the network (one-lane traces)"
+bash tools/ab_kernels.sh ISB_MBF16_FORM 1 2 hpe > gpurun_out/ab_mbf16_forms.txt 2>&1 || true
+bash tools/ab_kernels.sh ISB_MBF8_FORM 1 2 hpe > gpurun_out/ab_mbf8_forms.txt 2>&1 || true
 echo done
