@@ -10,7 +10,7 @@ import sys
 def load(p):
     out = {}
     for r in csv.DictReader(open(p)):
-        name = re.sub(r"\(.*", "", r["Name"]).replace("isb::", "").replace("(anonymous namespace)::", "")
+        name = re.sub(r"\(.*", "", r["Name"].replace("(anonymous namespace)::", "")).replace("isb::", "")
         out[name] = (int(r["Calls"]), float(r["TotalDurationNs"]))
     return out
 
