@@ -336,7 +336,6 @@ def mbfront_debug(x16, w1, scale1, shift1, dww, dwscale, dwshift, f16=False, for
     return d, pooled, float(ms.value)
 
 
-mbfront16_debug = mbfront_debug
 
 
 def dwconv_debug(x_bf16, w, scale, shift, stride=1, iters=1, device=0, in_f16=False, out_f16=False, general=False):

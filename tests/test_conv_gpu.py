@@ -731,7 +731,7 @@ def test_fused_front_16x16_forms_are_bit_identical(B, cin, cexp, f16):
     6: producer / consumer waves, four per SIMD, units cut into ranges that may cross a slice boundary -- the batch sizes here give
     ranges of one, several and a fractional number of samples per workgroup, XCDs with fewer samples than others, and 1344 = 10.5
     slices). Same arithmetic and summation orders: D and the pooled means bit for bit."""
-    from isbfsar_amd.hpe_engine import f32_to_f16, mbfront16_debug
+    from isbfsar_amd.hpe_engine import f32_to_f16, mbfront_debug
     rng = np.random.default_rng(B * 7 + cin + cexp + int(f16))
     x = rng.normal(0, 1, (B, 16, 16, cin)).astype(np.float32)
     w1 = (rng.normal(0, 1, (cexp, cin)) / np.sqrt(cin)).astype(np.float32)
@@ -741,10 +741,10 @@ def test_fused_front_16x16_forms_are_bit_identical(B, cin, cexp, f16):
     s2 = rng.uniform(0.8, 1.2, cexp).astype(np.float32)
     b2 = rng.uniform(-0.1, 0.1, cexp).astype(np.float32)
     x16 = f32_to_f16(x) if f16 else f32_to_bf16(x)
-    d0, p0, _ = mbfront16_debug(x16, w1, s1, b1, dww, s2, b2, f16=f16, form=0)
+    d0, p0, _ = mbfront_debug(x16, w1, s1, b1, dww, s2, b2, f16=f16, form=0)
     assert np.abs(p0).max() > 0 and np.isfinite(p0).all()
     for form in (1, 2):
-        d, pl, _ = mbfront16_debug(x16, w1, s1, b1, dww, s2, b2, f16=f16, form=form, iters=2)
+        d, pl, _ = mbfront_debug(x16, w1, s1, b1, dww, s2, b2, f16=f16, form=form, iters=2)
         assert np.array_equal(d, d0), (form, float(np.mean(d != d0)))
         assert np.array_equal(pl, p0), (form, float(np.abs(pl - p0).max()))
 

@@ -5,7 +5,7 @@ import sys
 
 import numpy as np
 
-from isbfsar_amd.hpe_engine import f32_to_f16, mbfront16_debug
+from isbfsar_amd.hpe_engine import f32_to_f16, mbfront_debug
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 B = int(args[0]) if len(args) > 0 else 256
@@ -24,11 +24,11 @@ for hw, cin, cexp in ((8, 384, 2304), (16, 224, 1344), (16, 192, 1152), (16, 192
     for rd in range(rounds):
         row = []
         for form in (0, 1, 2):
-            d, pl, ms = mbfront16_debug(x16, w1, s1, b1, dww, s2, b2, f16=True, form=form, iters=iters)
+            d, pl, ms = mbfront_debug(x16, w1, s1, b1, dww, s2, b2, f16=True, form=form, iters=iters)
             if ref is None:
                 ref = (d, pl)
             same = bool(np.array_equal(d, ref[0]) and np.array_equal(pl, ref[1]))
             row.append(f"form {form}: {ms * 1e3:7.1f} us{'' if same else ' (BITS DIFFER)'}")
         print(f"{hw:2d}x{hw:<2d} {cin:3d} -> {cexp:4d}, {B} frames, {iters} launches: " + " | ".join(row), flush=True)
     if (cin == 224 or hw == 8) and "--stamps" in sys.argv:
-        mbfront16_debug(x16, w1, s1, b1, dww, s2, b2, f16=True, form=2 | 0x100, iters=20)
+        mbfront_debug(x16, w1, s1, b1, dww, s2, b2, f16=True, form=2 | 0x100, iters=20)
