@@ -187,8 +187,8 @@ void isb_hpe_destroy(isb_hpe* h);
  * isb_hpe_set_lanes(h, 1) every launch covers the whole batch) pays one model + K workspaces instead of K of each, and gets the same
  * bits as one engine run batch after batch. The child copies the parent's configuration (device, precision, max_batch, lanes at the
  * time of the call); isb_hpe_load_weights / isb_hpe_set_joint_map are refused on a child (ISB_ERR_STATE) and, on the parent, wait for
- * the device and update the model every engine of the family reads. Either may be destroyed first. Needs a hardware queue per stream in
- * flight: isb_hw_queues(). */
+ * the device and update the model every engine of the family reads. Either may be destroyed first. A family is ONE host thread's (the
+ * handles share host-side state of the model as well as its device memory). Needs a hardware queue per stream in flight: isb_hw_queues(). */
 int isb_hpe_create_shared(isb_hpe* parent, isb_hpe** out);
 /* device memory behind a handle: bytes of the model it reads (shared by *engines_on_model handles), bytes of the workspaces it owns
  * (allocated lazily by the first passes). Any output may be NULL. */

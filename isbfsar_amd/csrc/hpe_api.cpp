@@ -116,7 +116,7 @@ struct isb_hpe {
     double K[9] = {0};
     // weights: ONE device copy per engine family (isb_hpe_create_shared: the children hold the parent's model)
     std::shared_ptr<HpeModel> m;
-    isb_hpe* parent = nullptr;    // non-null in an engine made by isb_hpe_create_shared (informational: the model is kept alive by `m`)
+    bool is_child = false;        // an engine made by isb_hpe_create_shared: it reads a model it may not replace (the model is kept alive by `m`)
     // test-time augmentation tables (hpe.py:88-93); n_aug = 0: off
     int n_aug = 0;
     DevBuf aug_rotflip, aug_scale;
@@ -609,7 +609,7 @@ extern "C" int isb_hpe_create_shared(isb_hpe* parent, isb_hpe** out) {
     h->cfg = parent->cfg;
     memcpy(h->K, parent->K, sizeof(h->K));
     h->m = parent->m;                         // (the model outlives whichever of the two is destroyed first)
-    h->parent = parent;
+    h->is_child = true;
     // the plan switches select which packed weight images exist: a child runs the parent's plan
     h->mb8_on = parent->mb8_on; h->dwmm16 = parent->dwmm16; h->stamp16 = parent->stamp16; h->mbf16_on = parent->mbf16_on;
     h->fmb_rege = parent->fmb_rege; h->dwmm_on = parent->dwmm_on; h->mbf8_on = parent->mbf8_on;
@@ -674,7 +674,7 @@ extern "C" int isb_hpe_load_weights(isb_hpe* h, const void* blob, size_t nbytes)
     return isb::guard([&]() -> int {
     ISB_REQUIRE(h, ISB_ERR_INVALID, "null handle");
     ISB_REQUIRE(!h->slot[0].busy && !h->slot[1].busy, ISB_ERR_STATE, "submitted host batches are outstanding: isb_hpe_wait_host first");
-    ISB_REQUIRE(!h->parent, ISB_ERR_STATE, "isb_hpe_load_weights on an engine made by isb_hpe_create_shared: load into the parent (the family reads one model)");
+    ISB_REQUIRE(!h->is_child, ISB_ERR_STATE, "isb_hpe_load_weights on an engine made by isb_hpe_create_shared: load into the parent (the family reads one model)");
     ISB_HIP(hipSetDevice(h->cfg.device));
     ISB_HIP(hipDeviceSynchronize());           // engines that share this model may have passes in flight on their own streams
     hipStream_t st = h->own_stream;
@@ -850,7 +850,7 @@ extern "C" int isb_hpe_set_joint_map(isb_hpe* h, const float* expand, const int3
     ISB_REQUIRE(n_out >= 1 && n_out <= 122, ISB_ERR_INVALID, "n_out %d outside [1,122]", n_out);
     ISB_REQUIRE(indices || n_out == 122, ISB_ERR_INVALID, "without indices n_out must be 122");
     ISB_REQUIRE(!h->slot[0].busy && !h->slot[1].busy, ISB_ERR_STATE, "submitted host batches are outstanding: isb_hpe_wait_host first");
-    ISB_REQUIRE(!h->parent, ISB_ERR_STATE, "isb_hpe_set_joint_map on an engine made by isb_hpe_create_shared: set it on the parent (the family reads one model)");
+    ISB_REQUIRE(!h->is_child, ISB_ERR_STATE, "isb_hpe_set_joint_map on an engine made by isb_hpe_create_shared: set it on the parent (the family reads one model)");
     if (indices)
         for (int i = 0; i < n_out; ++i)
             ISB_REQUIRE(indices[i] >= 0 && indices[i] < 122, ISB_ERR_INVALID, "joint index %d outside [0,122)", indices[i]);
