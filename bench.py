@@ -213,6 +213,12 @@ def main():
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run as {args.gpus} GPUs",
               file=sys.stderr)
         raise SystemExit(2)
+    # stdout carries ONE JSON line and nothing else: librccl prints a version banner to file descriptor 1 when a communicator is created
+    # (RCCL 2.26: "RCCL version : ..." and four more lines), which would stand in front of the line. From here on fd 1 IS stderr for
+    # every library of this process; the line goes to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
     # rehearsal of the N > 1 code path on a ONE-GPU box: ISB_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
@@ -331,7 +337,8 @@ def main():
             # and the bit-for-bit check of the gathered records against an unsharded recomputation
             "rccl_ranks": rccl_ranks, "gather_check": gather_check,
         }
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist_on:
         import torch.distributed as dist
         dist.destroy_process_group()
