@@ -32,13 +32,15 @@ def parent():
     import torch
     from oracle import hpe_oracle as ho
     from oracle.effnetv2_oracle import EffNetV2LOracle
-    torch.set_num_threads(os.cpu_count() or 8)
+    from bench_workloads import usable_cores          # (the cgroup's share, not the host's core count: oversubscribed torch crawls)
+    torch.set_num_threads(usable_cores())
     W = np.load(os.path.join(ROOT, "isbfsar_amd", "assets", "32_to_122.npy"))
     fr, bb = synth.frames(N, seed=0), synth.bboxes(N, seed=0)
     crops = np.stack([ho.warp(fr[b], ho.crop_params(bb[b], K())[2][0]) for b in range(N)])
     out = {}
     t0 = time.time()
     for prof, st in states().items():
+        print(f"oracle, profile {prof} ...", flush=True)
         net = EffNetV2LOracle(st, "f32")
         lg = np.concatenate([net.head(net.backbone(crops[i:i + 16])) for i in range(0, N, 16)])
         poses = [ho.postprocess(lg[j:j + 1], *ho.crop_params(bb[j], K())[:2], W, None) for j in range(N)]
@@ -48,7 +50,7 @@ def parent():
     os.makedirs(os.path.dirname(REFS), exist_ok=True)
     np.savez(REFS, n=N, **out)
     print(f"fp32 oracle: {N} frames x 2 profiles in {time.time() - t0:.1f} s", flush=True)
-    for v in ("0", "1", "2", "0", "1", "2"):
+    for v in ("0", "1", "2"):
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=dict(os.environ, ISB_STEM_SILU=v), capture_output=True, text=True)
         print(r.stdout.strip() or r.stderr[-600:], flush=True)
 
