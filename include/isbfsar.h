@@ -373,6 +373,13 @@ int isb_debug_mbfront(int32_t device, int32_t hw, const uint16_t* h_x, const flo
                       const float* h_dww, const float* h_dwscale, const float* h_dwshift, int32_t B, int32_t cin, int32_t cexp,
                       int32_t f16, int32_t form, int32_t iters, uint16_t* h_d, float* h_pooled, float* ms_per_iter);
 
+/* test hook: the squeeze-excite FCs of a batch on host tensors -- gate[b][c] = sigmoid(b2[c] + sum_j silu(b1[j] + sum_c' pooled[b][c']
+ * w1[j][c']) w2t[j][c]) with the fixed summation orders of the pose path (256-channel chunks, four hidden-unit quarters; a sample's gate
+ * does not depend on the batch it arrives in).
+ *   h_pooled f32 [B,C], h_w1 f32 [cse,C], h_b1 [cse], h_w2t f32 [cse,C], h_b2 [C] -> h_gate f32 [B,C]; C a multiple of 4, at most 3840; cse <= 160. */
+int isb_debug_se_fcs(int32_t device, const float* h_pooled, const float* h_w1, const float* h_b1, const float* h_w2t, const float* h_b2,
+                     int32_t B, int32_t C, int32_t cse, int32_t iters, float* h_gate, float* ms_per_iter);
+
 /* ------------------------------------------------------------------------------------------
  * Glue between the two stages (main.py:102-105 + ar.py:42-50): root-centre every pose on joint 0,
  * flatten to 3J and cut sliding windows of L consecutive frames per camera.

@@ -112,6 +112,7 @@ SIGNATURES = {
     "isb_debug_gemm_f32": (C.c_int, [C.c_int32] + [_P] * 5 + [C.c_int32] * 10 + [_P, C.POINTER(C.c_float)]),
     "isb_debug_mbfront": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_int32, _P, _P, C.POINTER(C.c_float)]),
+    "isb_debug_se_fcs": (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.POINTER(C.c_float)]),
     "isb_debug_dwconv": (C.c_int, [C.c_int32] + [_P] * 4 + [C.c_int32] * 5 + [_P, _P, C.POINTER(C.c_float)]),
     "isb_debug_dwconv_fc1": (C.c_int, [C.c_int32] + [_P] * 4 + [C.c_int32] * 5 + [_P, _P, C.POINTER(C.c_float), _P, C.c_int32, _P,
                                        C.POINTER(C.c_int32)]),

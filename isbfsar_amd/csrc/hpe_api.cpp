@@ -1599,6 +1599,46 @@ extern "C" int isb_debug_fused_mb(int32_t device, const uint16_t* x, const float
 // test / tuning hook: the FRONT half of a stride-1 MBConv block on 16 x 16 or 8 x 8 maps (1x1 expand + BN + SiLU -> depthwise 3x3 + BN +
 // SiLU -> D + squeeze-excite pool) on host tensors, three ways that must give the same bits: form 0 = the two launches (expand GEMM, then
 // dwconv3x3_mm_kernel), 1 = mbfront16_kernel / mbfront8_kernel, 2 = mbfront16r_kernel / mbfront8r_kernel (conv_mb16.hip, conv_mb8.hip)
+// The squeeze-excite FCs of a batch on their own (tests): pooled [B,C] f32, w1 [cse,C], b1 [cse], w2t [cse,C], b2 [C] -> gate [B,C]
+// through launch_se_fcs (se_fc1_part_kernel + se_fc2_kernel).
+extern "C" int isb_debug_se_fcs(int32_t device, const float* pooled, const float* w1, const float* b1, const float* w2t, const float* b2,
+                                int32_t B, int32_t C, int32_t cse, int32_t iters, float* gate, float* ms_per_iter) {
+    return isb::guard([&]() -> int {
+        ISB_REQUIRE(pooled && w1 && b1 && w2t && b2 && gate && ms_per_iter, ISB_ERR_INVALID, "null argument");
+        ISB_REQUIRE(B >= 1 && iters >= 1 && C >= 4 && cse >= 1, ISB_ERR_INVALID, "bad parameters");
+        ISB_HIP(hipSetDevice(device));
+        DevBuf dp, dw1, db1, dw2, db2, dpart, dgate;
+        ISB_TRY(upload(dp, pooled, (size_t)B * C * 4));
+        ISB_TRY(upload(dw1, w1, (size_t)cse * C * 4));
+        ISB_TRY(upload(db1, b1, (size_t)cse * 4));
+        ISB_TRY(upload(dw2, w2t, (size_t)cse * C * 4));
+        ISB_TRY(upload(db2, b2, (size_t)C * 4));
+        ISB_TRY(dpart.alloc((size_t)B * 160 * 32 * 4));
+        ISB_TRY(dgate.alloc((size_t)B * C * 4));
+        ISB_HIP(hipMemset(dgate.p, 0xff, (size_t)B * C * 4));
+        ISB_HIP(hipMemset(dpart.p, 0xff, (size_t)B * 160 * 32 * 4));
+        SeFcArgs se{};
+        se.pooled = dp.as<float>(); se.w1 = dw1.as<float>(); se.b1 = db1.as<float>(); se.w2t = dw2.as<float>(); se.b2 = db2.as<float>();
+        se.part = dpart.as<float>(); se.gate = dgate.as<float>(); se.B = B; se.C = C; se.cse = cse;
+        ISB_TRY(launch_se_fcs(se, nullptr));
+        ISB_HIP(hipDeviceSynchronize());
+        hipEvent_t e0, e1;
+        ISB_HIP(hipEventCreate(&e0));
+        ISB_HIP(hipEventCreate(&e1));
+        ISB_HIP(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < iters; ++i) ISB_TRY(launch_se_fcs(se, nullptr));
+        ISB_HIP(hipEventRecord(e1, nullptr));
+        ISB_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        ISB_HIP(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        *ms_per_iter = ms / iters;
+        ISB_HIP(hipMemcpy(gate, dgate.p, (size_t)B * C * 4, hipMemcpyDeviceToHost));
+        return ISB_OK;
+    });
+}
+
 extern "C" int isb_debug_mbfront(int32_t device, int32_t hw, const uint16_t* x, const float* w1, const float* scale1, const float* shift1,
                                  const float* dww, const float* dwscale, const float* dwshift, int32_t B, int32_t cin, int32_t cexp,
                                  int32_t f16, int32_t form, int32_t iters, uint16_t* d_out, float* pooled, float* ms_per_iter) {

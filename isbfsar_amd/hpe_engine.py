@@ -338,6 +338,19 @@ def mbfront_debug(x16, w1, scale1, shift1, dww, dwscale, dwshift, f16=False, for
 
 
 
+def se_fcs_debug(pooled, w1, b1, w2t, b2, iters=1, device=0):
+    """The squeeze-excite FCs of a batch through isb_debug_se_fcs: pooled f32 [B,C], w1 [cse,C], b1 [cse], w2t [cse,C], b2 [C].
+    Returns (gate f32 [B,C], ms per pair of launches)."""
+    arrs = [np.ascontiguousarray(a, dtype=np.float32) for a in (pooled, w1, b1, w2t, b2)]
+    B, Cc = arrs[0].shape
+    cse = arrs[1].shape[0]
+    gate = np.empty((B, Cc), np.float32)
+    ms = C.c_float()
+    _lib.check(_lib.lib().isb_debug_se_fcs(device, _ptr(arrs[0]), _ptr(arrs[1]), _ptr(arrs[2]), _ptr(arrs[3]), _ptr(arrs[4]), B, Cc, cse,
+                                           int(iters), _ptr(gate), C.byref(ms)), "isb_debug_se_fcs")
+    return gate, float(ms.value)
+
+
 def dwconv_debug(x_bf16, w, scale, shift, stride=1, iters=1, device=0, in_f16=False, out_f16=False, general=False):
     """Depthwise 3x3 + SiLU + SE mean through isb_debug_dwconv. x_bf16 uint16 [B,H,H,C], w f32 [C,3,3].
     Returns (out uint16 [B,H/stride,H/stride,C], pooled f32 [B,C], ms_per_launch). in_f16: x and the taps are fp16;

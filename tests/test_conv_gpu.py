@@ -772,3 +772,27 @@ def test_fused_front_8x8_forms_are_bit_identical(B, f16):
         d, pl, _ = mbfront_debug(x16, w1, s1, b1, dww, s2, b2, f16=f16, form=form, iters=2)
         assert np.array_equal(d, d0), (form, float(np.mean(d != d0)))
         assert np.array_equal(pl, p0), (form, float(np.abs(pl - p0).max()))
+
+
+@pytest.mark.parametrize("B,C,cse", [(256, 2304, 96), (64, 768, 48), (33, 3840, 160), (9, 384, 24), (130, 1344, 56), (8, 2304, 96), (1, 1152, 48)])
+def test_squeeze_excite_fcs_against_the_f64_definition_and_under_sharding(B, C, cse):
+    """se_fc1_part_kernel + se_fc2_kernel on their own (isb_debug_se_fcs): gate = sigmoid(b2 + W2 silu(b1 + W1 pooled)) within f32 rounding
+    of the f64 definition, and a sample's gate bit for bit the same whether it arrives alone, in a part of the batch or in all of it
+    (both kernels sum in orders that depend on the layer alone; B <= 8 takes the prefetching FC2 form)."""
+    from isbfsar_amd.hpe_engine import se_fcs_debug
+    rng = np.random.default_rng(B * 7 + C + cse)
+    pooled = rng.normal(0, 0.5, (B, C)).astype(np.float32)
+    w1 = (rng.normal(0, 1, (cse, C)) / np.sqrt(C)).astype(np.float32)
+    b1 = rng.uniform(-0.3, 0.3, cse).astype(np.float32)
+    w2t = (rng.normal(0, 1, (cse, C)) / np.sqrt(cse)).astype(np.float32)
+    b2 = rng.uniform(-0.5, 0.5, C).astype(np.float32)
+    g, _ = se_fcs_debug(pooled, w1, b1, w2t, b2)
+    mid = pooled.astype(np.float64) @ w1.T.astype(np.float64) + b1
+    mid = mid / (1.0 + np.exp(-mid))
+    want = 1.0 / (1.0 + np.exp(-(mid @ w2t.astype(np.float64) + b2)))
+    assert np.abs(g - want).max() < 2e-5
+    cut = max(1, B // 3)
+    for lo, hi in ((0, cut), (cut, B), (B - 1, B)):
+        if hi > lo:
+            part, _ = se_fcs_debug(pooled[lo:hi], w1, b1, w2t, b2)
+            assert np.array_equal(part, g[lo:hi]), (lo, hi)
