@@ -99,15 +99,16 @@ def _disassemble(lib_path: str) -> str:
 
 def mbfront8_wait_counted(lib_path: str):
     """mbfront8_kernel (csrc/conv_mb8.hip) waits for the next sample's LDS-DMA input tiles with a hand-counted
-    `s_waitcnt vmcnt(5)`: exactly five vector-memory operations (four 16-byte D-row stores, one pooled-means store) may be
+    `s_waitcnt vmcnt(5)`: exactly five vector-memory operations (four 16-byte D-row stores, one 16-byte pooled-means store) may be
     issued between those requests and the wait. vmcnt(N) waits until all but the N YOUNGEST vector-memory operations are done, so
     the dangerous direction is FEWER operations behind the requests than counted (a store the compiler merged or dropped: the wait
     would then let a tile piece stay in flight at the barrier and the MFMAs would read stale LDS -- silently); MORE
     operations (spill traffic, a split store) only make the wait stricter, but they also mean the code is not the code that was
     measured, so the check is an exact match either way and a future edit must not relax it towards "at most". So the built
-    code is checked: every instantiation must be free of scratch instructions and hold exactly four global_store_dwordx4 and
-    one global_store_dword between its loop's LDS-DMA requests and the end of the loop body (the stamp stores of the tuning
-    probe follow the loop). Returns None when the library passes, else the reason."""
+    code is checked: every instantiation must be free of scratch instructions and hold exactly five global_store_dwordx4
+    between its loop's LDS-DMA requests and the end of the loop body (the stamp stores of the tuning probe follow the loop;
+    until the pool moved to dw_mm.h's butterfly the fifth was a global_store_dword). Returns None when the library passes, else
+    the reason."""
     text = _disassemble(lib_path)
     if not text.startswith("\n"):
         return text
@@ -134,9 +135,9 @@ def mbfront8_wait_counted(lib_path: str):
             return f"{name}: no global_load_lds_dwordx4 found -- the input requests are lowered differently than the check knows"
         vm = [o for o in ops[last_dma + 1:] if o.startswith(("global_", "buffer_", "flat_"))]
         body = vm[:5]
-        if sorted(body) != ["global_store_dword"] + ["global_store_dwordx4"] * 4:
-            return f"{name}: expected four global_store_dwordx4 + one global_store_dword behind the input requests, found {vm[:8]}"
-        if any(not o.startswith("global_store_dwordx") for o in vm[5:]):      # (behind the loop: only the probe's stamp stores)
+        if body != ["global_store_dwordx4"] * 5:
+            return f"{name}: expected five global_store_dwordx4 behind the input requests, found {vm[:8]}"
+        if any(o not in ("global_store_dwordx2", "flat_store_dwordx2") for o in vm[5:]):      # (behind the loop: only the probe's 8-byte stamp stores, volatile in the source)
             return f"{name}: vector-memory operations besides the five stores behind the input requests: {vm[5:]}"
     return None
 

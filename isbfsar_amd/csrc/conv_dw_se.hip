@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_map_kernel(DwArgs p) {
 // wave owns CPW channels of the slab for ALL pixels: per 8-channel group and 32-pixel tile, three 16-byte fragment reads + three
 // v_mfma_f32_16x16x32 replace 288 v_dot2 (per lane: 4 outputs instead of 32 per pass, 7 vector instructions per output instead of
 // 17). The 16-bit results are staged in LDS and leave as full pixel rows; pooled means: per lane over its tiles in order, then the
-// 32 (pixel pair, pixel) slots in order.
+// 32 (pixel pair, pixel) lanes in dw_mm.h's butterfly.
 // LDS images: in  [TW x TW pixels][RB bytes], 16-byte chunk slot = chunk ^ f(y, x) with f chosen so that the sixteen lanes a
 //                 ds_read_b128 serves together (pixels 2n + j of two rows) fall into sixteen different slots;
 //             out [HW x HW pixels][RB bytes], chunk slot = chunk ^ (pixel >> 1).
@@ -474,20 +474,13 @@ __global__ __launch_bounds__(256, 2) void dwconv3x3_mm_kernel(DwArgs p) {
     }
     __syncthreads();                                        // every fragment read is done: the input image is free
     if (p.pooled) {
-        // pooled means, one fixed order (the fused front of the 8 x 8 blocks, conv_mb8.hip, walks the same one): a lane's sums over
-        // its tiles, then the 32 (pixel pair, pixel) slots in order -- through a per-wave scratch in the freed input image
-        float* const red = reinterpret_cast<float*>(tin + wave * (32 * CPW * 4));       // [slot = 2 n + s][CPW channels]
+        // pooled means, one fixed order (the fused fronts walk the same one): a lane's sums over its tiles, then dw_mm.h's butterfly over
+        // the 32 lanes that hold the same channels; lanes 0 and 16 (pixel pair 0, first pixel: the two channel halves) store
+        const int xaddr = (lane ^ 32) << 2;
 #pragma unroll
-        for (int g = 0; g < GPW; ++g)
-            *reinterpret_cast<float4*>(red + (2 * n + s) * CPW + g * 8 + 4 * (j & 1)) = make_float4(psum[g][0], psum[g][1], psum[g][2], psum[g][3]);
-        if (lane < CPW) {
-            float rv[32];
-#pragma unroll
-            for (int q = 0; q < 32; ++q) rv[q] = red[q * CPW + lane];
-            float tsum = 0.f;
-#pragma unroll
-            for (int q = 0; q < 32; ++q) tsum += rv[q];
-            p.pooled[(size_t)b * p.C + c0 + wave * CPW + lane] = tsum / (float)(HW * HW);
+        for (int g = 0; g < GPW; ++g) {
+            const float4 tot = dwmm_pool_sum4(psum[g], xaddr, 1.0f / (float)(HW * HW));
+            if ((lane & 47) == 0) *reinterpret_cast<float4*>(p.pooled + (size_t)b * p.C + c0 + wave * CPW + g * 8 + 4 * (j & 1)) = tot;
         }
     }
 #pragma unroll

@@ -15,7 +15,7 @@
 //                ring's zero columns): per 8-channel group three 16-byte fragment reads + three v_mfma_f32_16x16x32 (dw_mm.h),
 //                bias as the C operand, SiLU, one rounding, pooled sums, the two D rows through the two ring rows that just died.
 // Arithmetic and summation orders are those of the expand GEMM (k ascending in one accumulator) and of dwconv3x3_mm_kernel<16>
-// (tap MFMAs, lane sums over the bands in order, then the 32 (pixel pair, pixel) slots in order): bit-identical to that two-launch
+// (tap MFMAs, lane sums over the bands in order, then dw_mm.h's butterfly over the 32 (pixel pair, pixel) lanes): bit-identical to that two-launch
 // path (tested), which is what batches below the threshold run.
 #include "conv_tiles.h"
 #include "dw_mm.h"
@@ -252,24 +252,15 @@ __global__ __launch_bounds__(256, 3) void mbfront16_kernel(MbFront16Args p) {
         }
         uint64_t tp = 0;
         if (p.stamps) tp = __builtin_amdgcn_s_memtime();
-        // ---- pooled means: the lanes' sums over the eight bands -> the 32 (pixel pair, pixel) slots in order (dwconv3x3_mm_kernel's
-        // walk), / 256. Scratch: 4 KiB over the interiors of ring rows 0 .. 3 (every interior pixel is rewritten or zeroed before the
-        // next sample reads it; the zero columns are not touched)
-        auto red_at = [&](int fl) __attribute__((always_inline)) {        // float index -> address
-            const int o = fl * 4;
-            return reinterpret_cast<float*>(et + (o >> 10) * ET_ROW + 64 + (o & 1023));
-        };
+        // ---- pooled means: the lanes' sums over the eight bands -> dw_mm.h's butterfly over the 32 (pixel pair, pixel) lanes
+        // (dwconv3x3_mm_kernel's order), / 256; lane (pair g < 4, first pixel) stores group g's four channels of its channel half
+        {
+            const int xaddr = (lane ^ 32) << 2;
+            float4 tot[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<float4*>(red_at((2 * mn + ms) * 32 + g * 8 + 4 * (mj & 1))) = make_float4(psum[g][0], psum[g][1], psum[g][2], psum[g][3]);
-        if (lane < 32 && live) {
-            float rv[32];
-#pragma unroll
-            for (int s2 = 0; s2 < 32; ++s2) rv[s2] = *red_at(s2 * 32 + lane);
-            float t = 0.f;
-#pragma unroll
-            for (int s2 = 0; s2 < 32; ++s2) t += rv[s2];
-            p.pooled[(size_t)smp * CEXP + c0 + lane] = t / 256.0f;
+            for (int g = 0; g < 4; ++g) tot[g] = dwmm_pool_sum4(psum[g], xaddr, 1.0f / 256.0f);
+            const float4 mine = sel4(mn < 2, sel4(mn == 0, tot[0], tot[1]), sel4(mn == 2, tot[2], tot[3]));
+            if (mn < 4 && ms == 0 && live) *reinterpret_cast<float4*>(p.pooled + (size_t)smp * CEXP + c0 + mn * 8 + 4 * (mj & 1)) = mine;
         }
         if (p.stamps) stp[6] += __builtin_amdgcn_s_memtime() - tp;
     }
@@ -307,7 +298,7 @@ __global__ __launch_bounds__(256, 3) void mbfront16_kernel(MbFront16Args p) {
 // sits in one of two neighbouring rows) is folded into its base address, so every ring offset is an immediate -- except where the
 // two rows wrap around the ring (slots 7 -> 0: two fragment reads and two staging steps per sample pay one vector add).
 // Arithmetic and orders are the first kernel's (k ascending in one accumulator; tap MFMAs; lane sums over the bands in order, then the
-// 32 slots in order): bit-identical to it and to the two-launch path (tested).
+// butterfly over the 32 lanes): bit-identical to it and to the two-launch path (tested).
 // Work: units (slice, sample) of an XCD's samples in slice-major order, cut into equal contiguous ranges for the XCD's 64 workgroup
 // slots (a range that crosses a slice boundary drains and reloads: at most one of the 64 per boundary).
 template <int CIN>
@@ -573,30 +564,14 @@ __global__ __launch_bounds__(512, 4) void mbfront16r_kernel(MbFront16Args p) {
                             }
                         }
                         if (s == 8) {
-                            // pooled means: the lanes' sums over the eight bands -> the 32 (pixel pair, pixel) slots in order, / 256. Scratch: the
-                            // interiors of the two rows the D rows just left through (2 KiB = 16 slots x 32 channels): slots 0-15, then 16-31
-                            auto red_at = [&](int fl) __attribute__((always_inline)) {    // float index -> address
-                                const int o = fl * 4;
-                                return reinterpret_cast<float*>(ring + ((o >> 10) ? d_r1 : d_r0) + 64 + (o & 1023));
-                            };
-                            float tsum = 0.f;
+                            // pooled means: the lanes' sums over the eight bands -> dw_mm.h's butterfly over the 32 (pixel pair, pixel) lanes,
+                            // / 256; lane (pair g < 4, first pixel) stores group g's four channels of its channel half
+                            const int xaddr = (lane ^ 32) << 2;
+                            float4 tot[4];
 #pragma unroll
-                            for (int half = 0; half < 2; ++half) {
-                                if ((mn >> 3) == half) {
-#pragma unroll
-                                    for (int g = 0; g < 4; ++g)
-                                        *reinterpret_cast<float4*>(red_at((2 * (mn & 7) + ms) * 32 + g * 8 + 4 * (mj & 1))) =
-                                            make_float4(psum[g][0], psum[g][1], psum[g][2], psum[g][3]);
-                                }
-                                if (lane < 32) {
-                                    float rv[16];
-#pragma unroll
-                                    for (int s2 = 0; s2 < 16; ++s2) rv[s2] = *red_at(s2 * 32 + lane);
-#pragma unroll
-                                    for (int s2 = 0; s2 < 16; ++s2) tsum += rv[s2];
-                                }
-                            }
-                            if (lane < 32) p.pooled[(size_t)smp * CEXP + c0 + lane] = tsum / 256.0f;
+                            for (int g = 0; g < 4; ++g) tot[g] = dwmm_pool_sum4(psum[g], xaddr, 1.0f / 256.0f);
+                            const float4 mine = sel4(mn < 2, sel4(mn == 0, tot[0], tot[1]), sel4(mn == 2, tot[2], tot[3]));
+                            if (mn < 4 && ms == 0) *reinterpret_cast<float4*>(p.pooled + (size_t)smp * CEXP + c0 + mn * 8 + 4 * (mj & 1)) = mine;
                         }
                     }
                     tick_barrier(false);

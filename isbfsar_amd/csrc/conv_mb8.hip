@@ -694,28 +694,22 @@ __global__ __launch_bounds__(256, 2) void mbfront8_kernel(MbFront8Args p) {
             *reinterpret_cast<uint4*>(drow + (size_t)(oy * 8 + ox0 + o) * CEXP) = v;
         }
         if (p.stamps) { ti = __builtin_amdgcn_s_memtime(); st_ph[6] += ti - th; }
-        // pool: the lanes' sums over their two tiles -> the 32 (pixel pair, pixel) slots in order (dwconv3x3_mm_kernel's walk), / 64
-        float* const red = reinterpret_cast<float*>(et + 11 * 64);       // 4 KiB over the tile's interior (and ring pixels, re-zeroed below)
+        // pool: the lanes' sums over their two tiles -> dw_mm.h's butterfly over the 32 (pixel pair, pixel) lanes, / 64 (dwconv3x3_mm_kernel's
+        // order). ONE 16-byte store (the counted wait above numbers this sample's stores): lane (pair g < 4, first pixel) stores group g's
+        // four channels of its channel half
+        {
+            const int xaddr = (lane ^ 32) << 2;
+            float4 tot[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<float4*>(red + (2 * mn + ms) * 32 + g * 8 + 4 * (mj & 1)) = make_float4(psum[g][0], psum[g][1], psum[g][2], psum[g][3]);
-        if (lane < 32) {
-            float rv[32];
-#pragma unroll
-            for (int s2 = 0; s2 < 32; ++s2) rv[s2] = red[s2 * 32 + lane];
-            float t = 0.f;
-#pragma unroll
-            for (int s2 = 0; s2 < 32; ++s2) t += rv[s2];
-            p.pooled[(size_t)smp * CEXP + c0 + lane] = t / 64.0f;
-        }
-        if (lane < 48) {                                            // the ring pixels the sums overlapped: 19, 20, 29, 30, ..., 69, 70
-            const int qi = lane >> 2, ch = lane & 3;
-            *reinterpret_cast<uint4*>(et + (19 + 10 * (qi >> 1) + (qi & 1)) * 64 + ch * 16) = make_uint4(0, 0, 0, 0);
+            for (int g = 0; g < 4; ++g) tot[g] = dwmm_pool_sum4(psum[g], xaddr, 1.0f / 64.0f);
+            const float4 mine = sel4(mn < 2, sel4(mn == 0, tot[0], tot[1]), sel4(mn == 2, tot[2], tot[3]));
+            if (mn < 4 && ms == 0) *reinterpret_cast<float4*>(p.pooled + (size_t)smp * CEXP + c0 + mn * 8 + 4 * (mj & 1)) = mine;
         }
         if (p.stamps) { const uint64_t tf = __builtin_amdgcn_s_memtime(); st_body += tf - tb; st_ph[3] += tf - te; st_ph[7] += tf - ti; }
     }
     if (p.stamps && blockIdx.x < 32 && lane == 0) {
-        uint64_t* o = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 16;
+        // (volatile: 8-byte stores, one per stamp -- the build's check of the counted wait tells them from the loop's 16-byte stores)
+        volatile uint64_t* o = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 16;
         o[0] = __builtin_amdgcn_s_memtime() - st_t0; o[1] = st_wait; o[2] = st_body; o[3] = (uint64_t)it;
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[4 + i] = st_ph[i];
@@ -745,8 +739,7 @@ struct Mf8r {
     static constexpr int ET_OFF = 2 * XBUF;                 // [4 blocks][2 buffers]
     static constexpr int TBL_OFF = ET_OFF + 8 * ET;
     static constexpr int TBL_BYTES = 1024;                  // per channel block: bias [32] f32 | depthwise bias [32] f32 at 128 | taps [9][32] 16-bit at 256
-    static constexpr int RED_OFF = TBL_OFF + 4 * TBL_BYTES; // per consumer wave 1 KiB: the pool's scratch, [16 slots][16 channels] f32
-    static constexpr int LDS = RED_OFF + 8 * 1024;
+    static constexpr int LDS = TBL_OFF + 4 * TBL_BYTES;
     static_assert(LDS <= 160 * 1024, "one workgroup per CU");
 };
 
@@ -853,7 +846,6 @@ __global__ __launch_bounds__(768, 3) void mbfront8r_kernel(MbFront8Args p) {
         const int cw = wave - 4, blk = cw & 3, half = cw >> 2;      // the channel block and which 16 of its channels
         unsigned char* const et0 = lds + S::ET_OFF + blk * 2 * ET;
         unsigned char* const tbl = lds + S::TBL_OFF + blk * S::TBL_BYTES;
-        float* const red = reinterpret_cast<float*>(lds + S::RED_OFF + cw * 1024);
         // the next sample's input tile: 4 NKT pieces of 1 KiB over the eight consumer waves
         auto dma_x = [&](int smp, int buf) {
             const unsigned char* src = reinterpret_cast<const unsigned char*>(p.x) + (size_t)smp * 64 * CIN * 2;
@@ -912,12 +904,14 @@ __global__ __launch_bounds__(768, 3) void mbfront8r_kernel(MbFront8Args p) {
             // then a plain vmcnt(0) with a whole tick between every request and it (stamps: waiting for the pieces in mid-tick, before the
             // stores, cost the consumers 1 900 cycles of a 6 800-cycle tick -- an input piece lands about 2 000 cycles after its request)
             uint4 dv[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
-            float pool_v = 0.f;
+            float4 pool_v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int xaddr = (lane ^ 32) << 2;
             auto flush = [&](int smp) __attribute__((always_inline)) {
                 uint16_t* const drow = p.d + ((size_t)smp * 64 + (lane >> 1)) * CEXP + c0 + half * 16 + (lane & 1) * 8;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4*>(drow + (size_t)(32 * i) * CEXP) = dv[i];
-                if (lane < 16) p.pooled[(size_t)smp * CEXP + c0 + half * 16 + lane] = pool_v;
+                // (lane = pair gl < 2, first pixel: group gl's four channels of its channel half)
+                if (mn < 2 && ms == 0) *reinterpret_cast<float4*>(p.pooled + (size_t)smp * CEXP + c0 + half * 16 + mn * 8 + 4 * (mj & 1)) = pool_v;
             };
 #pragma unroll 1
             for (int T = 0; T <= n; ++T) {
@@ -972,25 +966,9 @@ __global__ __launch_bounds__(768, 3) void mbfront8r_kernel(MbFront8Args p) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i) dv[i] = *reinterpret_cast<const uint4*>(et + o_off[i]);
                     if constexpr (STAMP) { const uint64_t t2 = now(); stv[3] += t2 - tq; tq = t2; }
-                    // pooled means: the lanes' sums over their two tiles -> the 32 (pixel pair, pixel) slots in order, / 64, through the wave's
-                    // 1-KiB scratch: slots 0-15, then 16-31 (the order of mbfront8_kernel's walk over all 32)
-                    float tsum = 0.f;
-#pragma unroll
-                    for (int h2 = 0; h2 < 2; ++h2) {
-                        if ((mn >> 3) == h2) {
-#pragma unroll
-                            for (int gl = 0; gl < 2; ++gl)
-                                *reinterpret_cast<float4*>(red + (2 * (mn & 7) + ms) * 16 + gl * 8 + 4 * (mj & 1)) = make_float4(psum[gl][0], psum[gl][1], psum[gl][2], psum[gl][3]);
-                        }
-                        if (lane < 16) {
-                            float rv[16];
-#pragma unroll
-                            for (int s2 = 0; s2 < 16; ++s2) rv[s2] = red[s2 * 16 + lane];
-#pragma unroll
-                            for (int s2 = 0; s2 < 16; ++s2) tsum += rv[s2];
-                        }
-                    }
-                    pool_v = tsum / 64.0f;
+                    // pooled means: the lanes' sums over their two tiles -> dw_mm.h's butterfly over the 32 (pixel pair, pixel) lanes, / 64
+                    // (through the wave's LDS scratch, one lane per channel walking the slots, this was 1 250-1 500 cycles of the tick)
+                    pool_v = sel4(mn == 0, dwmm_pool_sum4(psum[0], xaddr, 1.0f / 64.0f), dwmm_pool_sum4(psum[1], xaddr, 1.0f / 64.0f));
                     if constexpr (STAMP) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const uint64_t t2 = now(); stv[4] += t2 - tq; tq = t2; }
                 }
                 // the pieces requested at the top of the tick have landed (and the previous sample's stores are done)

@@ -43,13 +43,28 @@ struct DwmmLane {
     }
 };
 
-// sum over the 16 lanes of a DPP row (row_ror 8, 4, 2, 1), the total in every lane
-__device__ __forceinline__ float dwmm_row16_sum(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+// The pool's cross-lane sum (round 6): v summed over the 32 lanes that hold the same channels as this one -- lanes n + 16 (j & 1) + 32 s
+// for the pixel pairs n = 0..15 and the two pixels s of a pair -- in ONE fixed butterfly: n ^ 1, n ^ 2 (quad permutes: every lane of a
+// quad then holds the quad's sum), 7 - n within each 8 (pairs the quads), 15 - n within the 16, then lane ^ 32. Both lanes of a pair add
+// the same two values (f32 addition commutes), so all 32 end with the same bits; five dependent adds per value, no LDS image, no barrier.
+// EVERY kernel that pools a dw_mm result uses it (dwconv3x3_mm_kernel, both forms of both fused fronts): the order is part of the
+// arithmetic they share. Before: each lane's sums went through a per-wave LDS scratch and one lane per channel walked the 32 slots in
+// order -- 1 250-1 500 of the 6 500 cycles of mbfront8r's consumer tick. xaddr = (lane ^ 32) << 2.
+__device__ __forceinline__ float dwmm_pool_sum(float v, int xaddr) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));   // row_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(xaddr, __builtin_bit_cast(int, v)));
     return v;
 }
+
+// the four channels 4 (j & 1) .. + 3 of group g, pooled: scale = 1 / pixels of the map (a power of two: the product is the quotient)
+__device__ __forceinline__ float4 dwmm_pool_sum4(const float (&ps)[4], int xaddr, float scale) {
+    return make_float4(dwmm_pool_sum(ps[0], xaddr) * scale, dwmm_pool_sum(ps[1], xaddr) * scale, dwmm_pool_sum(ps[2], xaddr) * scale,
+                       dwmm_pool_sum(ps[3], xaddr) * scale);
+}
+
+__device__ __forceinline__ float4 sel4(bool c, float4 a, float4 b) { return make_float4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w); }
 
 }  // namespace isb

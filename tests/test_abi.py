@@ -149,7 +149,9 @@ def test_mbfront8_counted_wait_is_guarded_by_the_build(built_lib):
         orig = build._disassemble
         try:
             first = next(i for i, ln in enumerate(lines) if "mbfront8_kernel" in ln and ln.rstrip().endswith(">:"))
-            body_store = next(i for i in range(first, len(lines)) if "global_store_dword " in lines[i] or lines[i].split()[:1] == ["global_store_dword"])
+            end = next((i for i in range(first + 1, len(lines)) if lines[i].rstrip().endswith(">:")), len(lines))
+            last_dma = max(i for i in range(first, end) if "global_load_lds_dwordx4" in lines[i])
+            body_store = next(i for i in range(last_dma, end) if "global_store_dwordx4" in lines[i])      # one of the sample's five stores
             doctored = lines[:body_store] + [lines[body_store]] + lines[body_store:]
             build._disassemble = lambda _p: "\n".join(doctored)
             assert build.mbfront8_wait_counted(built_lib) is not None
