@@ -54,6 +54,31 @@ def latest_traffic_json():
     return found[-1] if found else None
 
 
+def latest_power(workload: str, achieved=None, peak=None):
+    """profiles/rNN_power_<workload>.txt of the latest round (tools/power_probe.sh: rocm-smi samples beside a 400-600-step run of the
+    workload) as the roofline line's `power` object, or None. The pose and pipeline steps run AT the package power cap: the clock the
+    governor leaves is below the 2.4 GHz `peak` is priced at, so the object also carries achieved / (peak x sclk / 2400)."""
+    import glob
+    import re
+    found = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r[0-9][0-9]_power_{workload}.txt")))
+    if not found:
+        return None
+    try:
+        text = open(found[-1]).read()
+        m = re.search(r"median / max ([\d.]+) / ([\d.]+) / ([\d.]+) W; sclk as rocm-smi reports it (\d+) / (\d+) / (\d+) MHz", text)
+        cap = re.search(r"package power cap ([\d.]+) W", text)
+        if not m:
+            return None
+        out = {"what": "rocm-smi samples (0.2 s) beside a 400-600-step run of this workload in the round's profile session, not this run",
+               "package_w_median": float(m.group(2)), "package_w_cap": float(cap.group(1)) if cap else None,
+               "sclk_mhz_median": int(m.group(5)), "source": "profiles/" + os.path.basename(found[-1])}
+        if achieved and peak:
+            out["frac_at_that_clock"] = round(achieved / (peak * int(m.group(5)) / 2400.0), 4)
+        return out
+    except (OSError, ValueError):
+        return None
+
+
 def median_time(fn, warm: int = 3, iters: int = 10):
     """BASELINE.md 4 protocol: `warm` untimed passes, then the MEDIAN wall time of `iters` timed ones.
     Returns (median seconds per pass, total seconds spent)."""
@@ -295,6 +320,7 @@ class _HpeBase:
                 "algorithmic_bytes": alg, "traffic_over_algorithmic": round(traffic / alg, 3) if traffic else None,
                 "avg_launch_ms": round(ms / max(launches, 1), 5), "launches": int(launches),
                 "flops_per_step": flops / steps,
+                "power": latest_power("hpe", achieved, MFMA_PEAK_TFLOPS_BF16),
                 # the fused MBConv fronts (mbfront8 / mbfront16) are family launches that carry their blocks' depthwise + SiLU + pool work:
                 # every fusion of that kind moves time INTO the family and takes a depthwise launch away. Comparable across rounds:
                 "with_depthwise": {
@@ -496,6 +522,7 @@ class PipelineWorkload(_HpeBase):
                              "traffic": traffic, "traffic_unit": "HBM bytes of ONE 1024-window launch, way 60 (PMC, `--workload ar`)",
                              "algorithmic_bytes": ar_proto_algorithmic_bytes(1024, 60, self.L),
                              "traffic_over_algorithmic": round(traffic / ar_proto_algorithmic_bytes(1024, 60, self.L), 2) if traffic else None}
+        r["power"] = latest_power("pipeline", r.get("achieved"), MFMA_PEAK_TFLOPS_BF16) or r.get("power")
         return r
 
     def step_flops(self):
